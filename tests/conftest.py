@@ -1,0 +1,75 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fixture_reads():
+    """The reference's 99,000 fixture reads as columns (tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "fixture_reads.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def fixture_regions(fixture_reads):
+    """grgenes (20) + 30 seeded ranges; returns (regions json, ranges dict of int32 arrays)."""
+    reg = json.load(open(os.path.join(GOLDEN, "regions.json")))
+    names = [str(s) for s in fixture_reads["ref_names"]]
+    ranges = dict(
+        rid=np.asarray([names.index(c) for c in reg["chrom"]], dtype=np.int32),
+        loc=np.asarray(reg["start"], dtype=np.int32) - 1,
+        len=np.asarray(reg["width"], dtype=np.int32),
+        strand=np.asarray([{"+": 1, "-": -1}.get(s, 0) for s in reg["strand"]], dtype=np.int32),
+    )
+    return reg, ranges
+
+
+@pytest.fixture(scope="session")
+def expected_grid():
+    z = np.load(os.path.join(GOLDEN, "expected_grid.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def expected_extra():
+    z = np.load(os.path.join(GOLDEN, "expected_extra.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def parse_key(key):
+    """'profile|shift=0,mapq=0,ss=1,pe=filter,tf=50_200' -> (kind, dict)."""
+    kind, rest = key.split("|")
+    d = dict(kv.split("=") for kv in rest.split(","))
+    out = dict(pe=d["pe"], tf=None if d["tf"] == "NULL" else (50, 200), mapq=int(d["mapq"]))
+    if "shift" in d:
+        out["shift"] = int(d["shift"])
+    if "ss" in d:
+        out["ss"] = bool(int(d["ss"]))
+    return kind, out
+
+
+def core_args(kind, p):
+    """User-level parameters -> native arguments, as R/wrappers.R:76-173 does."""
+    pe = p["pe"]
+    req = 66 if pe != "ignore" else 0
+    tlf = () if pe == "ignore" else ((0, 1000) if p["tf"] is None else p["tf"])
+    if kind == "coverage":
+        return dict(tlen_filter=tlf, mapqual=p["mapq"], requiredF=req, filteredF=-1, tspan=(pe == "extend"))
+    a = dict(tlen_filter=tlf, mapqual=p["mapq"], shift=p["shift"], ss=p.get("ss", False), requiredF=req,
+             filteredF=-1, pe_mid=(pe == "midpoint"))
+    a["binsize"] = 1 if kind == "profile" else -1
+    if kind == "ff16":
+        a["filteredF"] = 16
+    return a
