@@ -1,0 +1,38 @@
+// Launchers of the gfx950 kernels (kernels.hip), used by the host runtime (runtime.hip).
+#ifndef BSIG_KERNELS_H
+#define BSIG_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bamsignals_abi.h"
+#include "bsig_types.h"
+
+namespace bsig {
+
+struct ScatterPtrs {
+    int32_t *pos[BSIG_MAX_CLASSES];
+    int32_t *end[BSIG_MAX_CLASSES];
+    uint32_t *fm[BSIG_MAX_CLASSES];
+    int32_t *tlen[BSIG_MAX_CLASSES];
+    uint32_t *gb[BSIG_MAX_CLASSES];
+    int32_t kshift[BSIG_MAX_CLASSES];
+};
+
+hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, const BsigKParams &P,
+                         const BsigWorkItem *items, int64_t n_items, int tile_cells,
+                         int32_t *out, hipStream_t st);
+hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag, const int64_t *cigar_off,
+                            const uint32_t *cigar, int32_t *end_out, hipStream_t st);
+int64_t prep_chunks(int64_t n);
+hipError_t launch_span_hist(int64_t n, const int32_t *pos, const int32_t *end, uint32_t *chunk_counts,
+                            int32_t *maxspan, hipStream_t st);
+hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, const uint32_t *ref_unit0,
+                          const uint32_t *ref_units, const int32_t *pos, const int32_t *end,
+                          const uint16_t *flag, const uint8_t *mapq, const int32_t *tlen,
+                          const uint64_t *chunk_base, const ScatterPtrs &S, hipStream_t st);
+hipError_t launch_build_idx(int64_t n, const uint32_t *gb, uint64_t n_buckets, uint32_t *idx, hipStream_t st);
+hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
+                         int64_t n_items, unsigned long long *acc, hipStream_t st);
+
+}  // namespace bsig
+#endif

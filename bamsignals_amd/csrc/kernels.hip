@@ -1,0 +1,612 @@
+// gfx950 (MI355X, CDNA4) kernels for the bamsignals interval-counting hot path.
+//
+// Replaces the per-read loop of overlapAndPileup<T> (reference src/bamsignals.cpp:240-291)
+// with one workgroup per *tile* of a range: bins staged in LDS, 16-B coalesced loads of the
+// read columns, LDS integer atomics for the histogram, 16-B coalesced stores of the result.
+// Pure 32-bit integer work, HBM-bound: no MFMA anywhere.
+//
+//   k_profile   Pileupper::setRead/pileup       src/bamsignals.cpp:326-363  (binsize >= 1)
+//   k_count     the same with binsize <= 0      src/bamsignals.cpp:148-169, 349-363
+//   k_coverage  Coverager::setRead/pileup+cumsum src/bamsignals.cpp:392-438, 464-470
+//   k_cigar_end bam_endpos - 1 from packed CIGAR (htslib; call site src/bamsignals.cpp:16-18)
+//   k_span_hist / k_scatter / k_build_idx       one-time layout of the reads in HBM (bsig_types.h)
+//   k_visits    counts read visits for the roofline figure
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bsig_types.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------
+
+// The filter of Pileupper::setRead (src/bamsignals.cpp:328-333) == Coverager::setRead (:394-399).
+__device__ __forceinline__ bool read_rejected(const BsigKParams &P, uint32_t fm, int32_t tl)
+{
+    const uint32_t nf = ~(fm & 0xFFFFu);                 // ~flag after int promotion
+    const int mapq = (int)((fm >> 16) & 0xFFu);
+    bool rej = (mapq < P.mapqual) | ((P.requiredF & nf) != 0u) | ((P.filteredF & nf) == 0u);
+    if (P.has_tlen_filter) {
+        const int a = tl < 0 ? -tl : tl;
+        rej |= (a < P.tf0) | (a > P.tf1);
+    }
+    return rej;
+}
+
+// Reads of class C that can touch the genomic interval [tlo, thi) lie in [j_lo, j_hi).
+// pos in [tlo - ext - maxspan + 1, thi + ext), rounded outwards to index buckets.
+__device__ __forceinline__ bool class_window(const BsigClassCols &C, const BsigWorkItem &w,
+                                             int64_t tlo, int64_t thi, int ext,
+                                             uint32_t &j_lo, uint32_t &j_hi)
+{
+    int64_t wlo = tlo - ext - C.maxspan + 1;
+    int64_t whi = thi + ext;
+    const int64_t ref_bp = (int64_t)(w.units_strand & 0x3FFFFFFFu) << BSIG_REF_UNIT_SHIFT;
+    if (wlo < 0) wlo = 0;
+    if (whi > ref_bp) whi = ref_bp;
+    if (wlo >= whi) return false;
+    const uint64_t g0 = (uint64_t)w.ref_unit0 << BSIG_REF_UNIT_SHIFT;
+    const uint64_t b_lo = (g0 + (uint64_t)wlo) >> C.kshift;
+    const uint64_t b_hi = (g0 + (uint64_t)whi - 1) >> C.kshift;
+    j_lo = C.idx[b_lo];
+    j_hi = C.idx[b_hi + 1];
+    return j_lo < j_hi;
+}
+
+// genomic interval covered by a profile/coverage tile (cells [c0, c0+nc) in range orientation)
+__device__ __forceinline__ void tile_interval(const BsigWorkItem &w, int binsize, bool neg_range,
+                                              int64_t &tlo, int64_t &thi)
+{
+    const int64_t a = (int64_t)w.c0 * binsize;
+    int64_t b = ((int64_t)w.c0 + w.nc) * binsize;
+    if (b > w.len) b = w.len;
+    if (neg_range) { tlo = (int64_t)w.loc + w.len - b; thi = (int64_t)w.loc + w.len - a; }
+    else           { tlo = (int64_t)w.loc + a;         thi = (int64_t)w.loc + b; }
+}
+
+template <int NT>
+__device__ __forceinline__ void block_sync()
+{
+    // a 64-thread workgroup is one wave: LDS operations of a wave execute in order
+    if (NT > kWave) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Store nv values that sit at lds[sh .. sh+nv) to out[out_off .. out_off+nv): the LDS image is
+// shifted by sh = out_off & 3 so that 16-B LDS vectors line up with 16-B aligned global addresses.
+__device__ __forceinline__ void store_vec(int32_t *__restrict__ gbase, int v, int4 x, int sh, int nv)
+{
+    const int e0 = 4 * v;
+    if (e0 >= sh && e0 + 4 <= sh + nv) {
+        *reinterpret_cast<int4 *>(gbase + e0) = x;
+    } else {
+        const int lo = sh, hi = sh + nv;
+        if (e0 + 0 >= lo && e0 + 0 < hi) gbase[e0 + 0] = x.x;
+        if (e0 + 1 >= lo && e0 + 1 < hi) gbase[e0 + 1] = x.y;
+        if (e0 + 2 >= lo && e0 + 2 < hi) gbase[e0 + 2] = x.z;
+        if (e0 + 3 >= lo && e0 + 3 < hi) gbase[e0 + 3] = x.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bamProfile: per-bin counts of 5' ends
+// ------------------------------------------------------------------------------------------
+template <int NT, bool SS>
+__global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const BsigKParams P,
+                                                const BsigWorkItem *__restrict__ items,
+                                                int32_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    constexpr int S = SS ? 2 : 1;
+    const int tid = threadIdx.x;
+    const BsigWorkItem w = items[blockIdx.x];
+    const int nv = w.nc * S;
+    const int sh = (int)(w.out_off & 3);
+    const int nvec = (sh + nv + 3) >> 2;
+    int4 *lds4 = reinterpret_cast<int4 *>(lds);
+
+    for (int v = tid; v < nvec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    block_sync<NT>();
+
+    const bool neg_range = (w.units_strand >> 30) & 1u;
+    int64_t tlo, thi;
+    tile_interval(w, P.binsize, neg_range, tlo, thi);
+
+    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
+        if (!valid || read_rejected(P, fm, tl)) return;
+        const bool neg = (fm & 0x10u) != 0u;                          // isNegStrand (:11-13)
+        const int a = tl < 0 ? -tl : tl;
+        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;  // :339
+        const int p5 = neg ? e - offset : p + offset;                  // :340-344
+        int rel = p5 - w.loc;                                          // :351
+        if ((unsigned)rel >= (unsigned)w.len) return;                  // :353
+        int anti = neg ? 1 : 0;
+        if (neg_range) { rel = w.len - rel - 1; anti ^= 1; }           // :356-359
+        const int cell = P.binsize == 1 ? rel
+                                        : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
+        const int lc = cell - w.c0;
+        if ((unsigned)lc < (unsigned)w.nc)
+            atomicAdd(&lds[sh + lc * S + (SS ? anti : 0)], 1);         // :361-362
+    };
+
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        if (C.n == 0) continue;
+        uint32_t j_lo, j_hi;
+        if (!class_window(C, w, tlo, thi, P.ext, j_lo, j_hi)) continue;
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
+            const int4 p4 = *reinterpret_cast<const int4 *>(C.pos + j);
+            const int4 e4 = *reinterpret_cast<const int4 *>(C.end + j);
+            const uint4 f4 = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t4 = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t4 = *reinterpret_cast<const int4 *>(C.tlen + j);
+            one(p4.x, e4.x, f4.x, t4.x, true);
+            one(p4.y, e4.y, f4.y, t4.y, j + 1 < j_hi);
+            one(p4.z, e4.z, f4.z, t4.z, j + 2 < j_hi);
+            one(p4.w, e4.w, f4.w, t4.w, j + 3 < j_hi);
+        }
+    }
+    block_sync<NT>();
+
+    int32_t *gbase = out + (w.out_off - sh);
+    for (int v = tid; v < nvec; v += NT) store_vec(gbase, v, lds4[v], sh, nv);
+}
+
+// ------------------------------------------------------------------------------------------
+// bamCount: one (or two, strand-specific) counters per range
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKParams P,
+                                              const BsigWorkItem *__restrict__ items,
+                                              int32_t *__restrict__ out)
+{
+    __shared__ int32_t wsum[2 * (NT / kWave)];
+    const int tid = threadIdx.x;
+    const BsigWorkItem w = items[blockIdx.x];
+    const bool neg_range = (w.units_strand >> 30) & 1u;
+    const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
+    const int gn = w.nc;
+    int c_sense = 0, c_anti = 0;
+
+    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
+        if (!valid || read_rejected(P, fm, tl)) return;
+        const bool neg = (fm & 0x10u) != 0u;
+        const int a = tl < 0 ? -tl : tl;
+        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
+        const int p5 = neg ? e - offset : p + offset;
+        if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
+        if (neg != neg_range) ++c_anti; else ++c_sense;
+    };
+
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        if (C.n == 0) continue;
+        uint32_t j_lo, j_hi;
+        if (!class_window(C, w, (int64_t)glo, (int64_t)glo + gn, P.ext, j_lo, j_hi)) continue;
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
+            const int4 p4 = *reinterpret_cast<const int4 *>(C.pos + j);
+            const int4 e4 = *reinterpret_cast<const int4 *>(C.end + j);
+            const uint4 f4 = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t4 = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t4 = *reinterpret_cast<const int4 *>(C.tlen + j);
+            one(p4.x, e4.x, f4.x, t4.x, true);
+            one(p4.y, e4.y, f4.y, t4.y, j + 1 < j_hi);
+            one(p4.z, e4.z, f4.z, t4.z, j + 2 < j_hi);
+            one(p4.w, e4.w, f4.w, t4.w, j + 3 < j_hi);
+        }
+    }
+    // wave reduction, then across the waves of the workgroup
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        c_sense += __shfl_down(c_sense, d);
+        c_anti += __shfl_down(c_anti, d);
+    }
+    if (NT > kWave) {
+        if ((tid & (kWave - 1)) == 0) { wsum[2 * (tid / kWave)] = c_sense; wsum[2 * (tid / kWave) + 1] = c_anti; }
+        __syncthreads();
+        if (tid == 0) {
+            c_sense = 0; c_anti = 0;
+            for (int k = 0; k < NT / kWave; ++k) { c_sense += wsum[2 * k]; c_anti += wsum[2 * k + 1]; }
+        }
+    }
+    if (tid == 0) {
+        const bool atomic = (w.units_strand >> 31) & 1u;
+        int32_t *o = out + w.out_off;
+        if (P.ss) {
+            if (atomic) { if (c_sense) atomicAdd(o, c_sense); if (c_anti) atomicAdd(o + 1, c_anti); }
+            else        { o[0] = c_sense; o[1] = c_anti; }
+        } else {
+            if (atomic) { if (c_sense + c_anti) atomicAdd(o, c_sense + c_anti); }
+            else        { o[0] = c_sense + c_anti; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bamCoverage: +1/-1 difference array in LDS, workgroup prefix scan, coalesced store
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const BsigKParams P,
+                                                 const BsigWorkItem *__restrict__ items,
+                                                 int32_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    // per-wave scan totals live behind the tile image, inside the dynamic region, so that the
+    // image itself starts at the 16-B aligned LDS base
+    int32_t *wtot = lds + P.tile_cells + 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const BsigWorkItem w = items[blockIdx.x];
+    const int nv = w.nc;
+    const int sh = (int)(w.out_off & 3);
+    const int nvec = (sh + nv + 3) >> 2;
+    int4 *lds4 = reinterpret_cast<int4 *>(lds);
+
+    for (int v = tid; v < nvec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    block_sync<NT>();
+
+    const bool neg_range = (w.units_strand >> 30) & 1u;
+    int64_t tlo, thi;
+    tile_interval(w, 1, neg_range, tlo, thi);
+    const int rend1 = w.loc + w.len - 1;     // last base of the range
+
+    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
+        if (!valid || read_rejected(P, fm, tl)) return;
+        int start = p, end = e;                                       // :401-403
+        if (P.tspan) {                                                // :404-413
+            const bool neg = (fm & 0x10u) != 0u;
+            if (neg && tl < 0) start = end + tl + 1;
+            else if (!neg && tl > 0) end = start + tl - 1;
+        }
+        // covered cells [ra, rb] in range orientation (:423-436), then relative to the tile
+        const int ra = neg_range ? rend1 - end : start - w.loc;
+        const int rb = neg_range ? rend1 - start : end - w.loc;
+        const int la = ra - w.c0, lb = rb - w.c0;
+        if (la >= w.nc || lb < 0) return;                             // :420
+        atomicAdd(&lds[sh + (la > 0 ? la : 0)], 1);
+        if (lb + 1 < w.nc) atomicAdd(&lds[sh + lb + 1], -1);
+    };
+
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        if (C.n == 0) continue;
+        uint32_t j_lo, j_hi;
+        if (!class_window(C, w, tlo, thi, P.ext, j_lo, j_hi)) continue;
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
+            const int4 p4 = *reinterpret_cast<const int4 *>(C.pos + j);
+            const int4 e4 = *reinterpret_cast<const int4 *>(C.end + j);
+            const uint4 f4 = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t4 = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t4 = *reinterpret_cast<const int4 *>(C.tlen + j);
+            one(p4.x, e4.x, f4.x, t4.x, true);
+            one(p4.y, e4.y, f4.y, t4.y, j + 1 < j_hi);
+            one(p4.z, e4.z, f4.z, t4.z, j + 2 < j_hi);
+            one(p4.w, e4.w, f4.w, t4.w, j + 3 < j_hi);
+        }
+    }
+    block_sync<NT>();
+
+    // cumsum (:464-470): each lane owns 4 consecutive cells, wave scan of the lane totals,
+    // carry across waves and across passes
+    int32_t *gbase = out + (w.out_off - sh);
+    int carry = 0;
+    for (int base = 0; base < nvec; base += NT) {
+        const int v = base + tid;
+        int4 x = v < nvec ? lds4[v] : make_int4(0, 0, 0, 0);
+        x.y += x.x; x.z += x.y; x.w += x.z;
+        const int tot = x.w;
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        int pre = carry;
+        int all = __shfl(incl, kWave - 1);
+        if (NT > kWave) {
+            if (lane == kWave - 1) wtot[tid / kWave] = incl;
+            __syncthreads();
+            all = 0;
+            for (int k = 0; k < NT / kWave; ++k) {
+                const int t = wtot[k];
+                if (k < tid / kWave) pre += t;
+                all += t;
+            }
+            __syncthreads();
+        }
+        const int add = pre + incl - tot;
+        x.x += add; x.y += add; x.z += add; x.w += add;
+        if (v < nvec) store_vec(gbase, v, x, sh, nv);
+        carry += all;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one-time layout of the reads in HBM
+// ------------------------------------------------------------------------------------------
+
+// bam_endpos(b) - 1 (htslib): sum of M(0) D(2) N(3) =(7) X(8) lengths; 0x4 or empty -> 1 base.
+__global__ void k_cigar_end(int64_t n, const int32_t *__restrict__ pos,
+                            const uint16_t *__restrict__ flag,
+                            const int64_t *__restrict__ cigar_off,
+                            const uint32_t *__restrict__ cigar, int32_t *__restrict__ end_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t rlen = 0;
+    if (!(flag[i] & 0x4)) {
+        const int64_t k1 = cigar_off[i + 1];
+        for (int64_t k = cigar_off[i]; k < k1; ++k) {
+            const uint32_t c = cigar[k];
+            const uint32_t op = c & 0xFu;
+            if ((0x18Du >> op) & 1u) rlen += c >> 4;    // bits 0,2,3,7,8
+        }
+    }
+    if (rlen == 0) rlen = 1;
+    end_out[i] = (int32_t)(pos[i] + rlen - 1);
+}
+
+__device__ __forceinline__ int span_class(int span)
+{
+    return span <= 256 ? 0 : span <= 4096 ? 1 : span <= 65536 ? 2 : 3;
+}
+
+constexpr int kPrepThreads = 256;
+constexpr int kPrepChunk = 2048;     // reads per workgroup in k_span_hist / k_scatter
+
+// per-chunk class counts + per-class max span
+__global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, const int32_t *__restrict__ pos,
+                                                            const int32_t *__restrict__ end,
+                                                            uint32_t *__restrict__ chunk_counts,
+                                                            int32_t *__restrict__ maxspan)
+{
+    __shared__ uint32_t cnt[BSIG_MAX_CLASSES];
+    __shared__ int32_t mx[BSIG_MAX_CLASSES];
+    const int tid = threadIdx.x;
+    if (tid < BSIG_MAX_CLASSES) { cnt[tid] = 0; mx[tid] = 0; }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kPrepChunk;
+    for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
+        const int64_t i = base + r * kPrepThreads + tid;
+        if (i < n) {
+            const int span = end[i] - pos[i] + 1;
+            const int c = span_class(span);
+            atomicAdd(&cnt[c], 1u);
+            atomicMax(&mx[c], span);
+        }
+    }
+    __syncthreads();
+    if (tid < BSIG_MAX_CLASSES) {
+        chunk_counts[(int64_t)blockIdx.x * BSIG_MAX_CLASSES + tid] = cnt[tid];
+        if (mx[tid] > 0) atomicMax(&maxspan[tid], mx[tid]);
+    }
+}
+
+struct ScatterOut {
+    int32_t *pos[BSIG_MAX_CLASSES];
+    int32_t *end[BSIG_MAX_CLASSES];
+    uint32_t *fm[BSIG_MAX_CLASSES];
+    int32_t *tlen[BSIG_MAX_CLASSES];
+    uint32_t *gb[BSIG_MAX_CLASSES];     // bucket number of every read (temporary)
+    int32_t kshift[BSIG_MAX_CLASSES];
+};
+
+// stable partition of the reads into their span classes; chunk_base = exclusive scan of chunk_counts
+__global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_ref,
+                                                          const int64_t *__restrict__ ref_off,
+                                                          const uint32_t *__restrict__ ref_unit0,
+                                                          const uint32_t *__restrict__ ref_units,
+                                                          const int32_t *__restrict__ pos,
+                                                          const int32_t *__restrict__ end,
+                                                          const uint16_t *__restrict__ flag,
+                                                          const uint8_t *__restrict__ mapq,
+                                                          const int32_t *__restrict__ tlen,
+                                                          const uint64_t *__restrict__ chunk_base,
+                                                          const ScatterOut O)
+{
+    constexpr int NW = kPrepThreads / kWave;
+    __shared__ uint32_t wcnt[NW][BSIG_MAX_CLASSES];
+    __shared__ uint64_t run[BSIG_MAX_CLASSES];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    if (tid < BSIG_MAX_CLASSES) run[tid] = chunk_base[(int64_t)blockIdx.x * BSIG_MAX_CLASSES + tid];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kPrepChunk;
+    for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
+        const int64_t i = base + r * kPrepThreads + tid;
+        const bool valid = i < n;
+        int p = 0, e = 0, cls = -1;
+        if (valid) { p = pos[i]; e = end[i]; cls = span_class(e - p + 1); }
+        uint32_t rank = 0;
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wv][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (valid) {
+            uint64_t dst = run[cls] + rank;
+            for (int k = 0; k < wv; ++k) dst += wcnt[k][cls];
+            // reference id of read i: last r with ref_off[r] <= i
+            int lo = 0, hi = n_ref;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (ref_off[mid] <= i) lo = mid; else hi = mid;
+            }
+            int64_t pp = p < 0 ? 0 : p;
+            const int64_t ref_bp = (int64_t)ref_units[lo] << BSIG_REF_UNIT_SHIFT;
+            if (pp >= ref_bp) pp = ref_bp - 1;
+            const uint64_t g = ((uint64_t)ref_unit0[lo] << BSIG_REF_UNIT_SHIFT) + (uint64_t)pp;
+            O.pos[cls][dst] = p;
+            O.end[cls][dst] = e;
+            O.fm[cls][dst] = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 16);
+            O.tlen[cls][dst] = tlen[i];
+            O.gb[cls][dst] = (uint32_t)(g >> O.kshift[cls]);
+        }
+        __syncthreads();
+        if (tid < BSIG_MAX_CLASSES) {
+            uint64_t t = 0;
+            for (int k = 0; k < NW; ++k) t += wcnt[k][tid];
+            run[tid] += t;
+        }
+        __syncthreads();
+    }
+}
+
+// idx[b] = first read of the class with bucket >= b (gb is sorted)
+__global__ void k_build_idx(int64_t n, const uint32_t *__restrict__ gb, uint64_t n_buckets,
+                            uint32_t *__restrict__ idx)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)gb[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    idx[b] = (uint32_t)lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// read visits of a plan, for the roofline's algorithmic bytes:
+//   acc[0] = reads whose pos lies in the exact candidate window of their tile (SURVEY 8d's V)
+//   acc[1] = reads actually streamed (windows rounded to index buckets and to 4 reads)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t lo, uint32_t hi, int64_t key)
+{
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)pos[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
+                         const BsigWorkItem *__restrict__ items, int64_t n_items,
+                         unsigned long long *__restrict__ acc)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    const BsigWorkItem w = items[t];
+    const bool neg_range = (w.units_strand >> 30) & 1u;
+    int64_t tlo, thi;
+    if (mode == BSIG_MODE_COUNT) { tlo = (int64_t)w.loc + w.c0; thi = tlo + w.nc; }
+    else tile_interval(w, mode == BSIG_MODE_COVERAGE ? 1 : P.binsize, neg_range, tlo, thi);
+    unsigned long long exact = 0, streamed = 0;
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        if (C.n == 0) continue;
+        uint32_t j_lo, j_hi;
+        if (!class_window(C, w, tlo, thi, P.ext, j_lo, j_hi)) continue;
+        streamed += ((j_hi + 3u) & ~3u) - (j_lo & ~3u);
+        int64_t wlo = tlo - P.ext - C.maxspan + 1, whi = thi + P.ext;
+        if (wlo < 0) wlo = 0;
+        const uint32_t a = lower_bound_pos(C.pos, j_lo, j_hi, wlo);
+        const uint32_t b = lower_bound_pos(C.pos, a, j_hi, whi);
+        exact += b - a;
+    }
+    atomicAdd(&acc[0], exact);
+    atomicAdd(&acc[1], streamed);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers (called by runtime.hip)
+// ------------------------------------------------------------------------------------------
+namespace bsig {
+
+template <int NT>
+static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const BsigKParams &P,
+                              const BsigWorkItem *items, int64_t n_items, int tile_cells,
+                              int32_t *out, hipStream_t st)
+{
+    if (n_items <= 0) return hipSuccess;
+    const dim3 grid((unsigned)n_items), block(NT);
+    if (mode == BSIG_MODE_PROFILE) {
+        const size_t lds = (size_t)(tile_cells * (ss ? 2 : 1) + 8) * sizeof(int32_t);
+        if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, R, P, items, out);
+        else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, R, P, items, out);
+    } else if (mode == BSIG_MODE_COVERAGE) {
+        const size_t lds = (size_t)(tile_cells + 8 + NT / 64) * sizeof(int32_t);
+        hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, R, P, items, out);
+    } else {
+        hipLaunchKernelGGL((k_count<NT>), grid, block, 0, st, R, P, items, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, const BsigKParams &P,
+                         const BsigWorkItem *items, int64_t n_items, int tile_cells,
+                         int32_t *out, hipStream_t st)
+{
+    switch (threads) {
+    case 64:  return launch_mode<64>(mode, ss, R, P, items, n_items, tile_cells, out, st);
+    case 128: return launch_mode<128>(mode, ss, R, P, items, n_items, tile_cells, out, st);
+    case 256: return launch_mode<256>(mode, ss, R, P, items, n_items, tile_cells, out, st);
+    default:  return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag, const int64_t *cigar_off,
+                            const uint32_t *cigar, int32_t *end_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cigar_end, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       n, pos, flag, cigar_off, cigar, end_out);
+    return hipGetLastError();
+}
+
+int64_t prep_chunks(int64_t n) { return (n + kPrepChunk - 1) / kPrepChunk; }
+
+hipError_t launch_span_hist(int64_t n, const int32_t *pos, const int32_t *end, uint32_t *chunk_counts,
+                            int32_t *maxspan, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_span_hist, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
+                       n, pos, end, chunk_counts, maxspan);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, const uint32_t *ref_unit0,
+                          const uint32_t *ref_units, const int32_t *pos, const int32_t *end,
+                          const uint16_t *flag, const uint8_t *mapq, const int32_t *tlen,
+                          const uint64_t *chunk_base, const ScatterPtrs &S, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    ScatterOut O;
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        O.pos[c] = S.pos[c]; O.end[c] = S.end[c]; O.fm[c] = S.fm[c]; O.tlen[c] = S.tlen[c];
+        O.gb[c] = S.gb[c]; O.kshift[c] = S.kshift[c];
+    }
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
+                       n, n_ref, ref_off, ref_unit0, ref_units, pos, end, flag, mapq, tlen, chunk_base, O);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_idx(int64_t n, const uint32_t *gb, uint64_t n_buckets, uint32_t *idx, hipStream_t st)
+{
+    const uint64_t total = n_buckets + 1;
+    hipLaunchKernelGGL(k_build_idx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       n, gb, n_buckets, idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
+                         int64_t n_items, unsigned long long *acc, hipStream_t st)
+{
+    if (n_items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_visits, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st,
+                       R, P, mode, items, n_items, acc);
+    return hipGetLastError();
+}
+
+}  // namespace bsig

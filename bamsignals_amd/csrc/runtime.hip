@@ -1,0 +1,557 @@
+// Host runtime behind include/bamsignals_abi.h: device context, reads resident in HBM,
+// plans (ranges + parameters -> work items) and their execution on a HIP stream.
+//
+// There is no CPU fallback in this library: every compute entry point needs a gfx950 device
+// and fails with BSIG_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/bamsignals_abi.h"
+#include "bsig_types.h"
+#include "host_util.h"
+#include "kernels.h"
+
+namespace bsig {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+}  // namespace bsig
+
+using bsig::fail;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,          \
+                        "HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__, #expr);                                            \
+    } while (0)
+
+namespace {
+
+// owns a set of device allocations
+struct DevPool {
+    std::vector<void *> ptrs;
+    int64_t bytes = 0;
+    template <typename T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        void *q = nullptr;
+        const size_t nbytes = std::max<size_t>(count * sizeof(T), 16);
+        hipError_t e = hipMalloc(&q, nbytes);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        ptrs.push_back(q);
+        bytes += (int64_t)nbytes;
+        *p = (T *)q;
+        return hipSuccess;
+    }
+    void release()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+        bytes = 0;
+    }
+    ~DevPool() { release(); }
+};
+
+}  // namespace
+
+struct bsig_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+};
+
+struct bsig_reads {
+    bsig_ctx *ctx = nullptr;
+    BsigReadsDev dev{};
+    DevPool pool;
+    bsig_reads_info info{};
+    int32_t n_ref = 0;
+    std::vector<uint32_t> ref_unit0, ref_units;
+    std::vector<int32_t> ref_len;
+};
+
+struct bsig_plan {
+    bsig_ctx *ctx = nullptr;
+    const bsig_reads *reads = nullptr;
+    int mode = 0;
+    BsigKParams kp{};
+    int tile_cells = 0, threads = 0;
+    int64_t n_ranges = 0, n_items = 0;
+    std::vector<int64_t> off;
+    DevPool pool;
+    BsigWorkItem *items = nullptr;
+    bool have_stats = false;
+    bsig_plan_stats stats{};
+};
+
+extern "C" {
+
+int bsig_abi_version(void) { return BSIG_ABI_VERSION; }
+
+const char *bsig_last_error(void) { return bsig::g_last_error.c_str(); }
+
+// allocateList's shapes (ref: src/bamsignals.cpp:139-192)
+int64_t bsig_layout(int64_t n, const int32_t *len, int32_t binsize, int32_t ss, int64_t *off)
+{
+    const int64_t mult = ss ? 2 : 1;
+    int64_t acc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        off[i] = acc;
+        if (binsize <= 0) acc += mult;
+        else if (len[i] > 0) acc += mult * (((int64_t)len[i] + binsize - 1) / binsize);
+    }
+    off[n] = acc;
+    return acc;
+}
+
+int bsig_device_count(int32_t *n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(BSIG_ERR_DEVICE, "no HIP device: %s", hipGetErrorString(e)); }
+    *n = c;
+    return BSIG_OK;
+}
+
+int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
+{
+    if (!out) return fail(BSIG_ERR_ARG, "ctx output pointer is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(BSIG_ERR_DEVICE, "no HIP device available (bamsignals_hip has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(BSIG_ERR_ARG, "device %d out of range [0,%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BSIG_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    bsig_ctx *c = new bsig_ctx;
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(BSIG_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return BSIG_OK;
+}
+
+void bsig_ctx_destroy(bsig_ctx *c)
+{
+    if (!c) return;
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bsig_ctx_sync(bsig_ctx *c)
+{
+    if (!c) return fail(BSIG_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BSIG_OK;
+}
+
+void *bsig_ctx_stream(bsig_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+// reads -> HBM
+// ---------------------------------------------------------------------------------------------
+static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
+{
+    const int64_t n = cols->n_reads;
+    const int32_t n_ref = cols->n_ref;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // global coordinate: references back to back in 64-kbp units
+    R->n_ref = n_ref;
+    R->ref_unit0.resize(n_ref);
+    R->ref_units.resize(n_ref);
+    R->ref_len.assign(cols->ref_len, cols->ref_len + n_ref);
+    uint64_t total_units = 0;
+    for (int r = 0; r < n_ref; ++r) {
+        if (cols->ref_len[r] < 0) return fail(BSIG_ERR_ARG, "negative length of reference %d", r);
+        const uint64_t u = ((uint64_t)cols->ref_len[r] >> BSIG_REF_UNIT_SHIFT) + 1;
+        if (total_units + u >= (1ull << 31)) return fail(BSIG_ERR_ARG, "genome too large for the bucket index");
+        R->ref_unit0[r] = (uint32_t)total_units;
+        R->ref_units[r] = (uint32_t)u;
+        total_units += u;
+    }
+    const uint64_t total_bp = total_units << BSIG_REF_UNIT_SHIFT;
+
+    R->info = bsig_reads_info{};
+    R->info.n_reads = n;
+    if (n == 0 || n_ref == 0) {
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) R->dev.cls[c] = BsigClassCols{};
+        return BSIG_OK;
+    }
+
+    DevPool tmp;
+    int32_t *d_pos, *d_end, *d_tlen;
+    uint16_t *d_flag;
+    uint8_t *d_mapq;
+    HIP_TRY(tmp.alloc(&d_pos, n));
+    HIP_TRY(tmp.alloc(&d_end, n));
+    HIP_TRY(tmp.alloc(&d_tlen, n));
+    HIP_TRY(tmp.alloc(&d_flag, n));
+    HIP_TRY(tmp.alloc(&d_mapq, n));
+    HIP_TRY(hipMemcpyAsync(d_pos, cols->pos, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_tlen, cols->tlen, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_flag, cols->flag, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_mapq, cols->mapq, n * sizeof(uint8_t), hipMemcpyHostToDevice, st));
+    if (cols->end) {
+        HIP_TRY(hipMemcpyAsync(d_end, cols->end, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    } else {
+        const int64_t n_ops = cols->cigar_off[n];
+        if (cols->cigar_off[0] != 0 || n_ops < 0) return fail(BSIG_ERR_ARG, "cigar_off must start at 0 and be non-decreasing");
+        int64_t *d_coff;
+        uint32_t *d_cig;
+        HIP_TRY(tmp.alloc(&d_coff, n + 1));
+        HIP_TRY(tmp.alloc(&d_cig, n_ops));
+        HIP_TRY(hipMemcpyAsync(d_coff, cols->cigar_off, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (n_ops) HIP_TRY(hipMemcpyAsync(d_cig, cols->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(bsig::launch_cigar_end(n, d_pos, d_flag, d_coff, d_cig, d_end, st));
+    }
+
+    // span classes: per-chunk counts -> host exclusive scan
+    const int64_t n_chunks = bsig::prep_chunks(n);
+    uint32_t *d_counts;
+    int32_t *d_maxspan;
+    HIP_TRY(tmp.alloc(&d_counts, n_chunks * BSIG_MAX_CLASSES));
+    HIP_TRY(tmp.alloc(&d_maxspan, BSIG_MAX_CLASSES));
+    HIP_TRY(hipMemsetAsync(d_maxspan, 0, BSIG_MAX_CLASSES * sizeof(int32_t), st));
+    HIP_TRY(bsig::launch_span_hist(n, d_pos, d_end, d_counts, d_maxspan, st));
+    std::vector<uint32_t> counts(n_chunks * BSIG_MAX_CLASSES);
+    int32_t maxspan[BSIG_MAX_CLASSES];
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(maxspan, d_maxspan, sizeof maxspan, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint64_t> base(n_chunks * BSIG_MAX_CLASSES);
+    uint64_t class_n[BSIG_MAX_CLASSES] = {0, 0, 0, 0};
+    for (int64_t k = 0; k < n_chunks; ++k)
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+            base[k * BSIG_MAX_CLASSES + c] = class_n[c];
+            class_n[c] += counts[k * BSIG_MAX_CLASSES + c];
+        }
+
+    // bucket width per class: about 16 reads per bucket, 16 bp .. 64 kbp
+    bsig::ScatterPtrs S{};
+    uint64_t n_buckets[BSIG_MAX_CLASSES] = {0, 0, 0, 0};
+    int min_shift = 4;
+    while ((total_bp >> min_shift) >= (1ull << 32)) ++min_shift;
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        BsigClassCols &C = R->dev.cls[c];
+        C = BsigClassCols{};
+        if (class_n[c] == 0) continue;
+        if (class_n[c] >= (1ull << 32) - 8) return fail(BSIG_ERR_ARG, "more than 2^32 reads in one span class");
+        const double bp_per_bucket = 16.0 * (double)total_bp / (double)class_n[c];
+        int k = 4;
+        while (k < BSIG_REF_UNIT_SHIFT && (double)(1ull << (k + 1)) <= bp_per_bucket) ++k;
+        k = std::max(k, min_shift);
+        if (k > BSIG_REF_UNIT_SHIFT) return fail(BSIG_ERR_ARG, "genome too large for the bucket index");
+        const size_t cap = ((size_t)class_n[c] + 3) / 4 * 4 + 4;
+        int32_t *p, *e, *t;
+        uint32_t *f, *gb, *idx;
+        HIP_TRY(R->pool.alloc(&p, cap));
+        HIP_TRY(R->pool.alloc(&e, cap));
+        HIP_TRY(R->pool.alloc(&f, cap));
+        HIP_TRY(R->pool.alloc(&t, cap));
+        HIP_TRY(tmp.alloc(&gb, cap));
+        n_buckets[c] = total_bp >> k;
+        HIP_TRY(R->pool.alloc(&idx, n_buckets[c] + 2));
+        // the tail padding is read by the 16-B loads: keep it defined
+        HIP_TRY(hipMemsetAsync(p + cap - 8, 0, 8 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(e + cap - 8, 0, 8 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(f + cap - 8, 0, 8 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(t + cap - 8, 0, 8 * sizeof(int32_t), st));
+        C.pos = p; C.end = e; C.fm = f; C.tlen = t; C.idx = idx;
+        C.n = (int64_t)class_n[c]; C.maxspan = maxspan[c]; C.kshift = k;
+        S.pos[c] = p; S.end[c] = e; S.fm[c] = f; S.tlen[c] = t; S.gb[c] = gb; S.kshift[c] = k;
+        R->info.class_n[c] = C.n;
+        R->info.class_maxspan[c] = C.maxspan;
+        R->info.class_bucket_shift[c] = k;
+        R->info.n_classes += 1;
+    }
+
+    int64_t *d_ref_off;
+    uint32_t *d_unit0, *d_units;
+    uint64_t *d_base;
+    HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
+    HIP_TRY(tmp.alloc(&d_unit0, n_ref));
+    HIP_TRY(tmp.alloc(&d_units, n_ref));
+    HIP_TRY(tmp.alloc(&d_base, base.size()));
+    HIP_TRY(hipMemcpyAsync(d_ref_off, cols->ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_unit0, R->ref_unit0.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_units, R->ref_units.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_base, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(bsig::launch_scatter(n, n_ref, d_ref_off, d_unit0, d_units, d_pos, d_end, d_flag, d_mapq, d_tlen,
+                                 d_base, S, st));
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c)
+        if (class_n[c])
+            HIP_TRY(bsig::launch_build_idx((int64_t)class_n[c], S.gb[c], n_buckets[c],
+                                           const_cast<uint32_t *>(R->dev.cls[c].idx), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    R->info.hbm_bytes = R->pool.bytes;
+    return BSIG_OK;
+}
+
+int bsig_reads_upload(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads **out)
+{
+    if (!ctx || !cols || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_upload");
+    *out = nullptr;
+    const int64_t n = cols->n_reads;
+    if (n < 0 || cols->n_ref < 0) return fail(BSIG_ERR_ARG, "negative read or reference count");
+    if (cols->n_ref > 0 && (!cols->ref_len || !cols->ref_off)) return fail(BSIG_ERR_ARG, "ref_len/ref_off missing");
+    if (n > 0) {
+        if (!cols->pos || !cols->flag || !cols->mapq || !cols->tlen) return fail(BSIG_ERR_ARG, "read columns missing");
+        if (!cols->end && (!cols->cigar_off || !cols->cigar)) return fail(BSIG_ERR_ARG, "need either end or cigar_off+cigar");
+        if (cols->n_ref == 0) return fail(BSIG_ERR_ARG, "reads without references");
+    }
+    if (cols->n_ref > 0) {
+        if (cols->ref_off[0] != 0 || cols->ref_off[cols->n_ref] != n)
+            return fail(BSIG_ERR_ARG, "ref_off must run from 0 to n_reads");
+        for (int r = 0; r < cols->n_ref; ++r)
+            if (cols->ref_off[r] > cols->ref_off[r + 1]) return fail(BSIG_ERR_ARG, "ref_off must be non-decreasing");
+    }
+    bsig_reads *R = new bsig_reads;
+    R->ctx = ctx;
+    const int rc = upload_impl(ctx, cols, R);
+    if (rc != BSIG_OK) { delete R; return rc; }
+    *out = R;
+    return BSIG_OK;
+}
+
+int bsig_reads_get_info(const bsig_reads *reads, bsig_reads_info *info)
+{
+    if (!reads || !info) return fail(BSIG_ERR_ARG, "NULL argument");
+    *info = reads->info;
+    return BSIG_OK;
+}
+
+void bsig_reads_free(bsig_reads *reads) { delete reads; }
+
+// ---------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------
+int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const int32_t *rid,
+                     const int32_t *loc, const int32_t *len, const int32_t *strand,
+                     const bsig_params *prm, bsig_plan **out)
+{
+    if (!ctx || !reads || !prm || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_plan_create");
+    *out = nullptr;
+    if (n < 0 || (n > 0 && (!rid || !loc || !len || !strand))) return fail(BSIG_ERR_ARG, "range arrays missing");
+    const int mode = prm->mode;
+    if (mode != BSIG_MODE_PROFILE && mode != BSIG_MODE_COUNT && mode != BSIG_MODE_COVERAGE)
+        return fail(BSIG_ERR_ARG, "unknown mode %d", mode);
+    if (mode == BSIG_MODE_PROFILE && prm->binsize < 1)
+        return fail(BSIG_ERR_ARG, "provide a binsize greater or equal to 1");       // ref: R/wrappers.R:136-137
+    if (prm->n_tlen_filter != 0 && prm->n_tlen_filter != 2)
+        return fail(BSIG_ERR_ARG, "tlen_filter must have 0 or 2 elements");
+    const bool mid = mode != BSIG_MODE_COVERAGE && prm->pe_mid;
+    const bool tspan = mode == BSIG_MODE_COVERAGE && prm->tspan;
+    if ((mid || tspan) && prm->n_tlen_filter != 2)
+        return fail(BSIG_ERR_ARG, "paired-end midpoint/extend needs a 2-element tlen_filter");
+    // ext: ref src/bamsignals.cpp:457 (pileup) and :487 (coverage); :243 rejects negatives
+    int64_t ext;
+    if (mode == BSIG_MODE_COVERAGE) ext = tspan ? prm->tlen_filter[1] : 0;
+    else ext = std::llabs((long long)prm->shift) + (mid ? (int64_t)prm->tlen_filter[1] : 0);
+    if (ext < 0) return fail(BSIG_ERR_EXT, "negative 'ext' values don't make sense");
+    if (ext > (1ll << 30)) return fail(BSIG_ERR_ARG, "shift / tlen filter too large");
+    for (int64_t i = 0; i < n; ++i) {
+        if (rid[i] < 0 || rid[i] >= reads->n_ref)
+            return fail(BSIG_ERR_CHROM, "chromosome id %d not present in the bam file", rid[i]);
+        if (len[i] < 0) return fail(BSIG_ERR_ARG, "range %lld has a negative width", (long long)i);
+    }
+
+    bsig_plan *P = new bsig_plan;
+    P->ctx = ctx; P->reads = reads; P->mode = mode; P->n_ranges = n;
+    P->tile_cells = prm->tile_cells > 0 ? prm->tile_cells : 2048;
+    P->tile_cells = std::min(std::max(P->tile_cells, 64), prm->ss && mode == BSIG_MODE_PROFILE ? 16384 : 32768);
+    P->tile_cells = (P->tile_cells + 3) & ~3;
+    P->threads = prm->threads > 0 ? prm->threads : 64;
+    if (P->threads != 64 && P->threads != 128 && P->threads != 256) {
+        delete P;
+        return fail(BSIG_ERR_ARG, "threads must be 64, 128 or 256");
+    }
+    BsigKParams &K = P->kp;
+    K.mapqual = prm->mapqual;
+    K.requiredF = (uint32_t)prm->requiredF;
+    K.filteredF = (uint32_t)prm->filteredF;
+    K.has_tlen_filter = prm->n_tlen_filter == 2;
+    K.tf0 = prm->tlen_filter[0]; K.tf1 = prm->tlen_filter[1];
+    K.shift = mode == BSIG_MODE_COVERAGE ? 0 : prm->shift;
+    K.midpoint = mid; K.tspan = tspan;
+    K.use_tlen = K.has_tlen_filter || mid || tspan;
+    K.ss = mode == BSIG_MODE_COVERAGE ? 0 : (prm->ss != 0);
+    K.binsize = mode == BSIG_MODE_PROFILE ? prm->binsize : 1;
+    K.ext = (int32_t)ext;
+    K.tile_cells = P->tile_cells;
+    bsig::magic_u31(K.binsize, &K.div_magic, &K.div_shift);
+
+    const int32_t lay_binsize = mode == BSIG_MODE_COUNT ? -1 : K.binsize;
+    P->off.resize(n + 1);
+    bsig_layout(n, len, lay_binsize, K.ss, P->off.data());
+
+    // tiles in genomic order (ref: std::sort by (rid, loc), src/bamsignals.cpp:222-226,246):
+    // neighbouring workgroups then stream neighbouring reads
+    std::vector<int64_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        if (rid[a] != rid[b]) return rid[a] < rid[b];
+        return loc[a] < loc[b];
+    });
+    std::vector<BsigWorkItem> items;
+    items.reserve(n);
+    const int64_t mult = K.ss ? 2 : 1;
+    const int count_split = 1 << 15;      // count mode: bases per workgroup
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t i = order[k];
+        if (len[i] <= 0) continue;
+        BsigWorkItem w{};
+        w.loc = loc[i]; w.len = len[i];
+        w.ref_unit0 = reads->ref_unit0[rid[i]];
+        w.units_strand = reads->ref_units[rid[i]] | (strand[i] < 0 ? (1u << 30) : 0u);
+        if (mode == BSIG_MODE_COUNT) {
+            const bool split = len[i] > count_split;
+            for (int64_t a = 0; a < len[i]; a += count_split) {
+                w.c0 = (int32_t)a;
+                w.nc = (int32_t)std::min<int64_t>(count_split, len[i] - a);
+                w.out_off = P->off[i];
+                if (split) w.units_strand |= 1u << 31;
+                items.push_back(w);
+            }
+        } else {
+            const int64_t cells = (P->off[i + 1] - P->off[i]) / mult;
+            for (int64_t c0 = 0; c0 < cells; c0 += P->tile_cells) {
+                w.c0 = (int32_t)c0;
+                w.nc = (int32_t)std::min<int64_t>(P->tile_cells, cells - c0);
+                w.out_off = P->off[i] + c0 * mult;
+                items.push_back(w);
+            }
+        }
+    }
+    P->n_items = (int64_t)items.size();
+    if (P->n_items >= (1ll << 31)) { delete P; return fail(BSIG_ERR_ARG, "too many tiles for one launch"); }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = P->pool.alloc(&P->items, std::max<size_t>(items.size(), 1));
+    if (e == hipSuccess && !items.empty())
+        e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        delete P;
+        return fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "plan upload failed: %s", hipGetErrorString(e));
+    }
+    *out = P;
+    return BSIG_OK;
+}
+
+const int64_t *bsig_plan_offsets(const bsig_plan *p) { return p ? p->off.data() : nullptr; }
+
+int64_t bsig_plan_cells(const bsig_plan *p) { return p ? p->off.back() : 0; }
+
+int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
+{
+    if (!p) return fail(BSIG_ERR_ARG, "plan is NULL");
+    const int64_t cells = p->off.back();
+    if (cells == 0) return BSIG_OK;
+    if (!out_dev) return fail(BSIG_ERR_ARG, "output buffer is NULL");
+    if (((uintptr_t)out_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device output buffer must be 16-byte aligned");
+    hipStream_t st = p->ctx->stream;
+    if (p->mode == BSIG_MODE_COUNT)
+        HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
+    HIP_TRY(bsig::launch_pileup(p->mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
+                                p->tile_cells, out_dev, st));
+    return BSIG_OK;
+}
+
+int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
+{
+    if (!p) return fail(BSIG_ERR_ARG, "plan is NULL");
+    const int64_t cells = p->off.back();
+    if (cells == 0) return BSIG_OK;
+    if (!out_host) return fail(BSIG_ERR_ARG, "output buffer is NULL");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    int32_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, cells * sizeof(int32_t)));
+    int rc = bsig_plan_run(p, d_out);
+    if (rc == BSIG_OK) {
+        hipError_t e = hipMemcpyAsync(out_host, d_out, cells * sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
+        if (e != hipSuccess) rc = fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
+{
+    if (!p || !s) return fail(BSIG_ERR_ARG, "NULL argument");
+    if (!p->have_stats) {
+        hipStream_t st = p->ctx->stream;
+        unsigned long long *d_acc = nullptr, acc[2] = {0, 0};
+        HIP_TRY(hipSetDevice(p->ctx->device));
+        HIP_TRY(hipMalloc((void **)&d_acc, sizeof acc));
+        hipError_t e = hipMemsetAsync(d_acc, 0, sizeof acc, st);
+        if (e == hipSuccess) e = bsig::launch_visits(p->reads->dev, p->kp, p->mode, p->items, p->n_items, d_acc, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_acc);
+        if (e != hipSuccess) return fail(BSIG_ERR_DEVICE, "visit count failed: %s", hipGetErrorString(e));
+        bsig_plan_stats &t = p->stats;
+        t.n_ranges = p->n_ranges;
+        t.n_items = p->n_items;
+        t.cells = p->off.back();
+        t.visits = (int64_t)acc[0];
+        t.streamed = (int64_t)acc[1];
+        t.bytes_per_visit = p->kp.use_tlen ? 16 : 12;
+        t.algorithmic_bytes = t.bytes_per_visit * t.visits + (int64_t)sizeof(BsigWorkItem) * t.n_items +
+                              8 * t.n_items * p->reads->info.n_classes + 4 * t.cells;
+        p->have_stats = true;
+    }
+    *s = p->stats;
+    return BSIG_OK;
+}
+
+void bsig_plan_free(bsig_plan *p) { delete p; }
+
+int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const int32_t *rid,
+                        const int32_t *loc, const int32_t *len, const int32_t *strand,
+                        const bsig_params *params, int32_t *out_host, const int64_t *off)
+{
+    bsig_plan *p = nullptr;
+    int rc = bsig_plan_create(ctx, reads, n, rid, loc, len, strand, params, &p);
+    if (rc != BSIG_OK) return rc;
+    if (off && memcmp(off, p->off.data(), (n + 1) * sizeof(int64_t)) != 0) {
+        bsig_plan_free(p);
+        return fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters");
+    }
+    rc = bsig_plan_run_host(p, out_host);
+    bsig_plan_free(p);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""Handle-level host API over the C ABI: a device context, reads resident in HBM, plans.
+
+This is plumbing for the reference-shaped entry points in ``wrappers.py`` and for ``bench.py``;
+all arithmetic happens in the HIP kernels (csrc/kernels.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context:
+    """One GPU + the HIP stream the kernels are launched on."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def stream(self):
+        return self._lib.bsig_ctx_stream(self._h)
+
+    def sync(self):
+        _lib.check(self._lib.bsig_ctx_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bsig_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Reads:
+    """Read columns resident in HBM (span classes + bucket index, see csrc/bsig_types.h).
+
+    ``end`` may be omitted when ``cigar_off``/``cigar`` (packed ``len<<4|op``) are given: the GPU
+    then derives ``bam_endpos - 1`` itself.
+    """
+
+    def __init__(self, ctx, ref_len, ref_off, pos, flag, mapq, tlen, end=None, cigar_off=None, cigar=None):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        ref_len = _i32(ref_len)
+        ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+        pos = _i32(pos)
+        flag = np.ascontiguousarray(flag, dtype=np.uint16)
+        mapq = np.ascontiguousarray(mapq, dtype=np.uint8)
+        tlen = _i32(tlen)
+        n = len(pos)
+        if not (len(flag) == len(mapq) == len(tlen) == n):
+            raise ValueError("read columns differ in length")
+        cols = _lib.Columns()
+        cols.n_reads = n
+        cols.n_ref = len(ref_len)
+        cols.ref_len = _ptr(ref_len).value
+        cols.ref_off = _ptr(ref_off).value
+        cols.pos, cols.flag, cols.mapq, cols.tlen = (_ptr(a).value for a in (pos, flag, mapq, tlen))
+        keep = [ref_len, ref_off, pos, flag, mapq, tlen]
+        if end is not None:
+            end = _i32(end)
+            if len(end) != n:
+                raise ValueError("end column differs in length")
+            cols.end = _ptr(end).value
+            keep.append(end)
+        else:
+            if cigar_off is None or cigar is None:
+                raise ValueError("need either end or cigar_off + cigar")
+            cigar_off = np.ascontiguousarray(cigar_off, dtype=np.int64)
+            cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+            if len(cigar_off) != n + 1:
+                raise ValueError("cigar_off must have n_reads + 1 entries")
+            cols.cigar_off = _ptr(cigar_off).value
+            cols.cigar = _ptr(cigar).value
+            keep += [cigar_off, cigar]
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_reads_upload(ctx._h, C.byref(cols), C.byref(h)))
+        self._h = h
+        self.n_reads = n
+        self.n_ref = len(ref_len)
+
+    def info(self):
+        inf = _lib.ReadsInfo()
+        _lib.check(self._lib.bsig_reads_get_info(self._h, C.byref(inf)))
+        return dict(n_reads=inf.n_reads, hbm_bytes=inf.hbm_bytes, n_classes=inf.n_classes,
+                    class_n=list(inf.class_n), class_maxspan=list(inf.class_maxspan),
+                    class_bucket_shift=list(inf.class_bucket_shift))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bsig_reads_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def make_params(mode, tlen_filter=(), mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
+                filteredF=-1, pe_mid=False, tspan=False, tile_cells=0, threads=0):
+    p = _lib.Params()
+    p.mode = mode
+    p.mapqual = int(mapqual)
+    p.binsize = int(binsize)
+    p.shift = int(shift)
+    p.ss = int(bool(ss))
+    p.requiredF = int(requiredF)
+    p.filteredF = int(filteredF)
+    p.pe_mid = int(bool(pe_mid))
+    p.tspan = int(bool(tspan))
+    tf = [] if tlen_filter is None else [int(x) for x in tlen_filter]
+    p.n_tlen_filter = len(tf)
+    if len(tf) not in (0, 2):
+        raise ValueError("tlen_filter must have 0 or 2 elements")
+    for i, v in enumerate(tf):
+        p.tlen_filter[i] = v
+    p.tile_cells = int(tile_cells)
+    p.threads = int(threads)
+    return p
+
+
+class Plan:
+    """Ranges + call parameters resident in HBM; run it any number of times."""
+
+    def __init__(self, ctx, reads, rid, loc, length, strand, params):
+        self._lib = _lib.load()
+        self.ctx, self.reads = ctx, reads
+        rid, loc, length, strand = _i32(rid), _i32(loc), _i32(length), _i32(strand)
+        n = len(rid)
+        if not (len(loc) == len(length) == len(strand) == n):
+            raise ValueError("range arrays differ in length")
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_plan_create(ctx._h, reads._h, n, _ptr(rid), _ptr(loc), _ptr(length),
+                                              _ptr(strand), C.byref(params), C.byref(h)))
+        self._h = h
+        self.n_ranges = n
+        self.cells = int(self._lib.bsig_plan_cells(h))
+        self.offsets = np.ctypeslib.as_array(self._lib.bsig_plan_offsets(h), shape=(n + 1,)).copy()
+
+    def run_host(self):
+        out = np.empty(self.cells, dtype=np.int32)
+        _lib.check(self._lib.bsig_plan_run_host(self._h, _ptr(out)))
+        return out
+
+    def run_device(self, out_ptr):
+        """Asynchronous launch on the context's stream; ``out_ptr`` is a device address."""
+        _lib.check(self._lib.bsig_plan_run(self._h, C.c_void_p(out_ptr)))
+
+    def stats(self):
+        s = _lib.PlanStats()
+        _lib.check(self._lib.bsig_plan_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bsig_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def layout(length, binsize, ss):
+    """Flat offsets of the result (allocateList's shapes, ref: src/bamsignals.cpp:139-192)."""
+    lib = _lib.load()
+    length = _i32(length)
+    off = np.empty(len(length) + 1, dtype=np.int64)
+    lib.bsig_layout(len(length), _ptr(length), int(binsize), int(bool(ss)), _ptr(off))
+    return off

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — Mbases profiled / s for bamProfile(binsize=1) on MI355X (BASELINE.json's metric).
+
+A "step" is one pass of the hot path (HIP kernel k_profile behind bsig_plan_run) over one batch
+of ranges, with the read columns and the range work items already resident in HBM and the result
+left in HBM.  Default workload = BASELINE config 2: 10,000 x 2 kb ranges, 5e7 synthetic
+single-end reads on one 250 Mbp reference.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): ranges are independent units,
+so they are sharded round-robin over the ranks with NO data-path collective; every rank holds
+the reads (weak scaling: each rank gets `--ranges` ranges).  After the timed region the per-rank
+results are gathered to rank 0 over RCCL once (the north star's final reassembly step); its time
+is reported separately in "gather" and is not part of `value`.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    # name: (reads, reference lengths, ranges, range width, paired, profile args)
+    "C2": dict(reads=50_000_000, ref_len=[250_000_000], ranges=10_000, width=2000, paired=False,
+               args=dict(binsize=1), desc="bamProfile binsize=1, 10k x 2kb ranges, 5e7 SE reads, 250 Mbp"),
+    "C2small": dict(reads=2_000_000, ref_len=[10_000_000], ranges=10_000, width=2000, paired=False,
+                    args=dict(binsize=1), desc="bamProfile binsize=1, 10k x 2kb ranges, 2e6 SE reads, 10 Mbp"),
+    "C4": dict(reads=500_000_000, ref_len=[250_000_000] * 10, ranges=100_000, width=2000, paired=True,
+               args=dict(binsize=1, ss=True, shift=75, requiredF=66, tlen_filter=(50, 500)),
+               desc="bamProfile PE filter tlenFilter=c(50,500) shift=75 ss=TRUE, 100k x 2kb, 5e8 PE reads"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--reads", type=int, default=0, help="override the number of reads")
+    ap.add_argument("--ranges", type=int, default=0, help="override the number of ranges per GPU")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--tile-cells", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0xBA51)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Context, Plan, Reads, make_params
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+
+    cfg = CONFIGS[a.config]
+    n_reads = a.reads or cfg["reads"]
+    n_ranges = a.ranges or cfg["ranges"]
+
+    # ---- synthetic input (identical reads on every rank; ranges sharded round-robin) ----------
+    t0 = time.time()
+    cols = synth_reads(n_reads, cfg["ref_len"], seed=a.seed, paired=cfg["paired"], with_cigar=False)
+    all_rg = synth_ranges(n_ranges * world, cfg["width"], cfg["ref_len"], seed=a.seed + 1)
+    order = np.lexsort((all_rg["loc"], all_rg["rid"]))            # sorted as the reference sorts them
+    mine = order[rank::world]                                     # round-robin shard of sorted ranges
+    rg = {k: v[mine] for k, v in all_rg.items()}
+    t_gen = time.time() - t0
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = Context(local, stream=stream.cuda_stream)
+        t0 = time.time()
+        reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"],
+                      cols["tlen"], end=cols["end"])
+        t_upload = time.time() - t0
+        t0 = time.time()
+        params = make_params(_lib.MODE_PROFILE, tile_cells=a.tile_cells, threads=a.threads, **cfg["args"])
+        plan = Plan(ctx, reads, rg["rid"], rg["loc"], rg["len"], rg["strand"], params)
+        t_plan = time.time() - t0
+        stats = plan.stats()
+        out = torch.empty(max(plan.cells, 4), dtype=torch.int32, device="cuda")
+        bases = int(rg["len"].astype(np.int64).sum())
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(a.warmup):
+            plan.run_device(out.data_ptr())
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        t_start = time.perf_counter()
+        for s in range(a.steps):
+            ev[s][0].record(stream)
+            plan.run_device(out.data_ptr())
+            ev[s][1].record(stream)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+        # whole-job time = max over ranks
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- correctness of what was just timed: a sample of ranges against the oracle --------
+        got = out[:plan.cells].cpu().numpy()
+        parity = None
+        cpu = None
+        if rank == 0:
+            from oracle import oracle_c
+            orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+            k = min(500, len(rg["rid"]))
+            sub = {kk: v[:k] for kk, v in rg.items()}
+            want, woff = oracle_c.pileup_core(orc, sub, **cfg["args"])
+            parity = bool(np.array_equal(got[:woff[-1]], want))
+            if not parity:
+                raise SystemExit("HIP result differs from the oracle: refusing to report a number")
+            if not a.no_cpu_baseline:
+                # the oracle (C restatement of overlapAndPileup + Pileupper, single thread) on the
+                # rank's whole workload, repeated until about 10 s have passed
+                reps, t_cpu = 0, 0.0
+                while t_cpu < 10.0 and reps < 200:
+                    t1 = time.perf_counter()
+                    oracle_c.pileup_core(orc, rg, **cfg["args"])
+                    t_cpu += time.perf_counter() - t1
+                    reps += 1
+                cpu = dict(value=bases * reps / t_cpu / 1e6, unit="Mbases/s", cores=1, kind="port",
+                           sample=f"{reps} x the full per-GPU workload ({len(rg['rid'])} ranges) on read columns "
+                                  f"already in RAM (BAM decode excluded), oracle/bamsignals_oracle.c, 1 thread")
+
+        # ---- final reassembly on rank 0 over RCCL (outside the timed region) -------------------
+        gather = None
+        if world > 1:
+            shard = out[:plan.cells]
+            bufs = [torch.empty_like(shard) for _ in range(world)] if rank == 0 else None
+            torch.cuda.synchronize(); dist.barrier()
+            t1 = time.perf_counter()
+            dist.gather(shard, bufs, dst=0)
+            torch.cuda.synchronize()
+            t_g = time.perf_counter() - t1
+            sums = torch.tensor([int(got.astype(np.int64).sum())], dtype=torch.int64, device="cuda")
+            allsums = [torch.zeros_like(sums) for _ in range(world)]
+            dist.all_gather(allsums, sums)
+            if rank == 0:
+                ok = all(int(b.sum(dtype=torch.int64).item()) == int(s.item()) for b, s in zip(bufs, allsums))
+                if not ok:
+                    raise SystemExit("gathered shards do not match the per-rank checksums")
+                gather = dict(ms=t_g * 1e3, bytes=int(shard.numel() * 4 * (world - 1)),
+                              GBps=shard.numel() * 4 * (world - 1) / t_g / 1e9, checked=True)
+
+    if rank == 0:
+        total_bases = bases * world
+        value = total_bases * a.steps / elapsed / 1e6
+        achieved = stats["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Mbases profiled/sec (bamProfile binsize=1)", "value": value, "unit": "Mbases/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": a.config + ": " + cfg["desc"], "reads": n_reads,
+                       "ranges_per_gpu": len(rg["rid"]), "range_width": cfg["width"],
+                       "parallelism": f"ranges round-robin over {world} GPU(s), reads replicated",
+                       "threads": params.threads or 64, "tile_cells": params.tile_cells or 2048},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_profile", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": stats["algorithmic_bytes"], "visits": stats["visits"],
+                         "streamed_reads": stats["streamed"], "bytes_per_visit": stats["bytes_per_visit"],
+                         "items": stats["n_items"], "cells": stats["cells"]},
+            "cpu_baseline": cpu,
+            "parity_checked": parity,
+            "gather": gather,
+            "setup_s": {"generate": t_gen, "upload_and_layout": t_upload, "plan": t_plan},
+            "reads_in_hbm": reads.info(),
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

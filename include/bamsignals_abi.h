@@ -1,0 +1,160 @@
+/* bamsignals_abi.h — C ABI of the MI355X-native bamsignals hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no R, Rcpp, torch or HIP types.
+ * The shared object is bamsignals_amd/libbamsignals_hip.so.  Callers: the plain-C R shim
+ * (bamsignals_amd/r_package/src/shim.c, the replacement of the reference's Rcpp glue
+ * src/RcppExports.cpp:10-82) and the Python ctypes host (bamsignals_amd/_lib.py), which
+ * mirrors the reference's R interface because R is not available in the build image.
+ *
+ * Citations "ref:" are file:line in lamortenera/bamsignals v1.41.1.
+ *
+ * Conventions
+ *   - every function returns BSIG_OK (0) or a negative BSIG_ERR_*; bsig_last_error() returns the
+ *     message of the last failure on the calling thread (the R shim passes it to Rf_error);
+ *   - ranges are flat arrays: rid (reference id in the BAM header), loc (0-based start =
+ *     GRanges start - 1, ref: src/bamsignals.cpp:131), len (width), strand (+1, -1, 0 for '*',
+ *     ref: src/bamsignals.cpp:123-129);
+ *   - results are ONE flat int32 buffer owned by the caller: range i owns
+ *     out[off[i] .. off[i+1]) with off from bsig_layout().  With ss the element
+ *     2*bin + antisense (the column-major 2 x width matrix of ref: src/bamsignals.cpp:172-190,361).
+ *     bamCount (binsize <= 0): mult cells per range, i.e. the single vector / 2 x n matrix of
+ *     ref: src/bamsignals.cpp:148-169.
+ */
+#ifndef BAMSIGNALS_ABI_H
+#define BAMSIGNALS_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSIG_ABI_VERSION 1
+
+enum {
+    BSIG_OK = 0,
+    BSIG_ERR_ARG = -1,       /* invalid argument                                              */
+    BSIG_ERR_IO = -2,        /* "Fail to open BAM file X"          ref: src/bamsignals.cpp:204 */
+    BSIG_ERR_NOINDEX = -3,   /* "BAM indexing file is not available for file X"      ref: :209 */
+    BSIG_ERR_CHROM = -4,     /* "chromosome X not present in the bam file"           ref: :119 */
+    BSIG_ERR_EXT = -5,       /* "negative 'ext' values don't make sense"             ref: :243 */
+    BSIG_ERR_DEVICE = -6,    /* HIP runtime failure / no GPU                                  */
+    BSIG_ERR_NOMEM = -7,
+    BSIG_ERR_FORMAT = -8     /* malformed BAM / BAI / SAM                                     */
+};
+
+enum { BSIG_MODE_PROFILE = 0, BSIG_MODE_COUNT = 1, BSIG_MODE_COVERAGE = 2 };
+
+int bsig_abi_version(void);
+const char *bsig_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Output layout — replaces allocateList (ref: src/bamsignals.cpp:139-192).
+ * off must hold n+1 entries; returns the total number of int32 cells (off[n]).
+ * binsize <= 0 selects bamCount's layout.  Also the native half of fastWidth
+ * (ref: src/CountSignals.cpp:19-29): width[i] = (off[i+1]-off[i]) / (ss ? 2 : 1).
+ * ------------------------------------------------------------------------------------------ */
+int64_t bsig_layout(int64_t n, const int32_t *len, int32_t binsize, int32_t ss, int64_t *off);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context: one per GPU (and per host thread that drives it).
+ * stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create one.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bsig_ctx bsig_ctx;
+int bsig_device_count(int32_t *n);
+int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **ctx);
+void bsig_ctx_destroy(bsig_ctx *ctx);
+int bsig_ctx_sync(bsig_ctx *ctx);
+void *bsig_ctx_stream(bsig_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Reads resident in HBM.  Input = the columnar arrays the CPU decode stage produces
+ * (what htslib's bam1_core_t holds for each record returned by bam_itr_next,
+ * ref: src/bamsignals.cpp:271), sorted by (reference id, pos) as in a coordinate-sorted BAM.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n_reads;
+    int32_t n_ref;
+    const int32_t *ref_len;    /* n_ref    : reference lengths (BAM header l_ref)               */
+    const int64_t *ref_off;    /* n_ref+1  : reads of reference r are [ref_off[r], ref_off[r+1]) */
+    const int32_t *pos;        /* core.pos, 0-based                                              */
+    const uint16_t *flag;      /* core.flag                                                      */
+    const uint8_t *mapq;       /* core.qual                                                      */
+    const int32_t *tlen;       /* core.isize                                                     */
+    const int32_t *end;        /* bam_endpos-1 (ref: src/bamsignals.cpp:16-18), or NULL to let   */
+    const int64_t *cigar_off;  /*   the GPU compute it from the packed CIGAR:                    */
+    const uint32_t *cigar;     /*   read i owns cigar[cigar_off[i] .. cigar_off[i+1]), len<<4|op */
+} bsig_columns;
+
+typedef struct bsig_reads bsig_reads;
+
+typedef struct {
+    int64_t n_reads;
+    int64_t hbm_bytes;              /* resident bytes: class columns + bucket indexes            */
+    int32_t n_classes;              /* span classes in use                                       */
+    int64_t class_n[4];
+    int32_t class_maxspan[4];
+    int32_t class_bucket_shift[4];
+} bsig_reads_info;
+
+int bsig_reads_upload(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads **reads);
+int bsig_reads_get_info(const bsig_reads *reads, bsig_reads_info *info);
+void bsig_reads_free(bsig_reads *reads);
+
+/* ------------------------------------------------------------------------------------------
+ * A plan = ranges + call parameters resident in HBM, ready to run any number of times.
+ * Replaces parseRegions' GArray vector + sort + the Pileupper/Coverager construction
+ * (ref: src/bamsignals.cpp:92-135, 246, 455-457, 485-487).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t mode;              /* BSIG_MODE_*                                                   */
+    int32_t mapqual;
+    int32_t binsize;           /* profile: >= 1; ignored otherwise                              */
+    int32_t shift;
+    int32_t ss;
+    int32_t requiredF;
+    int32_t filteredF;
+    int32_t pe_mid;            /* profile/count: paired.end == "midpoint"                       */
+    int32_t tspan;             /* coverage:      paired.end == "extend"                         */
+    int32_t n_tlen_filter;     /* 0 or 2 (ref: R/wrappers.R:84-98)                              */
+    int32_t tlen_filter[2];
+    /* tuning knobs, 0 = default */
+    int32_t tile_cells;        /* output cells per workgroup tile (default 2048)                */
+    int32_t threads;           /* 64, 128 or 256 threads per workgroup (default 64)             */
+} bsig_params;
+
+typedef struct bsig_plan bsig_plan;
+
+typedef struct {
+    int64_t n_ranges;
+    int64_t n_items;           /* workgroup tiles                                               */
+    int64_t cells;             /* int32 output cells                                            */
+    int64_t visits;            /* reads in the exact candidate windows of all tiles (V)         */
+    int64_t streamed;          /* reads actually loaded (windows rounded to index buckets)      */
+    int64_t algorithmic_bytes; /* bytes_per_visit*V + 32*items + 8*items*classes + 4*cells      */
+    int32_t bytes_per_visit;   /* 12, or 16 when the tlen column is needed                      */
+} bsig_plan_stats;
+
+int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,
+                     const int32_t *rid, const int32_t *loc, const int32_t *len,
+                     const int32_t *strand, const bsig_params *params, bsig_plan **plan);
+const int64_t *bsig_plan_offsets(const bsig_plan *plan);     /* n_ranges+1, host memory          */
+int64_t bsig_plan_cells(const bsig_plan *plan);
+int bsig_plan_get_stats(bsig_plan *plan, bsig_plan_stats *stats);
+/* run on the context's stream; out_dev: device buffer of bsig_plan_cells() int32, 16-B aligned.
+ * Asynchronous: call bsig_ctx_sync() (or synchronise the stream) before reading out_dev.       */
+int bsig_plan_run(bsig_plan *plan, int32_t *out_dev);
+/* run + copy to host memory + synchronise                                                      */
+int bsig_plan_run_host(bsig_plan *plan, int32_t *out_host);
+void bsig_plan_free(bsig_plan *plan);
+
+/* one-shot: columns already in HBM -> host result (upload ranges, run, download)               */
+int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,
+                        const int32_t *rid, const int32_t *loc, const int32_t *len,
+                        const int32_t *strand, const bsig_params *params,
+                        int32_t *out_host, const int64_t *off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAMSIGNALS_ABI_H */

@@ -1,0 +1,276 @@
+"""GPU: the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+Bit-exact: all arithmetic is 32-bit integer."""
+import numpy as np
+import pytest
+
+from conftest import core_args, parse_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from bamsignals_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _gpu(ctx, reads, ranges, kind, tile_cells=0, threads=0, **a):
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    if kind == "coverage":
+        p = make_params(_lib.MODE_COVERAGE, tile_cells=tile_cells, threads=threads, **a)
+    else:
+        bs = a.pop("binsize", 1)
+        mode = _lib.MODE_COUNT if bs <= 0 else _lib.MODE_PROFILE
+        p = make_params(mode, binsize=bs, tile_cells=tile_cells, threads=threads, **a)
+    plan = Plan(ctx, reads, ranges["rid"], ranges["loc"], ranges["len"], ranges["strand"], p)
+    out = plan.run_host()
+    off = plan.offsets
+    plan.close()
+    return out, off
+
+
+@pytest.fixture(scope="module")
+def fx_reads(ctx, fixture_reads):
+    from bamsignals_amd.device import Reads
+    fx = fixture_reads
+    r = Reads(ctx, fx["ref_len"], fx["ref_off"], fx["bam_pos"], fx["bam_flag"], fx["bam_mapq"], fx["bam_tlen"],
+              end=fx["bam_end"])
+    yield r
+    r.close()
+
+
+def test_golden_grid(ctx, fx_reads, fixture_regions, expected_grid):
+    """Full grid of tests/testthat/test_methods.R:33-104 on the reference's fixture reads."""
+    _, ranges = fixture_regions
+    plus = dict(ranges, strand=np.ones_like(ranges["strand"]))
+    for key, want in expected_grid.items():
+        kind, p = parse_key(key)
+        a = core_args(kind, p)
+        got, _ = _gpu(ctx, fx_reads, plus if kind == "ff16" else ranges, "coverage" if kind == "coverage" else "pileup", **a)
+        assert np.array_equal(got, want), key
+
+
+def test_golden_extra(ctx, fx_reads, fixture_regions, expected_extra):
+    _, ranges = fixture_regions
+    star = dict(ranges, strand=np.asarray([(1, -1, 0)[i % 3] for i in range(len(ranges["rid"]))], dtype=np.int32))
+    cases = {
+        "profile_star_bs1": ("pileup", star, dict(binsize=1)),
+        "profile_star_bs7_ss": ("pileup", star, dict(binsize=7, ss=True)),
+        "profile_bs50_shift-30": ("pileup", ranges, dict(binsize=50, shift=-30)),
+        "profile_ff0": ("pileup", ranges, dict(binsize=1, filteredF=0)),
+        "profile_ff1024": ("pileup", ranges, dict(binsize=1, filteredF=1024)),
+        "profile_ff1040": ("pileup", ranges, dict(binsize=1, filteredF=1040)),
+        "count_star_ss": ("pileup", star, dict(binsize=-1, ss=True)),
+        "profile_mid_bs3_ss": ("pileup", star, dict(binsize=3, ss=True, requiredF=66, tlen_filter=(30, 300),
+                                                    pe_mid=True, shift=5)),
+        "coverage_star": ("coverage", star, dict()),
+        "coverage_star_extend": ("coverage", star, dict(requiredF=66, tlen_filter=(0, 1000), tspan=True)),
+    }
+    assert set(cases) == set(expected_extra)
+    for name, (kind, rg, a) in cases.items():
+        got, _ = _gpu(ctx, fx_reads, rg, kind, **a)
+        assert np.array_equal(got, expected_extra[name]), name
+
+
+def test_end_from_cigar_on_gpu(ctx, fixture_reads, fixture_regions, expected_grid):
+    """bam_endpos computed by k_cigar_end instead of being supplied."""
+    from bamsignals_amd.device import Reads
+    fx = fixture_reads
+    r = Reads(ctx, fx["ref_len"], fx["ref_off"], fx["bam_pos"], fx["bam_flag"], fx["bam_mapq"], fx["bam_tlen"],
+              cigar_off=fx["bam_cigar_off"], cigar=fx["bam_cigar"])
+    _, ranges = fixture_regions
+    key = "profile|shift=100,mapq=0,ss=1,pe=midpoint,tf=50_200"
+    kind, p = parse_key(key)
+    got, _ = _gpu(ctx, r, ranges, "pileup", **core_args(kind, p))
+    assert np.array_equal(got, expected_grid[key])
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def synth(ctx):
+    """Synthetic multi-reference reads with D/N/S/I CIGARs (several span classes) + oracle handle."""
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_reads
+    from oracle import oracle_c
+    out = {}
+    for name, paired in (("se", False), ("pe", True)):
+        cols = synth_reads(400_000, [700_000, 150_000, 65_536, 300_001], seed=11 + paired, paired=paired)
+        # a few very long reads -> classes 2 and 3; unmapped-placed reads; a zero-op read
+        cig = cols["cigar"].copy()
+        first = cols["cigar_off"][:-1]
+        sel = np.arange(0, len(first), 40_001)
+        cig[first[sel]] = (70_000 << 4) | 3          # first op becomes a 70 kb N skip
+        sel2 = np.arange(7, len(first), 30_011)
+        cig[first[sel2]] = (5_000 << 4) | 2          # 5 kb deletion
+        flag = cols["flag"].copy()
+        flag[np.arange(3, len(flag), 9_973)] |= 4      # unmapped but placed: 1-bp reads
+        end = oracle_c.cigar_end(cols["pos"], flag, cols["cigar_off"], cig)
+        gpu = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], flag, cols["mapq"], cols["tlen"],
+                    cigar_off=cols["cigar_off"], cigar=cig)
+        orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], end, flag, cols["mapq"], cols["tlen"])
+        out[name] = (gpu, orc, cols, end)
+    yield out
+    for gpu, *_ in out.values():
+        gpu.close()
+
+
+def test_span_classes(synth):
+    gpu, _, cols, end = synth["se"]
+    info = gpu.info()
+    span = end - cols["pos"] + 1
+    want = [int(np.sum(span <= 256)), int(np.sum((span > 256) & (span <= 4096))),
+            int(np.sum((span > 4096) & (span <= 65536))), int(np.sum(span > 65536))]
+    assert info["class_n"] == want
+    assert all(w > 0 for w in want)
+    for c, (lo, hi) in enumerate(((0, 256), (256, 4096), (4096, 65536), (65536, 1 << 31))):
+        m = (span > lo) & (span <= hi)
+        assert info["class_maxspan"][c] == int(span[m].max())
+
+
+def _rand_ranges(rng, ref_len, n, maxw):
+    ref_len = np.asarray(ref_len)
+    rid = rng.integers(0, len(ref_len), n).astype(np.int32)
+    ln = rng.integers(0, maxw, n).astype(np.int32)
+    ln[rng.random(n) < 0.05] = 0                                   # zero-width ranges
+    loc = (rng.random(n) * (ref_len[rid] + 400) - 200).astype(np.int32)   # some hang over both ends
+    strand = rng.integers(-1, 2, n).astype(np.int32)
+    rg = dict(rid=rid, loc=loc, len=ln, strand=strand)
+    # duplicates and nested ranges
+    for k in ("rid", "loc", "len", "strand"):
+        rg[k][1] = rg[k][0]
+    rg["loc"][3] = rg["loc"][2] + 5
+    rg["rid"][3] = rg["rid"][2]
+    return rg
+
+
+PILEUP_CASES = [
+    dict(binsize=1),
+    dict(binsize=1, ss=True, shift=37),
+    dict(binsize=1, mapqual=30, filteredF=1024),
+    dict(binsize=1, shift=-80, ss=True, filteredF=16),
+    dict(binsize=2, ss=True),
+    dict(binsize=13, shift=5),
+    dict(binsize=200, ss=True, mapqual=10),
+    dict(binsize=100_000),
+    dict(binsize=-1),
+    dict(binsize=-1, ss=True, shift=-20, mapqual=17),
+]
+PE_CASES = [
+    dict(binsize=1, requiredF=66, tlen_filter=(0, 1000)),
+    dict(binsize=1, requiredF=66, tlen_filter=(120, 180), pe_mid=True, ss=True),
+    dict(binsize=9, requiredF=66, tlen_filter=(0, 1000), pe_mid=True, shift=75, ss=True),
+    dict(binsize=-1, requiredF=66, tlen_filter=(50, 500), pe_mid=True, ss=True, shift=75),
+    dict(binsize=1, tlen_filter=(50, 500), shift=75, ss=True, requiredF=66),
+]
+
+
+@pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
+def test_pileup_vs_oracle(ctx, synth, which, cases):
+    from oracle import oracle_c
+    gpu, orc, cols, _ = synth[which]
+    rng = np.random.default_rng(21)
+    small = _rand_ranges(rng, cols["ref_len"], 300, 3000)
+    big = _rand_ranges(rng, cols["ref_len"], 12, 120_000)          # many tiles / split counts
+    for rg in (small, big):
+        for a in cases:
+            want, woff = oracle_c.pileup_core(orc, rg, **a)
+            for threads, tile in ((64, 0), (256, 512), (128, 4096)):
+                got, off = _gpu(ctx, gpu, rg, "pileup", tile_cells=tile, threads=threads, **dict(a))
+                assert np.array_equal(off, woff)
+                assert np.array_equal(got, want), (which, a, threads, tile)
+
+
+@pytest.mark.parametrize("which", ["se", "pe"])
+def test_coverage_vs_oracle(ctx, synth, which):
+    from oracle import oracle_c
+    gpu, orc, cols, _ = synth[which]
+    rng = np.random.default_rng(22)
+    small = _rand_ranges(rng, cols["ref_len"], 300, 3000)
+    big = _rand_ranges(rng, cols["ref_len"], 12, 120_000)
+    cases = [dict(), dict(mapqual=25, filteredF=1024)]
+    if which == "pe":
+        cases += [dict(requiredF=66, tlen_filter=(0, 1000), tspan=True),
+                  dict(requiredF=66, tlen_filter=(100, 200), tspan=True, mapqual=5)]
+    for rg in (small, big):
+        for a in cases:
+            want, woff = oracle_c.coverage_core(orc, rg, **a)
+            for threads, tile in ((64, 0), (256, 512), (128, 4096)):
+                got, off = _gpu(ctx, gpu, rg, "coverage", tile_cells=tile, threads=threads, **dict(a))
+                assert np.array_equal(off, woff)
+                assert np.array_equal(got, want), (which, a, threads, tile)
+
+
+def test_whole_reference_tiling_properties(ctx, synth):
+    """Size-independent checks on a 1-bp tiling of every reference (BASELINE config 3 shape)."""
+    from bamsignals_amd.synth import tile_ranges
+    from oracle import oracle_c
+    gpu, orc, cols, end = synth["se"]
+    tiles = tile_ranges(cols["ref_len"], 2000, strand=0)
+    prof, _ = _gpu(ctx, gpu, tiles, "pileup", binsize=1)
+    # every read whose 5' end is inside its reference is counted exactly once
+    neg = (cols["flag"] & 16) != 0
+    p5 = np.where(neg, end, cols["pos"])
+    inside = (p5 >= 0) & (p5 < cols["ref_len"][cols["rid"]])
+    assert int(prof.sum()) == int(inside.sum())
+    # strand-split sums to the unsplit profile (vignettes/bamsignals.Rmd:148)
+    ss, _ = _gpu(ctx, gpu, tiles, "pileup", binsize=1, ss=True)
+    assert np.array_equal(ss.reshape(-1, 2).sum(axis=1), prof)
+    # binned = sums of the per-base signal (vignettes/bamsignals.Rmd:235); 2000 % 50 == 0
+    b50, off50 = _gpu(ctx, gpu, tiles, "pileup", binsize=50)
+    off1 = np.concatenate([[0], np.cumsum(tiles["len"])])
+    for i in (0, len(tiles["len"]) // 2, len(tiles["len"]) - 1):
+        v = prof[off1[i]:off1[i + 1]]
+        pad = (-len(v)) % 50
+        assert np.array_equal(np.concatenate([v, np.zeros(pad, dtype=v.dtype)]).reshape(-1, 50).sum(axis=1),
+                              b50[off50[i]:off50[i + 1]])
+    # coverage integrates to the clipped total span of the reads
+    cov, _ = _gpu(ctx, gpu, tiles, "coverage")
+    L = cols["ref_len"][cols["rid"]].astype(np.int64)
+    span = np.minimum(end.astype(np.int64), L - 1) - cols["pos"] + 1
+    assert int(cov.astype(np.int64).sum()) == int(span.sum())
+    want, _ = oracle_c.coverage_core(orc, tiles)
+    assert np.array_equal(cov, want)
+    # bamCount == sum of the profile
+    cnt, _ = _gpu(ctx, gpu, tiles, "pileup", binsize=-1)
+    sums = np.add.reduceat(prof, off1[:-1])
+    assert np.array_equal(cnt, sums)
+
+
+def test_empty_inputs(ctx, synth):
+    from bamsignals_amd.device import Reads
+    gpu, _, cols, _ = synth["se"]
+    empty = dict(rid=np.zeros(0, np.int32), loc=np.zeros(0, np.int32), len=np.zeros(0, np.int32),
+                 strand=np.zeros(0, np.int32))
+    for kind, a in (("pileup", dict(binsize=1)), ("pileup", dict(binsize=-1)), ("coverage", dict())):
+        got, off = _gpu(ctx, gpu, empty, kind, **a)
+        assert len(got) == 0 and list(off) == [0]
+    noreads = Reads(ctx, [1000, 2000], [0, 0, 0], [], [], [], [], end=[])
+    rg = dict(rid=np.asarray([0, 1], np.int32), loc=np.asarray([10, 0], np.int32), len=np.asarray([100, 50], np.int32),
+              strand=np.asarray([1, -1], np.int32))
+    for kind, a, n in (("pileup", dict(binsize=1, ss=True), 300), ("pileup", dict(binsize=-1), 2), ("coverage", dict(), 150)):
+        got, _ = _gpu(ctx, noreads, rg, kind, **a)
+        assert len(got) == n and not got.any()
+    noreads.close()
+
+
+def test_error_paths(ctx, synth):
+    from bamsignals_amd import _lib
+    gpu, _, cols, _ = synth["se"]
+    rg = dict(rid=np.asarray([0], np.int32), loc=np.asarray([10], np.int32), len=np.asarray([100], np.int32),
+              strand=np.asarray([1], np.int32))
+    with pytest.raises(_lib.BsigError) as e:
+        _gpu(ctx, gpu, rg, "pileup", binsize=1, pe_mid=True)               # tlen_filter[1] of an empty vector
+    assert e.value.code_name == "BSIG_ERR_ARG"
+    with pytest.raises(_lib.BsigError) as e:
+        _gpu(ctx, gpu, rg, "coverage", tspan=True, tlen_filter=(0, -5))    # ref: src/bamsignals.cpp:243
+    assert e.value.code_name == "BSIG_ERR_EXT" and "negative 'ext'" in str(e.value)
+    with pytest.raises(_lib.BsigError) as e:
+        _gpu(ctx, gpu, dict(rg, rid=np.asarray([9], np.int32)), "pileup", binsize=1)
+    assert e.value.code_name == "BSIG_ERR_CHROM"
+    from bamsignals_amd.device import Plan, make_params
+    with pytest.raises(_lib.BsigError) as e:
+        Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=0))
+    assert "binsize greater or equal to 1" in str(e.value)
