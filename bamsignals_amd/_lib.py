@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbamsignals_hip.so")
+# BSIG_LIB_PATH selects another build of the same ABI (the diagnostic stamps build); never a fallback
+SO_PATH = os.environ.get("BSIG_LIB_PATH") or os.path.join(_HERE, "libbamsignals_hip.so")
 
 BSIG_OK = 0
 MODE_PROFILE, MODE_COUNT, MODE_COVERAGE = 0, 1, 2

@@ -20,6 +20,7 @@ struct ScatterPtrs {
 
 hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, const BsigKParams &P,
                          const BsigWorkItem *items, int64_t n_items, int tile_cells,
+                         void *windows /* scratch: n_items * BSIG_MAX_CLASSES * 8 bytes */,
                          int32_t *out, hipStream_t st);
 hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag, const int64_t *cigar_off,
                             const uint32_t *cigar, int32_t *end_out, hipStream_t st);

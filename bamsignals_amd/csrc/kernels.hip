@@ -17,6 +17,25 @@
 #include "bsig_types.h"
 #include "kernels.h"
 
+#ifdef BSIG_STAMPS
+// Diagnostic build only (libbamsignals_hip_stamps.so, scripts/stamps.py): per-workgroup
+// s_memtime stamps of k_profile's phases.  The shipped library has no stamp code.
+__device__ unsigned long long *g_stamp_buf = nullptr;
+__device__ int g_ablate = 0;     // bit 0: skip the read streaming; bit 1: skip the global stores
+#define BSIG_STAMP(k)                                                                       \
+    do {                                                                                    \
+        if (g_stamp_buf && threadIdx.x == 0) {                                              \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            g_stamp_buf[(size_t)blockIdx.x * 8 + (k)] = t_;                                 \
+        }                                                                                   \
+    } while (0)
+#define BSIG_ABLATE(bit) (g_ablate & (bit))
+#else
+#define BSIG_STAMP(k) do { } while (0)
+#define BSIG_ABLATE(bit) 0
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -83,7 +102,11 @@ __device__ __forceinline__ void store_vec(int32_t *__restrict__ gbase, int v, in
 {
     const int e0 = 4 * v;
     if (e0 >= sh && e0 + 4 <= sh + nv) {
-        *reinterpret_cast<int4 *>(gbase + e0) = x;
+        // the result is written once and never re-read by this launch: non-temporal stores keep
+        // it from displacing the read columns in L2 (measured -6 % step time at config 2)
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        v4i_t xv = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(xv, reinterpret_cast<v4i_t *>(gbase + e0));
     } else {
         const int lo = sh, hi = sh + nv;
         if (e0 + 0 >= lo && e0 + 0 < hi) gbase[e0 + 0] = x.x;
@@ -93,29 +116,121 @@ __device__ __forceinline__ void store_vec(int32_t *__restrict__ gbase, int v, in
     }
 }
 
+// genomic interval a work item needs reads for
+__device__ __forceinline__ void item_interval(const BsigWorkItem &w, const BsigKParams &P, int mode,
+                                              int64_t &tlo, int64_t &thi)
+{
+    const bool neg_range = (w.units_strand >> 30) & 1u;
+    if (mode == BSIG_MODE_COUNT) { tlo = (int64_t)w.loc + w.c0; thi = tlo + w.nc; }
+    else tile_interval(w, mode == BSIG_MODE_COVERAGE ? 1 : P.binsize, neg_range, tlo, thi);
+}
+
+// Index lookup for every (tile, span class): windows[4*t + c] = [j_lo, j_hi) of class c's reads
+// that can touch tile t.  The device-side counterpart of bam_itr_queryi (src/bamsignals.cpp:267).
+// It runs in front of the pileup kernel on every bsig_plan_run(), so that the pileup workgroups,
+// which hold LDS, start with their windows known instead of chasing item -> index -> columns.
+__global__ void k_resolve(const BsigReadsDev R, const BsigKParams P, int mode,
+                          const BsigWorkItem *__restrict__ items, int64_t n_items,
+                          uint2 *__restrict__ windows)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = g >> 2;
+    const int c = (int)(g & 3);
+    if (t >= n_items) return;
+    const BsigWorkItem w = items[t];
+    int64_t tlo, thi;
+    item_interval(w, P, mode, tlo, thi);
+    uint32_t j_lo = 0, j_hi = 0;
+    const BsigClassCols &C = R.cls[c];
+    if (C.n == 0 || !class_window(C, w, tlo, thi, P.ext, j_lo, j_hi)) { j_lo = 0; j_hi = 0; }
+    windows[g] = make_uint2(j_lo, j_hi);
+}
+
+// Stream the reads of all span-class windows of one tile through `one(pos, end, fm, tlen, valid)`.
+// The first 16-B vector of every class is requested before anything is consumed, so the
+// workgroup pays one memory round trip for all classes; longer windows continue in a loop.
+template <int NT, typename F>
+__device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
+                                              const uint2 (&win)[BSIG_MAX_CLASSES], int tid, F &&one)
+{
+    int4 p4[BSIG_MAX_CLASSES], e4[BSIG_MAX_CLASSES], t4[BSIG_MAX_CLASSES];
+    uint4 f4[BSIG_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        const uint32_t j = (win[c].x & ~3u) + 4u * tid;
+        t4[c] = make_int4(0, 0, 0, 0);
+        if (j < win[c].y) {
+            p4[c] = *reinterpret_cast<const int4 *>(C.pos + j);
+            e4[c] = *reinterpret_cast<const int4 *>(C.end + j);
+            f4[c] = *reinterpret_cast<const uint4 *>(C.fm + j);
+            if (P.use_tlen) t4[c] = *reinterpret_cast<const int4 *>(C.tlen + j);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        const uint32_t j_lo = win[c].x, j_hi = win[c].y;
+        // the 16-B aligned loads may start before j_lo (possibly on the previous reference) and
+        // end after j_hi: only reads in [j_lo, j_hi) count
+        const uint32_t nj = j_hi - j_lo;
+        uint32_t j = (j_lo & ~3u) + 4u * tid;
+        if (j < j_hi) {
+            uint32_t dj = j - j_lo;
+            one(p4[c].x, e4[c].x, f4[c].x, t4[c].x, dj < nj);
+            one(p4[c].y, e4[c].y, f4[c].y, t4[c].y, dj + 1u < nj);
+            one(p4[c].z, e4[c].z, f4[c].z, t4[c].z, dj + 2u < nj);
+            one(p4[c].w, e4[c].w, f4[c].w, t4[c].w, dj + 3u < nj);
+            for (j += 4u * NT; j < j_hi; j += 4u * NT) {
+                const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
+                const int4 e = *reinterpret_cast<const int4 *>(C.end + j);
+                const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+                int4 t = make_int4(0, 0, 0, 0);
+                if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
+                dj = j - j_lo;
+                one(p.x, e.x, f.x, t.x, dj < nj);
+                one(p.y, e.y, f.y, t.y, dj + 1u < nj);
+                one(p.z, e.z, f.z, t.z, dj + 2u < nj);
+                one(p.w, e.w, f.w, t.w, dj + 3u < nj);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_windows(const uint2 *__restrict__ windows, uint2 (&win)[BSIG_MAX_CLASSES])
+{
+    const uint4 *wp = reinterpret_cast<const uint4 *>(windows + (size_t)BSIG_MAX_CLASSES * blockIdx.x);
+    const uint4 a = wp[0], b = wp[1];
+    win[0] = make_uint2(a.x, a.y); win[1] = make_uint2(a.z, a.w);
+    win[2] = make_uint2(b.x, b.y); win[3] = make_uint2(b.z, b.w);
+}
+
 // ------------------------------------------------------------------------------------------
 // bamProfile: per-bin counts of 5' ends
 // ------------------------------------------------------------------------------------------
 template <int NT, bool SS>
 __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const BsigKParams P,
                                                 const BsigWorkItem *__restrict__ items,
+                                                const uint2 *__restrict__ windows,
                                                 int32_t *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     constexpr int S = SS ? 2 : 1;
     const int tid = threadIdx.x;
+    BSIG_STAMP(0);
     const BsigWorkItem w = items[blockIdx.x];
+    uint2 win[BSIG_MAX_CLASSES];
+    load_windows(windows, win);
+    int4 *lds4 = reinterpret_cast<int4 *>(lds);
+    // clear the whole tile image: this needs nothing from the work item, so it overlaps its load
+    for (int v = tid; v < (P.tile_cells * S + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     const int nv = w.nc * S;
     const int sh = (int)(w.out_off & 3);
     const int nvec = (sh + nv + 3) >> 2;
-    int4 *lds4 = reinterpret_cast<int4 *>(lds);
-
-    for (int v = tid; v < nvec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     block_sync<NT>();
+    BSIG_STAMP(1);
 
     const bool neg_range = (w.units_strand >> 30) & 1u;
-    int64_t tlo, thi;
-    tile_interval(w, P.binsize, neg_range, tlo, thi);
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
         if (!valid || read_rejected(P, fm, tl)) return;
@@ -133,29 +248,25 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
         if ((unsigned)lc < (unsigned)w.nc)
             atomicAdd(&lds[sh + lc * S + (SS ? anti : 0)], 1);         // :361-362
     };
-
-#pragma unroll
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
-        const BsigClassCols &C = R.cls[c];
-        if (C.n == 0) continue;
-        uint32_t j_lo, j_hi;
-        if (!class_window(C, w, tlo, thi, P.ext, j_lo, j_hi)) continue;
-        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
-            const int4 p4 = *reinterpret_cast<const int4 *>(C.pos + j);
-            const int4 e4 = *reinterpret_cast<const int4 *>(C.end + j);
-            const uint4 f4 = *reinterpret_cast<const uint4 *>(C.fm + j);
-            int4 t4 = make_int4(0, 0, 0, 0);
-            if (P.use_tlen) t4 = *reinterpret_cast<const int4 *>(C.tlen + j);
-            one(p4.x, e4.x, f4.x, t4.x, true);
-            one(p4.y, e4.y, f4.y, t4.y, j + 1 < j_hi);
-            one(p4.z, e4.z, f4.z, t4.z, j + 2 < j_hi);
-            one(p4.w, e4.w, f4.w, t4.w, j + 3 < j_hi);
-        }
-    }
+    if (!BSIG_ABLATE(1)) for_each_read<NT>(R, P, win, tid, one);
     block_sync<NT>();
+    BSIG_STAMP(2);
 
     int32_t *gbase = out + (w.out_off - sh);
-    for (int v = tid; v < nvec; v += NT) store_vec(gbase, v, lds4[v], sh, nv);
+    if (!BSIG_ABLATE(2))
+        for (int v = tid; v < nvec; v += NT) store_vec(gbase, v, lds4[v], sh, nv);
+    BSIG_STAMP(3);
+#ifdef BSIG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BSIG_STAMP(4);
+    if (g_stamp_buf && threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_stamp_buf[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -164,11 +275,14 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
 template <int NT>
 __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKParams P,
                                               const BsigWorkItem *__restrict__ items,
+                                              const uint2 *__restrict__ windows,
                                               int32_t *__restrict__ out)
 {
     __shared__ int32_t wsum[2 * (NT / kWave)];
     const int tid = threadIdx.x;
     const BsigWorkItem w = items[blockIdx.x];
+    uint2 win[BSIG_MAX_CLASSES];
+    load_windows(windows, win);
     const bool neg_range = (w.units_strand >> 30) & 1u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
     const int gn = w.nc;
@@ -183,25 +297,8 @@ __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKP
         if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
         if (neg != neg_range) ++c_anti; else ++c_sense;
     };
+    for_each_read<NT>(R, P, win, tid, one);
 
-#pragma unroll
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
-        const BsigClassCols &C = R.cls[c];
-        if (C.n == 0) continue;
-        uint32_t j_lo, j_hi;
-        if (!class_window(C, w, (int64_t)glo, (int64_t)glo + gn, P.ext, j_lo, j_hi)) continue;
-        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
-            const int4 p4 = *reinterpret_cast<const int4 *>(C.pos + j);
-            const int4 e4 = *reinterpret_cast<const int4 *>(C.end + j);
-            const uint4 f4 = *reinterpret_cast<const uint4 *>(C.fm + j);
-            int4 t4 = make_int4(0, 0, 0, 0);
-            if (P.use_tlen) t4 = *reinterpret_cast<const int4 *>(C.tlen + j);
-            one(p4.x, e4.x, f4.x, t4.x, true);
-            one(p4.y, e4.y, f4.y, t4.y, j + 1 < j_hi);
-            one(p4.z, e4.z, f4.z, t4.z, j + 2 < j_hi);
-            one(p4.w, e4.w, f4.w, t4.w, j + 3 < j_hi);
-        }
-    }
     // wave reduction, then across the waves of the workgroup
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
@@ -235,6 +332,7 @@ __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKP
 template <int NT>
 __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const BsigKParams P,
                                                  const BsigWorkItem *__restrict__ items,
+                                                 const uint2 *__restrict__ windows,
                                                  int32_t *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -244,17 +342,16 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const BsigWorkItem w = items[blockIdx.x];
+    uint2 win[BSIG_MAX_CLASSES];
+    load_windows(windows, win);
+    int4 *lds4 = reinterpret_cast<int4 *>(lds);
+    for (int v = tid; v < (P.tile_cells + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     const int nv = w.nc;
     const int sh = (int)(w.out_off & 3);
     const int nvec = (sh + nv + 3) >> 2;
-    int4 *lds4 = reinterpret_cast<int4 *>(lds);
-
-    for (int v = tid; v < nvec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     block_sync<NT>();
 
     const bool neg_range = (w.units_strand >> 30) & 1u;
-    int64_t tlo, thi;
-    tile_interval(w, 1, neg_range, tlo, thi);
     const int rend1 = w.loc + w.len - 1;     // last base of the range
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
@@ -273,25 +370,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
         atomicAdd(&lds[sh + (la > 0 ? la : 0)], 1);
         if (lb + 1 < w.nc) atomicAdd(&lds[sh + lb + 1], -1);
     };
-
-#pragma unroll
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
-        const BsigClassCols &C = R.cls[c];
-        if (C.n == 0) continue;
-        uint32_t j_lo, j_hi;
-        if (!class_window(C, w, tlo, thi, P.ext, j_lo, j_hi)) continue;
-        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
-            const int4 p4 = *reinterpret_cast<const int4 *>(C.pos + j);
-            const int4 e4 = *reinterpret_cast<const int4 *>(C.end + j);
-            const uint4 f4 = *reinterpret_cast<const uint4 *>(C.fm + j);
-            int4 t4 = make_int4(0, 0, 0, 0);
-            if (P.use_tlen) t4 = *reinterpret_cast<const int4 *>(C.tlen + j);
-            one(p4.x, e4.x, f4.x, t4.x, true);
-            one(p4.y, e4.y, f4.y, t4.y, j + 1 < j_hi);
-            one(p4.z, e4.z, f4.z, t4.z, j + 2 < j_hi);
-            one(p4.w, e4.w, f4.w, t4.w, j + 3 < j_hi);
-        }
-    }
+    for_each_read<NT>(R, P, win, tid, one);
     block_sync<NT>();
 
     // cumsum (:464-470): each lane owns 4 consecutive cells, wave scan of the lane totals,
@@ -496,10 +575,8 @@ __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_items) return;
     const BsigWorkItem w = items[t];
-    const bool neg_range = (w.units_strand >> 30) & 1u;
     int64_t tlo, thi;
-    if (mode == BSIG_MODE_COUNT) { tlo = (int64_t)w.loc + w.c0; thi = tlo + w.nc; }
-    else tile_interval(w, mode == BSIG_MODE_COVERAGE ? 1 : P.binsize, neg_range, tlo, thi);
+    item_interval(w, P, mode, tlo, thi);
     unsigned long long exact = 0, streamed = 0;
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         const BsigClassCols &C = R.cls[c];
@@ -527,31 +604,33 @@ namespace bsig {
 template <int NT>
 static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const BsigKParams &P,
                               const BsigWorkItem *items, int64_t n_items, int tile_cells,
-                              int32_t *out, hipStream_t st)
+                              uint2 *windows, int32_t *out, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
+                       R, P, mode, items, n_items, windows);
     const dim3 grid((unsigned)n_items), block(NT);
     if (mode == BSIG_MODE_PROFILE) {
         const size_t lds = (size_t)(tile_cells * (ss ? 2 : 1) + 8) * sizeof(int32_t);
-        if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, R, P, items, out);
-        else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, R, P, items, out);
+        if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, R, P, items, windows, out);
+        else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, R, P, items, windows, out);
     } else if (mode == BSIG_MODE_COVERAGE) {
         const size_t lds = (size_t)(tile_cells + 8 + NT / 64) * sizeof(int32_t);
-        hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, R, P, items, out);
+        hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, R, P, items, windows, out);
     } else {
-        hipLaunchKernelGGL((k_count<NT>), grid, block, 0, st, R, P, items, out);
+        hipLaunchKernelGGL((k_count<NT>), grid, block, 0, st, R, P, items, windows, out);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, const BsigKParams &P,
                          const BsigWorkItem *items, int64_t n_items, int tile_cells,
-                         int32_t *out, hipStream_t st)
+                         void *windows, int32_t *out, hipStream_t st)
 {
     switch (threads) {
-    case 64:  return launch_mode<64>(mode, ss, R, P, items, n_items, tile_cells, out, st);
-    case 128: return launch_mode<128>(mode, ss, R, P, items, n_items, tile_cells, out, st);
-    case 256: return launch_mode<256>(mode, ss, R, P, items, n_items, tile_cells, out, st);
+    case 64:  return launch_mode<64>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, out, st);
+    case 128: return launch_mode<128>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, out, st);
+    case 256: return launch_mode<256>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, out, st);
     default:  return hipErrorInvalidValue;
     }
 }
@@ -610,3 +689,14 @@ hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, 
 }
 
 }  // namespace bsig
+
+#ifdef BSIG_STAMPS
+extern "C" int bsig_debug_set_stamp_buffer(void *buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+}
+extern "C" int bsig_debug_set_ablate(int bits)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &bits, sizeof(bits));
+}
+#endif

@@ -102,6 +102,7 @@ struct bsig_plan {
     std::vector<int64_t> off;
     DevPool pool;
     BsigWorkItem *items = nullptr;
+    void *windows = nullptr;       // [n_items][BSIG_MAX_CLASSES] read windows, rewritten by every run
     bool have_stats = false;
     bsig_plan_stats stats{};
 };
@@ -458,6 +459,11 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     if (P->n_items >= (1ll << 31)) { delete P; return fail(BSIG_ERR_ARG, "too many tiles for one launch"); }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = P->pool.alloc(&P->items, std::max<size_t>(items.size(), 1));
+    if (e == hipSuccess) {
+        uint64_t *wbuf = nullptr;
+        e = P->pool.alloc(&wbuf, std::max<size_t>(items.size(), 1) * BSIG_MAX_CLASSES);
+        P->windows = wbuf;
+    }
     if (e == hipSuccess && !items.empty())
         e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -484,7 +490,7 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (p->mode == BSIG_MODE_COUNT)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
     HIP_TRY(bsig::launch_pileup(p->mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
-                                p->tile_cells, out_dev, st));
+                                p->tile_cells, p->windows, out_dev, st));
     return BSIG_OK;
 }
 
@@ -528,8 +534,11 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         t.visits = (int64_t)acc[0];
         t.streamed = (int64_t)acc[1];
         t.bytes_per_visit = p->kp.use_tlen ? 16 : 12;
-        t.algorithmic_bytes = t.bytes_per_visit * t.visits + (int64_t)sizeof(BsigWorkItem) * t.n_items +
-                              8 * t.n_items * p->reads->info.n_classes + 4 * t.cells;
+        // reads + work items (read by k_resolve and by the pileup kernel) + index entries +
+        // windows (written once, read once) + result cells
+        t.algorithmic_bytes = t.bytes_per_visit * t.visits + 2 * (int64_t)sizeof(BsigWorkItem) * t.n_items +
+                              8 * t.n_items * p->reads->info.n_classes +
+                              2 * 8 * BSIG_MAX_CLASSES * t.n_items + 4 * t.cells;
         p->have_stats = true;
     }
     *s = p->stats;
