@@ -97,6 +97,24 @@ def load():
     lib.bsig_plan_free.restype = None
     lib.bsig_pileup_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
+    lib.bsig_bam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.bsig_bam_close.argtypes = [C.c_void_p]
+    lib.bsig_bam_close.restype = None
+    lib.bsig_bam_n_ref.argtypes = [C.c_void_p]
+    lib.bsig_bam_ref_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.bsig_bam_ref_name.restype = C.c_char_p
+    lib.bsig_bam_ref_len.argtypes = [C.c_void_p, C.c_int32]
+    lib.bsig_bam_name2id.argtypes = [C.c_void_p, C.c_char_p]
+    lib.bsig_bam_decode.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.POINTER(Columns)]
+    core_head = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p,
+                 C.c_void_p, C.c_void_p, C.c_int32]
+    lib.bsig_pileup_core.argtypes = core_head + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]
+    lib.bsig_coverage_core.argtypes = core_head + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
+    lib.bsig_write_sam_as_bam_and_index.argtypes = [C.c_char_p, C.c_char_p]
+    lib.bsig_write_columns_as_bam.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Columns),
+                                              C.c_int32]
+    lib.bsig_cache_clear.restype = None
     _lib = lib
     return lib
 

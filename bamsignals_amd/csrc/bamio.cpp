@@ -1,0 +1,1040 @@
+// BGZF / BAM / BAI reader + writer and a SAM text parser (CPU decode stage).  See bamio.h.
+#include "bamio.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <thread>
+
+#include "../../include/bamsignals_abi.h"
+#include "host_util.h"
+
+namespace bsig {
+
+// ---------------------------------------------------------------------------------------------
+// raw DEFLATE codec: libdeflate through dlopen when present, zlib otherwise
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct LibDeflate {
+    void *h = nullptr;
+    void *(*alloc_d)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_d)(void *) = nullptr;
+    void *(*alloc_c)(int) = nullptr;
+    size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*free_c)(void *) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate()
+    {
+        if (getenv("BAMSIGNALS_NO_LIBDEFLATE")) return;
+        for (const char *n : {"libdeflate.so.0", "libdeflate.so"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return;
+        alloc_d = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        free_d = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        alloc_c = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        free_c = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        crc32 = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc_d && decompress && free_d && alloc_c && compress && free_c && crc32;
+    }
+};
+
+const LibDeflate &ld()
+{
+    static LibDeflate l;
+    return l;
+}
+
+// per-thread inflater / deflater
+struct Inflater {
+    void *d = nullptr;
+    Inflater() { if (ld().ok) d = ld().alloc_d(); }
+    ~Inflater() { if (d) ld().free_d(d); }
+    bool run(const uint8_t *in, size_t n_in, uint8_t *out, size_t n_out)
+    {
+        if (n_out == 0) return true;
+        if (d) {
+            size_t actual = 0;
+            return ld().decompress(d, in, n_in, out, n_out, &actual) == 0 && actual == n_out;
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(in); zs.avail_in = (uInt)n_in;
+        zs.next_out = out; zs.avail_out = (uInt)n_out;
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool ok = rc == Z_STREAM_END && zs.total_out == n_out;
+        inflateEnd(&zs);
+        return ok;
+    }
+};
+
+struct Deflater {
+    void *c = nullptr;
+    int level;
+    explicit Deflater(int lvl) : level(lvl) { if (ld().ok) c = ld().alloc_c(lvl); }
+    ~Deflater() { if (c) ld().free_c(c); }
+    // returns compressed size, 0 on failure
+    size_t run(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap)
+    {
+        if (c) return ld().compress(c, in, n_in, out, cap);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+        zs.next_in = const_cast<Bytef *>(in); zs.avail_in = (uInt)n_in;
+        zs.next_out = out; zs.avail_out = (uInt)cap;
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t n = rc == Z_STREAM_END ? zs.total_out : 0;
+        deflateEnd(&zs);
+        return n;
+    }
+};
+
+uint32_t crc32_of(const uint8_t *p, size_t n)
+{
+    if (ld().ok) return ld().crc32(0, p, n);
+    return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
+
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline int32_t rdi32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+int n_threads(int t)
+{
+    if (t > 0) return t;
+    if (const char *e = getenv("BAMSIGNALS_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hc, 32u));
+}
+
+template <typename F>
+void parallel_for(int64_t n, int threads, F &&body)
+{
+    threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
+    if (threads == 1) { for (int64_t i = 0; i < n; ++i) body(i, 0); return; }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> ts;
+    for (int t = 0; t < threads; ++t)
+        ts.emplace_back([&, t] {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                body(i, t);
+            }
+        });
+    for (auto &t : ts) t.join();
+}
+
+// read-only memory map of a file
+struct MappedFile {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    int open(const std::string &path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return -1;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return -1;
+        size = (size_t)st.st_size;
+        if (size == 0) { data = nullptr; return 0; }
+        void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) return -1;
+        data = (const uint8_t *)p;
+        madvise(p, size, MADV_SEQUENTIAL);
+        return 0;
+    }
+    ~MappedFile()
+    {
+        if (data) munmap((void *)data, size);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+// one BGZF block (SAM spec 4.1)
+struct Block {
+    uint64_t coff;       // file offset of the block
+    uint32_t csize;      // whole block
+    uint32_t doff;       // offset of the deflate data inside the block
+    uint32_t dlen;       // deflate bytes
+    uint32_t isize;      // uncompressed bytes
+};
+
+// parses the block header at file offset `off`; false on a malformed block
+bool parse_block(const MappedFile &f, uint64_t off, Block &b)
+{
+    if (off + 18 > f.size) return false;
+    const uint8_t *p = f.data + off;
+    if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return false;
+    const uint32_t xlen = rd16(p + 10);
+    if (off + 12 + xlen > f.size) return false;
+    uint32_t bsize = 0;
+    bool found = false;
+    for (uint32_t x = 0; x + 4 <= xlen;) {
+        const uint8_t *s = p + 12 + x;
+        const uint32_t slen = rd16(s + 2);
+        if (s[0] == 'B' && s[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = rd16(s + 4); found = true; }
+        x += 4 + slen;
+    }
+    if (!found) return false;
+    b.coff = off;
+    b.csize = bsize + 1;
+    if (off + b.csize > f.size || b.csize < 12 + xlen + 8) return false;
+    b.doff = 12 + xlen;
+    b.dlen = b.csize - b.doff - 8;
+    b.isize = rd32(p + b.csize - 4);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BAM stream parser: header, then records -> columns.  Fed with consecutive pieces of the
+// uncompressed stream; keeps the unparsed tail between calls.
+// ---------------------------------------------------------------------------------------------
+class BamParser {
+public:
+    BamParser(BamHeader &h, HostColumns &c, bool want_header) : hdr_(h), cols_(c), in_header_(want_header) {}
+
+    // stop parsing at this absolute stream position (records starting at or after it are left alone)
+    void set_limit(uint64_t lim) { limit_ = lim; }
+    void set_position(uint64_t p) { abs_ = p; carry_.clear(); done_ = false; }
+    bool reached_limit() const { return done_; }
+    bool in_header() const { return in_header_; }
+    size_t pending() const { return carry_.size(); }
+
+    // returns 0, or a negative BSIG_ERR_* (message recorded)
+    int feed(const uint8_t *d, size_t n)
+    {
+        if (done_) return 0;
+        if (!carry_.empty() || in_header_) {
+            // the header and records that straddle two pieces are assembled in the carry buffer
+            size_t used = 0;
+            for (;;) {
+                const size_t need = bytes_needed();
+                if (carry_.size() < need) {
+                    const size_t take = std::min(n - used, need - carry_.size());
+                    if (take == 0) return 0;                       // input exhausted, unit incomplete
+                    carry_.insert(carry_.end(), d + used, d + used + take);
+                    used += take;
+                    continue;
+                }
+                if (in_header_) {
+                    const int rc = try_header();
+                    if (rc < 0) return rc;
+                    if (in_header_) continue;                      // header_need_ grew
+                    break;
+                }
+                if (abs_ >= limit_) { done_ = true; return 0; }
+                if (rdi32(carry_.data()) < 32) return fail(BSIG_ERR_FORMAT, "malformed BAM record (block_size %d)", rdi32(carry_.data()));
+                const int rc = one_record(carry_.data(), carry_.size());
+                if (rc < 0) return rc;
+                abs_ += carry_.size();
+                carry_.clear();
+                break;
+            }
+            d += used; n -= used;
+        }
+        // fast path: whole records inside this piece
+        size_t o = 0;
+        while (o + 4 <= n) {
+            if (abs_ + o >= limit_) { done_ = true; return 0; }
+            const int32_t bs = rdi32(d + o);
+            if (bs < 32) return fail(BSIG_ERR_FORMAT, "malformed BAM record (block_size %d)", bs);
+            if (o + 4 + (size_t)bs > n) break;
+            const int rc = one_record(d + o, 4 + (size_t)bs);
+            if (rc < 0) return rc;
+            o += 4 + (size_t)bs;
+        }
+        abs_ += o;
+        carry_.assign(d + o, d + n);
+        return 0;
+    }
+
+    void finish_refs()
+    {
+        const int n_ref = (int)hdr_.names.size();
+        while ((int)cols_.ref_off.size() < n_ref + 1) cols_.ref_off.push_back(cols_.size());
+        if (cols_.cigar_off.empty()) cols_.cigar_off.push_back(0);
+    }
+
+private:
+    size_t bytes_needed() const
+    {
+        if (in_header_) return header_need_;
+        if (carry_.size() < 4) return 4;
+        const int32_t bs = rdi32(carry_.data());
+        return 4 + (size_t)std::max(bs, 0);
+    }
+
+    int try_header()
+    {
+        const uint8_t *p = carry_.data();
+        const size_t n = carry_.size();
+        if (n < 12) { header_need_ = 12; return 0; }
+        if (memcmp(p, "BAM\1", 4) != 0) return fail(BSIG_ERR_FORMAT, "not a BAM file (bad magic)");
+        const int32_t l_text = rdi32(p + 4);
+        if (l_text < 0) return fail(BSIG_ERR_FORMAT, "malformed BAM header");
+        size_t o = 8 + (size_t)l_text;
+        if (n < o + 4) { header_need_ = o + 4; return 0; }
+        const int32_t n_ref = rdi32(p + o);
+        if (n_ref < 0) return fail(BSIG_ERR_FORMAT, "malformed BAM header");
+        o += 4;
+        for (int r = 0; r < n_ref; ++r) {
+            if (n < o + 4) { header_need_ = o + 4; return 0; }
+            const int32_t l_name = rdi32(p + o);
+            if (l_name < 1) return fail(BSIG_ERR_FORMAT, "malformed BAM header");
+            if (n < o + 4 + (size_t)l_name + 4) { header_need_ = o + 4 + (size_t)l_name + 4; return 0; }
+            o += 4 + (size_t)l_name + 4;
+        }
+        if (n < o) { header_need_ = o; return 0; }
+        // complete: decode
+        hdr_.text.assign((const char *)p + 8, (size_t)l_text);
+        while (!hdr_.text.empty() && hdr_.text.back() == '\0') hdr_.text.pop_back();
+        hdr_.names.clear(); hdr_.lens.clear();
+        size_t q = 8 + (size_t)l_text + 4;
+        for (int r = 0; r < n_ref; ++r) {
+            const int32_t l_name = rdi32(p + q);
+            hdr_.names.emplace_back((const char *)p + q + 4, (size_t)l_name - 1);
+            hdr_.lens.push_back(rdi32(p + q + 4 + l_name));
+            q += 4 + (size_t)l_name + 4;
+        }
+        // feed() never takes more than bytes_needed(), so the carry holds exactly the header
+        abs_ += o;
+        carry_.clear();
+        in_header_ = false;
+        return 0;
+    }
+
+    int one_record(const uint8_t *r, size_t len)
+    {
+        const uint8_t *c = r + 4;
+        const int32_t rid = rdi32(c);
+        const int32_t pos = rdi32(c + 4);
+        const uint32_t l_name = c[8];
+        const uint8_t mapq = c[9];
+        uint32_t n_cig = rd16(c + 12);
+        const uint16_t flag = rd16(c + 14);
+        const int32_t l_seq = rdi32(c + 16);
+        const int32_t tlen = rdi32(c + 28);
+        if (36 + (size_t)l_name + 4 * (size_t)n_cig > len)
+            return fail(BSIG_ERR_FORMAT, "malformed BAM record (fields exceed block_size)");
+        if (rid < 0) { ++cols_.n_unplaced; return 0; }
+        if (rid >= (int)hdr_.names.size()) return fail(BSIG_ERR_FORMAT, "BAM record with refID %d out of range", rid);
+        if (rid < last_rid_ || (rid == last_rid_ && pos < last_pos_))
+            return fail(BSIG_ERR_FORMAT, "BAM file is not sorted by coordinate");
+        while ((int)cols_.ref_off.size() <= rid) cols_.ref_off.push_back(cols_.size());
+        last_rid_ = rid; last_pos_ = pos;
+        const uint8_t *cig = c + 32 + l_name;
+        if (cols_.cigar_off.empty()) cols_.cigar_off.push_back(0);
+        // long CIGARs (> 65535 ops) live in the CG:B,I tag behind a kSmN placeholder (SAM spec 4.2.2)
+        bool done = false;
+        if (n_cig == 2 && l_seq >= 0 && (rd32(cig) & 0xF) == 4 && (int32_t)(rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 0xF) == 3) {
+            size_t a = 36 + (size_t)l_name + 8 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+            while (a + 3 <= len) {
+                const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+                a += 3;
+                size_t sz = 0;
+                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                else if (ty == 's' || ty == 'S') sz = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                else if (ty == 'Z' || ty == 'H') { while (a + sz < len && r[a + sz]) ++sz; ++sz; }
+                else if (ty == 'B') {
+                    if (a + 5 > len) break;
+                    const uint8_t sub = r[a];
+                    const uint32_t cnt = rd32(r + a + 1);
+                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4 * (size_t)cnt <= len) {
+                        for (uint32_t k = 0; k < cnt; ++k) cols_.cigar.push_back(rd32(r + a + 5 + 4 * (size_t)k));
+                        done = true;
+                        break;
+                    }
+                    sz = 5 + es * cnt;
+                } else break;
+                a += sz;
+            }
+        }
+        if (!done)
+            for (uint32_t k = 0; k < n_cig; ++k) cols_.cigar.push_back(rd32(cig + 4 * (size_t)k));
+        cols_.cigar_off.push_back((int64_t)cols_.cigar.size());
+        cols_.pos.push_back(pos);
+        cols_.flag.push_back(flag);
+        cols_.mapq.push_back(mapq);
+        cols_.tlen.push_back(tlen);
+        return 0;
+    }
+
+    BamHeader &hdr_;
+    HostColumns &cols_;
+    bool in_header_;
+    bool done_ = false;
+    size_t header_need_ = 12;
+    std::vector<uint8_t> carry_;
+    uint64_t abs_ = 0;                       // stream position of the first unparsed byte
+    uint64_t limit_ = ~0ull;
+    int32_t last_rid_ = -1, last_pos_ = -1;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// whole-file decode: blocks are inflated by a thread pool in batches while the previous batch
+// is parsed
+// ---------------------------------------------------------------------------------------------
+static int scan_blocks(const MappedFile &f, const std::string &path, std::vector<Block> &blocks)
+{
+    uint64_t off = 0;
+    while (off < f.size) {
+        Block b;
+        if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block at offset %llu of %s", (unsigned long long)off, path.c_str());
+        blocks.push_back(b);
+        off += b.csize;
+    }
+    return 0;
+}
+
+static int inflate_batch(const MappedFile &f, const std::vector<Block> &blocks, size_t b0, size_t b1,
+                         int threads, std::vector<uint8_t> &out)
+{
+    std::vector<uint64_t> uoff(b1 - b0 + 1, 0);
+    for (size_t k = b0; k < b1; ++k) uoff[k - b0 + 1] = uoff[k - b0] + blocks[k].isize;
+    out.resize(uoff.back());
+    std::atomic<int> bad(0);
+    std::vector<Inflater> inf((size_t)std::max(1, threads));
+    parallel_for((int64_t)(b1 - b0), threads, [&](int64_t i, int t) {
+        const Block &b = blocks[b0 + (size_t)i];
+        if (!inf[(size_t)t].run(f.data + b.coff + b.doff, b.dlen, out.data() + uoff[(size_t)i], b.isize)) bad = 1;
+    });
+    if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+    return 0;
+}
+
+int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostColumns &cols)
+{
+    MappedFile f;
+    if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    threads = n_threads(threads);
+    std::vector<Block> blocks;
+    int rc = scan_blocks(f, path, blocks);
+    if (rc) return rc;
+    cols = HostColumns();
+    // rough reservation: ~50 bytes of uncompressed BAM per record
+    uint64_t total_u = 0;
+    for (const Block &b : blocks) total_u += b.isize;
+    const size_t guess = (size_t)(total_u / 45) + 16;
+    cols.pos.reserve(guess); cols.tlen.reserve(guess); cols.flag.reserve(guess); cols.mapq.reserve(guess);
+    cols.cigar_off.reserve(guess + 1); cols.cigar.reserve(guess + guess / 4);
+
+    BamParser parser(hdr, cols, true);
+    const size_t batch = 2048;        // blocks per batch (<= 128 MiB uncompressed)
+    std::vector<uint8_t> cur, nxt;
+    size_t b0 = 0;
+    if (!blocks.empty()) {
+        rc = inflate_batch(f, blocks, 0, std::min(batch, blocks.size()), threads, cur);
+        if (rc) return rc;
+    }
+    while (b0 < blocks.size()) {
+        const size_t b1 = std::min(b0 + batch, blocks.size());
+        const size_t b2 = std::min(b1 + batch, blocks.size());
+        int rc_next = 0;
+        std::thread producer;
+        if (b1 < b2) producer = std::thread([&] { rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt); });
+        rc = parser.feed(cur.data(), cur.size());
+        if (producer.joinable()) producer.join();
+        if (rc) return rc;
+        if (rc_next) return rc_next;
+        cur.swap(nxt);
+        b0 = b1;
+    }
+    if (parser.in_header()) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
+    if (parser.pending()) return fail(BSIG_ERR_FORMAT, "truncated BAM record at the end of %s", path.c_str());
+    parser.finish_refs();
+    return 0;
+}
+
+int bam_read_header(const std::string &path, BamHeader &hdr)
+{
+    MappedFile f;
+    if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    HostColumns dummy;
+    BamParser parser(hdr, dummy, true);
+    Inflater inf;
+    uint64_t off = 0;
+    std::vector<uint8_t> buf;
+    while (off < f.size && parser.in_header()) {
+        Block b;
+        if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block in %s", path.c_str());
+        buf.resize(b.isize);
+        if (!inf.run(f.data + b.coff + b.doff, b.dlen, buf.data(), b.isize)) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+        parser.set_limit(0);     // header only: never parse a record
+        const int rc = parser.feed(buf.data(), buf.size());
+        if (rc) return rc;
+        off += b.csize;
+    }
+    if (parser.in_header()) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BAI (SAM spec 5.2)
+// ---------------------------------------------------------------------------------------------
+int bai_load(const std::string &bai_path, BaiIndex &idx)
+{
+    std::ifstream in(bai_path, std::ios::binary);
+    if (!in) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", bai_path.c_str());
+    std::vector<uint8_t> d((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    size_t o = 0;
+    auto need = [&](size_t n) { return o + n <= d.size(); };
+    if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) return fail(BSIG_ERR_FORMAT, "%s is not a BAI index", bai_path.c_str());
+    const int32_t n_ref = rdi32(d.data() + 4);
+    o = 8;
+    if (n_ref < 0) return fail(BSIG_ERR_FORMAT, "malformed BAI index");
+    idx.refs.assign((size_t)n_ref, BaiRef());
+    for (int r = 0; r < n_ref; ++r) {
+        if (!need(4)) return fail(BSIG_ERR_FORMAT, "truncated BAI index");
+        const int32_t n_bin = rdi32(d.data() + o); o += 4;
+        for (int b = 0; b < n_bin; ++b) {
+            if (!need(8)) return fail(BSIG_ERR_FORMAT, "truncated BAI index");
+            const uint32_t bin = rd32(d.data() + o);
+            const int32_t n_chunk = rdi32(d.data() + o + 4); o += 8;
+            if (n_chunk < 0 || !need(16 * (size_t)n_chunk)) return fail(BSIG_ERR_FORMAT, "truncated BAI index");
+            std::vector<BaiChunk> ch((size_t)n_chunk);
+            for (int k = 0; k < n_chunk; ++k) { ch[(size_t)k].beg = rd64(d.data() + o); ch[(size_t)k].end = rd64(d.data() + o + 8); o += 16; }
+            idx.refs[(size_t)r].bins.emplace_back(bin, std::move(ch));
+        }
+        std::sort(idx.refs[(size_t)r].bins.begin(), idx.refs[(size_t)r].bins.end(),
+                  [](const auto &a, const auto &b) { return a.first < b.first; });
+        if (!need(4)) return fail(BSIG_ERR_FORMAT, "truncated BAI index");
+        const int32_t n_intv = rdi32(d.data() + o); o += 4;
+        if (n_intv < 0 || !need(8 * (size_t)n_intv)) return fail(BSIG_ERR_FORMAT, "truncated BAI index");
+        idx.refs[(size_t)r].linear.resize((size_t)n_intv);
+        for (int k = 0; k < n_intv; ++k) { idx.refs[(size_t)r].linear[(size_t)k] = rd64(d.data() + o); o += 8; }
+    }
+    idx.n_no_coor = need(8) ? rd64(d.data() + o) : 0;
+    return 0;
+}
+
+namespace {
+
+// bins overlapping [beg, end) (SAM spec 5.3, reg2bins)
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &out)
+{
+    out.clear();
+    if (beg >= end) return;
+    --end;
+    out.push_back(0);
+    for (int k = 1 + (int)(beg >> 26); k <= 1 + (int)(end >> 26); ++k) out.push_back((uint32_t)k);
+    for (int k = 9 + (int)(beg >> 23); k <= 9 + (int)(end >> 23); ++k) out.push_back((uint32_t)k);
+    for (int k = 73 + (int)(beg >> 20); k <= 73 + (int)(end >> 20); ++k) out.push_back((uint32_t)k);
+    for (int k = 585 + (int)(beg >> 17); k <= 585 + (int)(end >> 17); ++k) out.push_back((uint32_t)k);
+    for (int k = 4681 + (int)(beg >> 14); k <= 4681 + (int)(end >> 14); ++k) out.push_back((uint32_t)k);
+}
+
+uint32_t reg2bin(int64_t beg, int64_t end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+}  // namespace
+
+int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::vector<Region> &regions,
+                       int threads, BamHeader &hdr, HostColumns &cols)
+{
+    MappedFile f;
+    if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    threads = n_threads(threads);
+    int rc = bam_read_header(path, hdr);
+    if (rc) return rc;
+    cols = HostColumns();
+
+    // candidate chunks of every region (htslib's iterator: bins + linear-index lower bound)
+    std::vector<BaiChunk> chunks;
+    std::vector<uint32_t> bins;
+    for (const Region &rg : regions) {
+        if (rg.rid < 0 || rg.rid >= (int)idx.refs.size()) continue;
+        const BaiRef &R = idx.refs[(size_t)rg.rid];
+        const int64_t beg = std::max<int64_t>(rg.beg, 0), end = std::min<int64_t>(rg.end, 1ll << 29);
+        if (beg >= end) continue;
+        uint64_t min_off = 0;
+        if (!R.linear.empty()) {
+            const size_t w = (size_t)(beg >> 14);
+            min_off = w < R.linear.size() ? R.linear[w] : R.linear.back();
+        }
+        reg2bins(beg, end, bins);
+        for (uint32_t b : bins) {
+            auto it = std::lower_bound(R.bins.begin(), R.bins.end(), b, [](const auto &x, uint32_t v) { return x.first < v; });
+            if (it == R.bins.end() || it->first != b) continue;
+            for (const BaiChunk &c : it->second)
+                if (c.end > min_off) chunks.push_back(c);
+        }
+    }
+    std::sort(chunks.begin(), chunks.end(), [](const BaiChunk &a, const BaiChunk &b) { return a.beg < b.beg; });
+    std::vector<BaiChunk> merged;
+    for (const BaiChunk &c : chunks) {
+        if (!merged.empty() && c.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, c.end);
+        else merged.push_back(c);
+    }
+
+    // the records of one merged chunk are parsed from consecutively inflated blocks
+    BamParser parser(hdr, cols, false);
+    Inflater inf1;
+    for (const BaiChunk &c : merged) {
+        const uint64_t cb = c.beg >> 16, ub = c.beg & 0xFFFF, ce = c.end >> 16, ue = c.end & 0xFFFF;
+        // blocks cb .. ce (ce only if ue > 0), inflated in parallel
+        std::vector<Block> bl;
+        uint64_t off = cb;
+        while (off < f.size && (off < ce || (off == ce && ue > 0))) {
+            Block b;
+            if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "BAI points at a malformed BGZF block in %s", path.c_str());
+            bl.push_back(b);
+            off += b.csize;
+        }
+        if (bl.empty()) continue;
+        std::vector<uint8_t> buf;
+        rc = inflate_batch(f, bl, 0, bl.size(), threads, buf);
+        if (rc) return rc;
+        uint64_t limit = 0;
+        for (const Block &b : bl) { if (b.coff == ce) break; limit += b.isize; }
+        limit += ue;                       // stream position (relative to block cb) of the chunk end
+        if (ub > buf.size()) return fail(BSIG_ERR_FORMAT, "BAI offset beyond its BGZF block in %s", path.c_str());
+        parser.set_position(ub);
+        parser.set_limit(limit);
+        rc = parser.feed(buf.data() + ub, buf.size() - ub);
+        if (rc) return rc;
+        // a record that starts before the chunk end may continue in the following blocks
+        while (parser.pending() && !parser.reached_limit() && off < f.size) {
+            Block b;
+            if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block in %s", path.c_str());
+            std::vector<uint8_t> more(b.isize);
+            if (!inf1.run(f.data + b.coff + b.doff, b.dlen, more.data(), b.isize)) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+            rc = parser.feed(more.data(), more.size());
+            if (rc) return rc;
+            off += b.csize;
+        }
+    }
+    parser.finish_refs();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// writer: BGZF blocks + BAI
+// ---------------------------------------------------------------------------------------------
+struct BamWriter::Impl {
+    FILE *fp = nullptr;
+    std::string path;
+    int level = 6;
+    std::vector<uint8_t> ubuf;               // current uncompressed block
+    uint64_t coff = 0;                       // file offset of the current block
+    Deflater *defl = nullptr;
+    int n_ref = 0;
+    // index under construction
+    struct RefIdx {
+        std::map<uint32_t, std::vector<BaiChunk>> bins;
+        std::vector<uint64_t> linear;
+        uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0, n_unmapped = 0;
+        uint32_t last_bin = ~0u;
+    };
+    std::vector<RefIdx> ridx;
+    uint64_t n_no_coor = 0;
+    int last_rid = -1, last_pos = -1;
+    bool sorted = true;
+
+    static constexpr size_t kBlockData = 0xff00;   // htslib's BGZF_BLOCK_SIZE
+
+    uint64_t tell() const { return coff << 16 | (uint64_t)ubuf.size(); }
+
+    int flush_block()
+    {
+        if (ubuf.empty()) return 0;
+        return write_block(ubuf.data(), ubuf.size());
+    }
+
+    int write_block(const uint8_t *data, size_t n)
+    {
+        uint8_t out[0x10000 + 64];
+        size_t clen = n ? defl->run(data, n, out + 18, 0x10000 - 18 - 8) : 0;
+        if (n && clen == 0) {
+            // incompressible: store with level 0 through zlib
+            Deflater store(0);
+            clen = store.run(data, n, out + 18, 0x10000 + 64 - 18 - 8);
+            if (clen == 0 || clen + 26 > 0x10000) return fail(BSIG_ERR_IO, "BGZF block does not fit");
+        }
+        if (n == 0) { out[18] = 3; out[19] = 0; clen = 2; }      // empty final deflate block
+        static const uint8_t head[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
+        memcpy(out, head, 12);
+        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+        const uint16_t bsize = (uint16_t)(clen + 25);
+        memcpy(out + 16, &bsize, 2);
+        const uint32_t crc = crc32_of(data, n), isz = (uint32_t)n;
+        memcpy(out + 18 + clen, &crc, 4);
+        memcpy(out + 22 + clen, &isz, 4);
+        const size_t total = clen + 26;
+        if (fwrite(out, 1, total, fp) != total) return fail(BSIG_ERR_IO, "write to %s failed", path.c_str());
+        coff += total;
+        ubuf.clear();
+        return 0;
+    }
+
+    int append(const uint8_t *d, size_t n, bool keep_together)
+    {
+        if (keep_together && ubuf.size() + n > kBlockData && !ubuf.empty()) {
+            const int rc = flush_block();
+            if (rc) return rc;
+        }
+        while (n) {
+            const size_t take = std::min(n, kBlockData - ubuf.size());
+            ubuf.insert(ubuf.end(), d, d + take);
+            d += take; n -= take;
+            if (ubuf.size() == kBlockData) { const int rc = flush_block(); if (rc) return rc; }
+        }
+        return 0;
+    }
+
+    void index_push(int rid, int64_t beg, int64_t end, uint64_t v0, uint64_t v1, bool mapped)
+    {
+        if (rid < 0) { ++n_no_coor; return; }
+        RefIdx &R = ridx[(size_t)rid];
+        const uint32_t bin = reg2bin(beg, end);
+        if (bin == R.last_bin && !R.bins[bin].empty()) R.bins[bin].back().end = v1;
+        else R.bins[bin].push_back(BaiChunk{v0, v1});
+        R.last_bin = bin;
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (R.linear.size() <= w1) R.linear.resize(w1 + 1, ~0ull);
+        for (size_t w = w0; w <= w1; ++w)
+            if (R.linear[w] == ~0ull) R.linear[w] = v0;
+        R.off_beg = std::min(R.off_beg, v0);
+        R.off_end = std::max(R.off_end, v1);
+        if (mapped) ++R.n_mapped; else ++R.n_unmapped;
+    }
+
+    int write_bai()
+    {
+        const std::string bp = path + ".bai";
+        FILE *o = fopen(bp.c_str(), "wb");
+        if (!o) return fail(BSIG_ERR_IO, "cannot write %s", bp.c_str());
+        auto w32 = [&](uint32_t v) { fwrite(&v, 4, 1, o); };
+        auto w64 = [&](uint64_t v) { fwrite(&v, 8, 1, o); };
+        fwrite("BAI\1", 1, 4, o);
+        w32((uint32_t)n_ref);
+        for (RefIdx &R : ridx) {
+            // linear index: windows without a read inherit the next window's offset (as htslib does)
+            for (size_t k = R.linear.size(); k-- > 0;)
+                if (R.linear[k] == ~0ull) R.linear[k] = k + 1 < R.linear.size() ? R.linear[k + 1] : R.off_end;
+            const bool any = R.n_mapped + R.n_unmapped > 0;
+            w32((uint32_t)(R.bins.size() + (any ? 1 : 0)));
+            for (auto &kv : R.bins) {
+                w32(kv.first);
+                w32((uint32_t)kv.second.size());
+                for (const BaiChunk &c : kv.second) { w64(c.beg); w64(c.end); }
+            }
+            if (any) {          // pseudo-bin 37450: file span + mapped/unmapped counts
+                w32(37450); w32(2);
+                w64(R.off_beg); w64(R.off_end); w64(R.n_mapped); w64(R.n_unmapped);
+            }
+            w32((uint32_t)R.linear.size());
+            for (uint64_t v : R.linear) w64(v);
+        }
+        w64(n_no_coor);
+        if (fclose(o) != 0) return fail(BSIG_ERR_IO, "cannot write %s", bp.c_str());
+        return 0;
+    }
+};
+
+BamWriter::BamWriter() : p_(new Impl) {}
+BamWriter::~BamWriter()
+{
+    if (p_->fp) fclose(p_->fp);
+    delete p_->defl;
+    delete p_;
+}
+
+int BamWriter::open(const std::string &path, const BamHeader &hdr, int level)
+{
+    p_->fp = fopen(path.c_str(), "wb");
+    if (!p_->fp) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    p_->path = path;
+    p_->level = level;
+    p_->defl = new Deflater(level);
+    p_->n_ref = (int)hdr.names.size();
+    p_->ridx.assign(hdr.names.size(), Impl::RefIdx());
+    std::vector<uint8_t> h;
+    auto put32 = [&](int32_t v) { const uint8_t *b = (const uint8_t *)&v; h.insert(h.end(), b, b + 4); };
+    h.insert(h.end(), {'B', 'A', 'M', 1});
+    put32((int32_t)hdr.text.size());
+    h.insert(h.end(), hdr.text.begin(), hdr.text.end());
+    put32((int32_t)hdr.names.size());
+    for (size_t r = 0; r < hdr.names.size(); ++r) {
+        put32((int32_t)hdr.names[r].size() + 1);
+        h.insert(h.end(), hdr.names[r].begin(), hdr.names[r].end());
+        h.push_back(0);
+        put32(hdr.lens[r]);
+    }
+    int rc = p_->append(h.data(), h.size(), false);
+    if (rc) return rc;
+    return p_->flush_block();      // records start in a fresh block, as samtools writes them
+}
+
+static int64_t cigar_rlen(const uint32_t *cig, int n, uint16_t flag)
+{
+    int64_t rlen = 0;
+    if (!(flag & 0x4))
+        for (int k = 0; k < n; ++k)
+            if ((0x18Du >> (cig[k] & 0xF)) & 1u) rlen += cig[k] >> 4;
+    return rlen ? rlen : 1;
+}
+
+static const char *kSeqNt16 = "=ACMGRSVTWYHKDBN";
+
+int BamWriter::write(const BamRecord &r)
+{
+    std::vector<uint8_t> b;
+    const size_t l_name = r.name.size() + 1;
+    if (l_name > 255) return fail(BSIG_ERR_FORMAT, "read name longer than 254 characters");
+    if (r.cigar.size() > 65535) return fail(BSIG_ERR_FORMAT, "more than 65535 CIGAR operations are not supported by the writer");
+    const size_t l_seq = r.seq.size();
+    const size_t bs = 32 + l_name + 4 * r.cigar.size() + (l_seq + 1) / 2 + l_seq + r.aux.size();
+    b.resize(4 + bs);
+    const int64_t endpos = (int64_t)r.pos + cigar_rlen(r.cigar.data(), (int)r.cigar.size(), r.flag);
+    const int32_t bs32 = (int32_t)bs;
+    const uint16_t bin = (uint16_t)reg2bin(std::max(r.pos, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)r.cigar.size();
+    const int32_t lseq32 = (int32_t)l_seq;
+    uint8_t *p = b.data();
+    memcpy(p, &bs32, 4); memcpy(p + 4, &r.rid, 4); memcpy(p + 8, &r.pos, 4);
+    p[12] = (uint8_t)l_name; p[13] = r.mapq;
+    memcpy(p + 14, &bin, 2); memcpy(p + 16, &ncig, 2); memcpy(p + 18, &r.flag, 2);
+    memcpy(p + 20, &lseq32, 4); memcpy(p + 24, &r.next_rid, 4); memcpy(p + 28, &r.next_pos, 4); memcpy(p + 32, &r.tlen, 4);
+    memcpy(p + 36, r.name.c_str(), l_name);
+    size_t o = 36 + l_name;
+    if (!r.cigar.empty()) memcpy(p + o, r.cigar.data(), 4 * r.cigar.size());
+    o += 4 * r.cigar.size();
+    for (size_t i = 0; i < l_seq; ++i) {
+        const char *q = strchr(kSeqNt16, toupper((unsigned char)r.seq[i]));
+        const uint8_t code = q && *q ? (uint8_t)(q - kSeqNt16) : 15;
+        if (i & 1) p[o + i / 2] |= code; else p[o + i / 2] = (uint8_t)(code << 4);
+    }
+    o += (l_seq + 1) / 2;
+    for (size_t i = 0; i < l_seq; ++i) p[o + i] = r.qual.size() == l_seq ? (uint8_t)(r.qual[i] - 33) : 0xFF;
+    o += l_seq;
+    if (!r.aux.empty()) memcpy(p + o, r.aux.data(), r.aux.size());
+
+    if (r.rid >= 0 && (r.rid < p_->last_rid || (r.rid == p_->last_rid && r.pos < p_->last_pos))) p_->sorted = false;
+    if (r.rid >= 0) { p_->last_rid = r.rid; p_->last_pos = r.pos; }
+    if (p_->ubuf.size() + b.size() > Impl::kBlockData && !p_->ubuf.empty()) { const int rc = p_->flush_block(); if (rc) return rc; }
+    const uint64_t v0 = p_->tell();
+    const int rc = p_->append(b.data(), b.size(), false);
+    if (rc) return rc;
+    if (r.rid >= p_->n_ref) return fail(BSIG_ERR_FORMAT, "record with refID %d but only %d references", r.rid, p_->n_ref);
+    p_->index_push(r.rid, r.pos, endpos, v0, p_->tell(), !(r.flag & 0x4));
+    return 0;
+}
+
+int BamWriter::write_core(int32_t rid, int32_t pos, uint16_t flag, uint8_t mapq, int32_t tlen,
+                          const uint32_t *cigar, int n_cigar)
+{
+    uint8_t b[4 + 32 + 2 + 4 * 64];
+    if (n_cigar > 64) {
+        BamRecord r;
+        r.rid = rid; r.pos = pos; r.flag = flag; r.mapq = mapq; r.tlen = tlen; r.name = "*";
+        r.cigar.assign(cigar, cigar + n_cigar);
+        return write(r);
+    }
+    const int32_t bs = 32 + 2 + 4 * n_cigar;
+    const int64_t endpos = (int64_t)pos + cigar_rlen(cigar, n_cigar, flag);
+    const uint16_t bin = (uint16_t)reg2bin(std::max(pos, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)n_cigar;
+    const int32_t zero = 0, m1 = -1;
+    memcpy(b, &bs, 4); memcpy(b + 4, &rid, 4); memcpy(b + 8, &pos, 4);
+    b[12] = 2; b[13] = mapq;
+    memcpy(b + 14, &bin, 2); memcpy(b + 16, &ncig, 2); memcpy(b + 18, &flag, 2);
+    memcpy(b + 20, &zero, 4); memcpy(b + 24, &m1, 4); memcpy(b + 28, &m1, 4); memcpy(b + 32, &tlen, 4);
+    b[36] = '*'; b[37] = 0;
+    if (n_cigar) memcpy(b + 38, cigar, 4 * (size_t)n_cigar);
+    const size_t len = 4 + (size_t)bs;
+    if (rid >= 0 && (rid < p_->last_rid || (rid == p_->last_rid && pos < p_->last_pos))) p_->sorted = false;
+    if (rid >= 0) { p_->last_rid = rid; p_->last_pos = pos; }
+    if (p_->ubuf.size() + len > Impl::kBlockData && !p_->ubuf.empty()) { const int rc = p_->flush_block(); if (rc) return rc; }
+    const uint64_t v0 = p_->tell();
+    const int rc = p_->append(b, len, false);
+    if (rc) return rc;
+    if (rid >= p_->n_ref) return fail(BSIG_ERR_FORMAT, "record with refID %d but only %d references", rid, p_->n_ref);
+    p_->index_push(rid, pos, endpos, v0, p_->tell(), !(flag & 0x4));
+    return 0;
+}
+
+int BamWriter::close()
+{
+    if (!p_->fp) return 0;
+    int rc = p_->flush_block();
+    if (rc == 0) rc = p_->write_block(nullptr, 0);         // the 28-byte EOF marker
+    if (fclose(p_->fp) != 0 && rc == 0) rc = fail(BSIG_ERR_IO, "closing %s failed", p_->path.c_str());
+    p_->fp = nullptr;
+    if (rc) return rc;
+    if (!p_->sorted) return fail(BSIG_ERR_FORMAT, "cannot index %s: records are not sorted by coordinate", p_->path.c_str());
+    return p_->write_bai();
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM text -> BAM + BAI (writeSamAsBamAndIndex, ref: src/bamsignals.cpp:496-534)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+bool parse_cigar(const std::string &s, std::vector<uint32_t> &out)
+{
+    out.clear();
+    if (s == "*") return true;
+    uint64_t len = 0;
+    bool have = false;
+    for (char ch : s) {
+        if (ch >= '0' && ch <= '9') { len = len * 10 + (uint64_t)(ch - '0'); have = true; continue; }
+        const char *q = strchr("MIDNSHP=X", ch);
+        if (!q || !have || len >= (1u << 28)) return false;
+        out.push_back((uint32_t)(len << 4 | (uint32_t)(q - "MIDNSHP=X")));
+        len = 0; have = false;
+    }
+    return !have;
+}
+
+template <typename T>
+void put(std::vector<uint8_t> &v, T x)
+{
+    const uint8_t *b = (const uint8_t *)&x;
+    v.insert(v.end(), b, b + sizeof(T));
+}
+
+bool parse_aux(const std::string &f, std::vector<uint8_t> &aux)
+{
+    if (f.size() < 5 || f[2] != ':' || f[4] != ':') return false;
+    const char ty = f[3];
+    const std::string val = f.substr(5);
+    aux.push_back((uint8_t)f[0]); aux.push_back((uint8_t)f[1]);
+    if (ty == 'A') { if (val.size() != 1) return false; aux.push_back('A'); aux.push_back((uint8_t)val[0]); }
+    else if (ty == 'i') {
+        char *e = nullptr;
+        const long long x = strtoll(val.c_str(), &e, 10);
+        if (!e || *e) return false;
+        if (x >= 0) {
+            if (x <= 0xFF) { aux.push_back('C'); put<uint8_t>(aux, (uint8_t)x); }
+            else if (x <= 0xFFFF) { aux.push_back('S'); put<uint16_t>(aux, (uint16_t)x); }
+            else { aux.push_back('I'); put<uint32_t>(aux, (uint32_t)x); }
+        } else {
+            if (x >= -128) { aux.push_back('c'); put<int8_t>(aux, (int8_t)x); }
+            else if (x >= -32768) { aux.push_back('s'); put<int16_t>(aux, (int16_t)x); }
+            else { aux.push_back('i'); put<int32_t>(aux, (int32_t)x); }
+        }
+    } else if (ty == 'f') { aux.push_back('f'); put<float>(aux, strtof(val.c_str(), nullptr)); }
+    else if (ty == 'Z' || ty == 'H') { aux.push_back((uint8_t)ty); aux.insert(aux.end(), val.begin(), val.end()); aux.push_back(0); }
+    else if (ty == 'B') {
+        if (val.empty()) return false;
+        const char sub = val[0];
+        std::vector<std::string> parts;
+        std::stringstream ss(val.size() > 1 ? val.substr(2) : "");
+        for (std::string t; std::getline(ss, t, ',');) parts.push_back(t);
+        aux.push_back('B'); aux.push_back((uint8_t)sub); put<uint32_t>(aux, (uint32_t)parts.size());
+        for (const std::string &t : parts) {
+            switch (sub) {
+            case 'c': put<int8_t>(aux, (int8_t)atoi(t.c_str())); break;
+            case 'C': put<uint8_t>(aux, (uint8_t)atoi(t.c_str())); break;
+            case 's': put<int16_t>(aux, (int16_t)atoi(t.c_str())); break;
+            case 'S': put<uint16_t>(aux, (uint16_t)atoi(t.c_str())); break;
+            case 'i': put<int32_t>(aux, (int32_t)atoll(t.c_str())); break;
+            case 'I': put<uint32_t>(aux, (uint32_t)atoll(t.c_str())); break;
+            case 'f': put<float>(aux, strtof(t.c_str(), nullptr)); break;
+            default: return false;
+            }
+        }
+    } else return false;
+    return true;
+}
+
+}  // namespace
+
+int sam_to_bam_and_index(const std::string &sam_path, const std::string &bam_path)
+{
+    std::ifstream in(sam_path);
+    if (!in) return fail(BSIG_ERR_IO, "Fail to open SAM file %s", sam_path.c_str());
+    BamHeader hdr;
+    std::string line;
+    std::vector<std::string> body;
+    bool header_done = false;
+    BamWriter w;
+    int64_t lineno = 0;
+    auto start_writer = [&]() -> int {
+        header_done = true;
+        return w.open(bam_path, hdr);
+    };
+    while (std::getline(in, line)) {
+        ++lineno;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '@' && !header_done) {
+            hdr.text += line + "\n";
+            if (line.compare(0, 3, "@SQ") == 0) {
+                std::string sn; long long ln = -1;
+                std::stringstream ss(line);
+                for (std::string t; std::getline(ss, t, '\t');) {
+                    if (t.compare(0, 3, "SN:") == 0) sn = t.substr(3);
+                    else if (t.compare(0, 3, "LN:") == 0) ln = atoll(t.c_str() + 3);
+                }
+                if (sn.empty() || ln < 0) return fail(BSIG_ERR_FORMAT, "malformed @SQ line %lld in %s", (long long)lineno, sam_path.c_str());
+                hdr.names.push_back(sn); hdr.lens.push_back((int32_t)ln);
+            }
+            continue;
+        }
+        if (!header_done) { const int rc = start_writer(); if (rc) return rc; }
+        std::vector<std::string> f;
+        {
+            size_t a = 0;
+            for (;;) {
+                const size_t t = line.find('\t', a);
+                f.push_back(line.substr(a, t == std::string::npos ? std::string::npos : t - a));
+                if (t == std::string::npos) break;
+                a = t + 1;
+            }
+        }
+        if (f.size() < 11) return fail(BSIG_ERR_FORMAT, "SAM line %lld of %s has fewer than 11 fields", (long long)lineno, sam_path.c_str());
+        BamRecord r;
+        r.name = f[0];
+        r.flag = (uint16_t)atoi(f[1].c_str());
+        r.rid = f[2] == "*" ? -1 : hdr.name2id(f[2]);
+        if (f[2] != "*" && r.rid < 0) return fail(BSIG_ERR_FORMAT, "SAM line %lld: unknown reference %s", (long long)lineno, f[2].c_str());
+        r.pos = atoi(f[3].c_str()) - 1;
+        r.mapq = (uint8_t)atoi(f[4].c_str());
+        if (!parse_cigar(f[5], r.cigar)) return fail(BSIG_ERR_FORMAT, "SAM line %lld: malformed CIGAR %s", (long long)lineno, f[5].c_str());
+        r.next_rid = f[6] == "*" ? -1 : f[6] == "=" ? r.rid : hdr.name2id(f[6]);
+        r.next_pos = atoi(f[7].c_str()) - 1;
+        r.tlen = atoi(f[8].c_str());
+        if (f[9] != "*") r.seq = f[9];
+        if (f[10] != "*") r.qual = f[10];
+        for (size_t k = 11; k < f.size(); ++k)
+            if (!f[k].empty() && !parse_aux(f[k], r.aux)) return fail(BSIG_ERR_FORMAT, "SAM line %lld: malformed tag %s", (long long)lineno, f[k].c_str());
+        const int rc = w.write(r);
+        if (rc) return rc;
+    }
+    if (!header_done) { const int rc = start_writer(); if (rc) return rc; }
+    return w.close();
+}
+
+}  // namespace bsig

@@ -1,0 +1,94 @@
+// Self-contained BGZF / BAM / BAI reader and writer (CPU decode stage).
+//
+// The reference reaches BAM files only through htslib (via Rhtslib; call sites
+// src/bamsignals.cpp:95,202,207,267,271,505-531).  htslib is not part of this build, so the
+// binary layouts are implemented here from the SAM/BAM specification (sections 4.1, 4.2, 5.2).
+// Inflate/deflate use libdeflate when the shared object can be dlopen()ed, zlib otherwise.
+#ifndef BSIG_BAMIO_H
+#define BSIG_BAMIO_H
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace bsig {
+
+struct BamHeader {
+    std::string text;                 // SAM header text
+    std::vector<std::string> names;   // reference names, in BAM order
+    std::vector<int32_t> lens;
+    int name2id(const std::string &n) const
+    {
+        for (size_t i = 0; i < names.size(); ++i)
+            if (names[i] == n) return (int)i;
+        return -1;
+    }
+};
+
+// columns of the placed records (refID >= 0), in file order = sorted by (refID, pos)
+struct HostColumns {
+    std::vector<int64_t> ref_off;     // n_ref + 1
+    std::vector<int32_t> pos, tlen;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<int64_t> cigar_off;   // n + 1
+    std::vector<uint32_t> cigar;
+    int64_t n_unplaced = 0;           // records with refID < 0 (skipped)
+    int64_t size() const { return (int64_t)pos.size(); }
+};
+
+struct BaiChunk { uint64_t beg, end; };
+struct BaiRef {
+    std::vector<std::pair<uint32_t, std::vector<BaiChunk>>> bins;   // sorted by bin number
+    std::vector<uint64_t> linear;                                    // 16 kbp windows
+};
+struct BaiIndex {
+    std::vector<BaiRef> refs;
+    uint64_t n_no_coor = 0;
+};
+
+struct Region { int32_t rid; int64_t beg, end; };   // 0-based half-open
+
+// Whole file -> columns.  threads <= 0: hardware concurrency.
+int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostColumns &cols);
+// Only the BGZF blocks the index lists for `regions` (a superset of the overlapping records,
+// each record at most once, file order kept).
+int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::vector<Region> &regions,
+                       int threads, BamHeader &hdr, HostColumns &cols);
+int bam_read_header(const std::string &path, BamHeader &hdr);
+int bai_load(const std::string &bai_path, BaiIndex &idx);
+
+// One alignment for the writer
+struct BamRecord {
+    int32_t rid = -1, pos = -1;
+    uint8_t mapq = 0;
+    uint16_t flag = 0;
+    int32_t next_rid = -1, next_pos = -1, tlen = 0;
+    std::string name;                 // without NUL
+    std::vector<uint32_t> cigar;      // len << 4 | op
+    std::string seq;                  // bases, or empty for '*'
+    std::string qual;                 // phred+33 text, or empty for '*'
+    std::vector<uint8_t> aux;         // binary tags
+};
+
+// Streaming BAM writer that also builds the BAI (bins + 16-kbp linear index + pseudo-bin).
+class BamWriter {
+public:
+    BamWriter();
+    ~BamWriter();
+    int open(const std::string &path, const BamHeader &hdr, int level = 6);
+    int write(const BamRecord &r);
+    // columnar fast path used for synthetic data: name "*", no sequence
+    int write_core(int32_t rid, int32_t pos, uint16_t flag, uint8_t mapq, int32_t tlen,
+                   const uint32_t *cigar, int n_cigar);
+    int close();                              // flushes, writes EOF block and <path>.bai
+private:
+    struct Impl;
+    Impl *p_;
+};
+
+// writeSamAsBamAndIndex (ref: src/bamsignals.cpp:496-534): text SAM -> BAM + BAI
+int sam_to_bam_and_index(const std::string &sam_path, const std::string &bam_path);
+
+}  // namespace bsig
+#endif

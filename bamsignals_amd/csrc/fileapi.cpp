@@ -1,0 +1,307 @@
+// File-level half of the C ABI: BAM handles, the drop-in bsig_pileup_core / bsig_coverage_core,
+// the BAM writers.  Pure host code; the compute goes through bsig_reads_upload / bsig_plan_*.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bamsignals_abi.h"
+#include "bamio.h"
+#include "host_util.h"
+
+using bsig::fail;
+
+struct bsig_bam {
+    std::string path;
+    bsig::BamHeader hdr;
+    bsig::BaiIndex idx;
+    bsig::HostColumns cols;
+};
+
+namespace {
+
+void fill_columns(const bsig_bam *b, bsig_columns *c)
+{
+    memset(c, 0, sizeof *c);
+    c->n_reads = b->cols.size();
+    c->n_ref = (int32_t)b->hdr.names.size();
+    c->ref_len = b->hdr.lens.data();
+    c->ref_off = b->cols.ref_off.data();
+    c->pos = b->cols.pos.data();
+    c->flag = b->cols.flag.data();
+    c->mapq = b->cols.mapq.data();
+    c->tlen = b->cols.tlen.data();
+    c->end = nullptr;
+    c->cigar_off = b->cols.cigar_off.data();
+    c->cigar = b->cols.cigar.data();
+}
+
+// one BAM decoded to HBM, kept between file-level calls (the reference re-opens file and index on
+// every call, src/bamsignals.cpp:449,479; here the expensive part is the decode + upload)
+struct Cache {
+    std::mutex mu;
+    std::string key;
+    int device = -1;
+    bsig_ctx *ctx = nullptr;
+    bsig_reads *reads = nullptr;
+    void clear()
+    {
+        if (reads) bsig_reads_free(reads);
+        reads = nullptr;
+        key.clear();
+    }
+};
+Cache g_cache;
+
+std::string file_key(const std::string &path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return std::string();
+    return path + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtime) +
+           "|" + std::to_string((long long)st.st_mtim.tv_nsec);
+}
+
+int pick_device(int device)
+{
+    if (device >= 0) return device;
+    if (const char *e = getenv("BAMSIGNALS_DEVICE")) return atoi(e);
+    return 0;
+}
+
+// the common body of pileup_core / coverage_core
+int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+               const char *const *levels, const int32_t *start, const int32_t *width,
+               const int32_t *strand, const bsig_params &prm, int32_t device, int32_t *out,
+               const int64_t *off)
+{
+    if (!bampath) return fail(BSIG_ERR_ARG, "bampath is NULL");
+    if (n < 0 || (n > 0 && (!seq_code || !start || !width || !strand || !levels)))
+        return fail(BSIG_ERR_ARG, "range arrays missing");
+    bsig_bam *bam = nullptr;
+    int rc = bsig_bam_open(bampath, &bam);                       // ref: Bamfile ctor :200-214
+    if (rc) return rc;
+    std::unique_ptr<bsig_bam, void (*)(bsig_bam *)> guard(bam, bsig_bam_close);
+
+    // seqnames -> BAM reference ids, by name (ref: parseRegions :113-120)
+    std::vector<int32_t> level_rid((size_t)n_levels, -2);
+    std::vector<int32_t> rid((size_t)n), loc((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t c = seq_code[i];
+        if (c < 0 || c >= n_levels) return fail(BSIG_ERR_ARG, "seqnames code %d out of range", c);
+        if (level_rid[(size_t)c] == -2) level_rid[(size_t)c] = bsig_bam_name2id(bam, levels[c]);
+        if (level_rid[(size_t)c] < 0)
+            return fail(BSIG_ERR_CHROM, "chromosome %s not present in the bam file", levels[c]);   // ref: :119
+        rid[(size_t)i] = level_rid[(size_t)c];
+        loc[(size_t)i] = start[i] - 1;                          // ref: :131
+        if (width[i] < 0) return fail(BSIG_ERR_ARG, "range %lld has a negative width", (long long)i);
+    }
+    // same argument checks as bsig_plan_create, before any I/O
+    const bool mid = prm.mode != BSIG_MODE_COVERAGE && prm.pe_mid;
+    const bool tspan = prm.mode == BSIG_MODE_COVERAGE && prm.tspan;
+    if ((mid || tspan) && prm.n_tlen_filter != 2)
+        return fail(BSIG_ERR_ARG, "paired-end midpoint/extend needs a 2-element tlen_filter");
+    int64_t ext = prm.mode == BSIG_MODE_COVERAGE ? (tspan ? prm.tlen_filter[1] : 0)
+                                                 : std::llabs((long long)prm.shift) + (mid ? prm.tlen_filter[1] : 0);
+    if (ext < 0) return fail(BSIG_ERR_EXT, "negative 'ext' values don't make sense");             // ref: :243
+
+    const int dev = pick_device(device);
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    if (g_cache.ctx && g_cache.device != dev) {
+        g_cache.clear();
+        bsig_ctx_destroy(g_cache.ctx);
+        g_cache.ctx = nullptr;
+    }
+    if (!g_cache.ctx) {
+        rc = bsig_ctx_create(dev, nullptr, &g_cache.ctx);
+        if (rc) return rc;
+        g_cache.device = dev;
+    }
+
+    // How much of the file do the ranges need?  Small queries decode only the BGZF blocks the
+    // index lists (ref: one bam_itr_queryi per chunk of ranges, :252-267); large ones decode the
+    // whole file once and keep it in HBM for the next call.
+    int64_t genome = 0, wanted = 0;
+    for (int32_t l : bam->hdr.lens) genome += l;
+    for (int64_t i = 0; i < n; ++i) wanted += (int64_t)width[i] + 2 * ext + 16384;
+    const std::string key = file_key(bampath);
+    bsig_reads *reads = nullptr;
+    bool owned = false;
+    const char *force = getenv("BAMSIGNALS_DECODE");   // "all" | "regions" (testing / tuning)
+    bool whole = wanted * 4 > genome;
+    if (force && !strcmp(force, "all")) whole = true;
+    if (force && !strcmp(force, "regions")) whole = false;
+    if (!key.empty() && key == g_cache.key && g_cache.reads) {
+        reads = g_cache.reads;
+    } else {
+        bsig_columns cols;
+        if (whole) {
+            rc = bsig_bam_decode(bam, -1, nullptr, nullptr, nullptr, 0, &cols);
+        } else {
+            std::vector<int64_t> beg((size_t)n), end((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                beg[(size_t)i] = (int64_t)loc[(size_t)i] - ext;
+                end[(size_t)i] = (int64_t)loc[(size_t)i] + width[i] + ext;
+            }
+            rc = bsig_bam_decode(bam, n, rid.data(), beg.data(), end.data(), 0, &cols);
+        }
+        if (rc) return rc;
+        rc = bsig_reads_upload(g_cache.ctx, &cols, &reads);
+        if (rc) return rc;
+        if (whole && !key.empty()) {
+            g_cache.clear();
+            g_cache.reads = reads;
+            g_cache.key = key;
+        } else {
+            owned = true;
+        }
+    }
+    rc = bsig_pileup_columns(g_cache.ctx, reads, n, rid.data(), loc.data(), width, strand, &prm, out, off);
+    if (owned) bsig_reads_free(reads);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsig_bam_open(const char *path, bsig_bam **out)
+{
+    if (!path || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_bam_open");
+    *out = nullptr;
+    std::unique_ptr<bsig_bam> b(new bsig_bam);
+    b->path = path;
+    int rc = bsig::bam_read_header(b->path, b->hdr);
+    if (rc == BSIG_ERR_IO) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path);
+    if (rc) return rc;
+    rc = bsig::bai_load(b->path + ".bai", b->idx);
+    if (rc == BSIG_ERR_NOINDEX) {
+        // samtools also accepts foo.bai next to foo.bam
+        std::string alt = b->path;
+        if (alt.size() > 4 && alt.compare(alt.size() - 4, 4, ".bam") == 0) {
+            alt.replace(alt.size() - 4, 4, ".bai");
+            if (bsig::bai_load(alt, b->idx) == 0) rc = 0;
+        }
+        if (rc) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", path);
+    }
+    if (rc) return rc;
+    *out = b.release();
+    return BSIG_OK;
+}
+
+void bsig_bam_close(bsig_bam *b) { delete b; }
+
+int32_t bsig_bam_n_ref(const bsig_bam *b) { return b ? (int32_t)b->hdr.names.size() : 0; }
+
+const char *bsig_bam_ref_name(const bsig_bam *b, int32_t rid)
+{
+    return (b && rid >= 0 && rid < (int32_t)b->hdr.names.size()) ? b->hdr.names[(size_t)rid].c_str() : nullptr;
+}
+
+int32_t bsig_bam_ref_len(const bsig_bam *b, int32_t rid)
+{
+    return (b && rid >= 0 && rid < (int32_t)b->hdr.lens.size()) ? b->hdr.lens[(size_t)rid] : -1;
+}
+
+int32_t bsig_bam_name2id(const bsig_bam *b, const char *name) { return (b && name) ? b->hdr.name2id(name) : -1; }
+
+int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const int64_t *beg,
+                    const int64_t *end, int32_t threads, bsig_columns *cols)
+{
+    if (!b || !cols) return fail(BSIG_ERR_ARG, "NULL argument to bsig_bam_decode");
+    int rc;
+    bsig::BamHeader h;
+    if (n_regions < 0) {
+        rc = bsig::bam_decode_all(b->path, threads, h, b->cols);
+    } else {
+        if (n_regions > 0 && (!rid || !beg || !end)) return fail(BSIG_ERR_ARG, "region arrays missing");
+        std::vector<bsig::Region> rg((size_t)n_regions);
+        for (int64_t i = 0; i < n_regions; ++i) rg[(size_t)i] = bsig::Region{rid[i], beg[i], end[i]};
+        rc = bsig::bam_decode_regions(b->path, b->idx, rg, threads, h, b->cols);
+    }
+    if (rc) return rc;
+    fill_columns(b, cols);
+    return BSIG_OK;
+}
+
+int bsig_pileup_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                     const char *const *levels, const int32_t *start, const int32_t *width,
+                     const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                     int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss, int32_t requiredF,
+                     int32_t filteredF, int32_t pe_mid, int32_t maxgap, int32_t device, int32_t *out,
+                     const int64_t *off)
+{
+    (void)maxgap;
+    bsig_params p;
+    memset(&p, 0, sizeof p);
+    p.mode = binsize <= 0 ? BSIG_MODE_COUNT : BSIG_MODE_PROFILE;   // ref: allocateList :148
+    p.mapqual = mapqual; p.binsize = binsize; p.shift = shift; p.ss = ss;
+    p.requiredF = requiredF; p.filteredF = filteredF; p.pe_mid = pe_mid;
+    if (n_tlen_filter != 0 && n_tlen_filter != 2) return fail(BSIG_ERR_ARG, "tlen_filter must have 0 or 2 elements");
+    p.n_tlen_filter = n_tlen_filter;
+    for (int k = 0; k < n_tlen_filter; ++k) p.tlen_filter[k] = tlen_filter[k];
+    return file_level(bampath, n, seq_code, n_levels, levels, start, width, strand, p, device, out, off);
+}
+
+int bsig_coverage_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                       const char *const *levels, const int32_t *start, const int32_t *width,
+                       const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                       int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
+                       int32_t maxgap, int32_t device, int32_t *out, const int64_t *off)
+{
+    (void)maxgap;
+    bsig_params p;
+    memset(&p, 0, sizeof p);
+    p.mode = BSIG_MODE_COVERAGE;
+    p.mapqual = mapqual; p.binsize = 1; p.requiredF = requiredF; p.filteredF = filteredF; p.tspan = tspan;
+    if (n_tlen_filter != 0 && n_tlen_filter != 2) return fail(BSIG_ERR_ARG, "tlen_filter must have 0 or 2 elements");
+    p.n_tlen_filter = n_tlen_filter;
+    for (int k = 0; k < n_tlen_filter; ++k) p.tlen_filter[k] = tlen_filter[k];
+    return file_level(bampath, n, seq_code, n_levels, levels, start, width, strand, p, device, out, off);
+}
+
+int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath)
+{
+    if (!sampath || !bampath) return fail(BSIG_ERR_ARG, "NULL path");
+    return bsig::sam_to_bam_and_index(sampath, bampath);
+}
+
+int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *const *ref_names,
+                              const bsig_columns *c, int32_t level)
+{
+    if (!bampath || !c || (n_ref > 0 && !ref_names)) return fail(BSIG_ERR_ARG, "NULL argument");
+    if (c->n_ref != n_ref) return fail(BSIG_ERR_ARG, "n_ref does not match the columns");
+    if (c->n_reads > 0 && (!c->cigar_off || !c->cigar)) return fail(BSIG_ERR_ARG, "the writer needs cigar_off + cigar");
+    bsig::BamHeader h;
+    h.text = "@HD\tVN:1.0\tSO:coordinate\n";
+    for (int r = 0; r < n_ref; ++r) {
+        h.names.emplace_back(ref_names[r]);
+        h.lens.push_back(c->ref_len[r]);
+        h.text += "@SQ\tSN:" + h.names.back() + "\tLN:" + std::to_string(c->ref_len[r]) + "\n";
+    }
+    bsig::BamWriter w;
+    int rc = w.open(bampath, h, level > 0 ? level : 1);
+    if (rc) return rc;
+    for (int r = 0; r < n_ref; ++r)
+        for (int64_t i = c->ref_off[r]; i < c->ref_off[r + 1]; ++i) {
+            rc = w.write_core(r, c->pos[i], c->flag[i], c->mapq[i], c->tlen[i], c->cigar + c->cigar_off[i],
+                              (int)(c->cigar_off[i + 1] - c->cigar_off[i]));
+            if (rc) return rc;
+        }
+    return w.close();
+}
+
+void bsig_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    g_cache.clear();
+    if (g_cache.ctx) bsig_ctx_destroy(g_cache.ctx);
+    g_cache.ctx = nullptr;
+    g_cache.device = -1;
+}
+
+}  // extern "C"

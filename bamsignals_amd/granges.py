@@ -1,0 +1,56 @@
+"""A minimal GRanges: exactly the slots the reference's native code reads
+(``seqnames``, ``ranges@start``, ``ranges@width``, ``strand``; ref: parseRegions,
+src/bamsignals.cpp:92-135).  Coordinates are 1-based and closed, as in GenomicRanges."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class GRanges:
+    def __init__(self, seqnames, start, width=None, end=None, strand="*"):
+        self.start = np.atleast_1d(np.asarray(start, dtype=np.int64)).astype(np.int32)
+        n = len(self.start)
+        if width is None:
+            if end is None:
+                raise ValueError("give width or end")
+            width = np.atleast_1d(np.asarray(end, dtype=np.int64)) - self.start + 1
+        self.width = np.broadcast_to(np.asarray(width, dtype=np.int64), (n,)).astype(np.int32)
+        if np.any(self.width < 0):
+            raise ValueError("negative widths are not allowed")
+        if isinstance(seqnames, str):
+            seqnames = [seqnames] * n
+        self.seqnames = [str(s) for s in seqnames]
+        if isinstance(strand, str):
+            strand = [strand] * n
+        self.strand = [str(s) for s in strand]
+        if len(self.seqnames) != n or len(self.strand) != n:
+            raise ValueError("seqnames, start, width and strand differ in length")
+        bad = set(self.strand) - {"+", "-", "*"}
+        if bad:
+            raise ValueError(f"invalid strand values {sorted(bad)}")
+
+    def __len__(self):
+        return len(self.start)
+
+    @property
+    def end(self):
+        return self.start + self.width - 1
+
+    def __getitem__(self, i):
+        idx = np.arange(len(self))[i]
+        idx = np.atleast_1d(idx)
+        return GRanges([self.seqnames[k] for k in idx], self.start[idx], width=self.width[idx],
+                       strand=[self.strand[k] for k in idx])
+
+    def flatten(self):
+        """(levels, codes, start, width, strand_int) as the C ABI's file-level entry points take them."""
+        levels = list(dict.fromkeys(self.seqnames))
+        lut = {s: k for k, s in enumerate(levels)}
+        codes = np.asarray([lut[s] for s in self.seqnames], dtype=np.int32)
+        strand = np.asarray([1 if s == "+" else -1 if s == "-" else 0 for s in self.strand], dtype=np.int32)
+        return levels, codes, self.start, self.width, strand
+
+    def __repr__(self):
+        head = ", ".join(f"{s}:{a}-{b}:{t}" for s, a, b, t in
+                         list(zip(self.seqnames, self.start, self.end, self.strand))[:4])
+        return f"GRanges with {len(self)} ranges [{head}{', ...' if len(self) > 4 else ''}]"

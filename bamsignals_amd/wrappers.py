@@ -1,0 +1,167 @@
+"""bamCount / bamProfile / bamCoverage: the reference's user API (R/wrappers.R:75-184), with the
+same argument names, defaults, normalisation, warnings, errors and return shapes, over the C ABI.
+
+R is not available in the build image, so this Python module is the host side that can be run
+and tested here; the R files with the identical logic are in bamsignals_amd/r_package/.
+``paired.end`` is spelled ``paired_end``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import random
+import sys
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .countsignals import CountSignals
+from .granges import GRanges
+
+
+def _match_arg(value, choices, name):
+    """R's match.arg: a vector of choices means the first one; unique prefixes are accepted."""
+    if isinstance(value, (list, tuple)):
+        if list(value) == list(choices):
+            return choices[0]
+        if len(value) != 1:
+            raise ValueError(f"'{name}' must be of length 1")
+        value = value[0]
+    hits = [c for c in choices if c.startswith(str(value))] if value != "" else []
+    if value in choices:
+        return value
+    if len(hits) != 1:
+        raise ValueError(f"'{name}' should be one of " + ", ".join(f"‘{c}’" for c in choices))
+    return hits[0]
+
+
+def flagMask(paired_end):
+    """R/wrappers.R:76-81: only the first read of a properly mapped pair (0x2 | 0x40) unless ignored."""
+    return 66 if paired_end != "ignore" else 0
+
+
+def tlenFilter(tlenFilter, paired_end):  # noqa: N802,N803 - reference names
+    """R/wrappers.R:84-98."""
+    if paired_end == "ignore":
+        return ()
+    if tlenFilter is None:
+        return (0, 1000)
+    tf = list(np.atleast_1d(tlenFilter))
+    if len(tf) != 2 or tf[0] < 0 or tf[1] < 0:
+        raise ValueError("tlenFilter must be NULL or vector of 2 positive integers")
+    if tf[0] > tf[1]:
+        raise ValueError("tlenFilter[1] must be smaller or equal to tlenFilter[2]")
+    return (int(tf[0]), int(tf[1]))
+
+
+_SENTENCES = (
+    "tHaT'S tHa fAStEsT pIlE-uP bAm iN tHe SoUth!!!",
+    "yOu cAn'T pIlE-Up FaStEr!!!",
+    "I'M gOnNa cHaSe'em and PiLe'em aLl up!!!",
+    "fOr brOoMmHiLdA!!!",
+    "tHe lEgEnD said, hE cOuLd PiLe uP fAsTeR thAn LiGht",
+    "I gEt gOoSeBuMPs wHen I seE yOu pilEuPpiNg...",
+)
+
+
+def _print_sentence(path):
+    print(f"Processing {path}: {random.choice(_SENTENCES)}", file=sys.stderr)
+
+
+def _check_gr(gr):
+    if not isinstance(gr, GRanges):
+        raise TypeError("must provide a GRanges object")        # ref: src/bamsignals.cpp:93-94
+
+
+def _split(out, off, ss):
+    sigs = []
+    for i in range(len(off) - 1):
+        v = out[off[i]:off[i + 1]]
+        sigs.append(v.reshape(-1, 2).T if ss else v)
+    return sigs
+
+
+def pileup_core(bampath, gr, tlen_filter, mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
+                filteredF=-1, pe_mid=False, maxgap=16385, device=-1):
+    """The native entry point behind bamCount/bamProfile (ref: R/RcppExports.R:12-14).  Returns the
+    R list as a Python list: per-range vectors / 2 x w matrices, or, for binsize <= 0, a list of
+    length one holding the count vector / 2 x n matrix."""
+    _check_gr(gr)
+    lib = _lib.load()
+    levels, codes, start, width, strand = gr.flatten()
+    n = len(gr)
+    off = np.empty(n + 1, dtype=np.int64)
+    cells = lib.bsig_layout(n, width.ctypes.data, int(binsize), int(bool(ss)), off.ctypes.data)
+    out = np.zeros(cells, dtype=np.int32)
+    tf = np.asarray([int(x) for x in tlen_filter], dtype=np.int32)
+    names = (C.c_char_p * max(len(levels), 1))(*[s.encode() for s in levels])
+    _lib.check(lib.bsig_pileup_core(os.path.expanduser(str(bampath)).encode(), n, codes.ctypes.data, len(levels),
+                                    names, start.ctypes.data, width.ctypes.data, strand.ctypes.data,
+                                    tf.ctypes.data, len(tf), int(mapqual), int(binsize), int(shift),
+                                    int(bool(ss)), int(requiredF), int(filteredF), int(bool(pe_mid)),
+                                    int(maxgap), int(device), out.ctypes.data, off.ctypes.data))
+    if binsize <= 0:
+        return [out.reshape(-1, 2).T if ss else out]
+    return _split(out, off, ss)
+
+
+def coverage_core(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1, tspan=False,
+                  maxgap=16385, device=-1):
+    """The native entry point behind bamCoverage (ref: R/RcppExports.R:16-18)."""
+    _check_gr(gr)
+    lib = _lib.load()
+    levels, codes, start, width, strand = gr.flatten()
+    n = len(gr)
+    off = np.empty(n + 1, dtype=np.int64)
+    cells = lib.bsig_layout(n, width.ctypes.data, 1, 0, off.ctypes.data)
+    out = np.zeros(cells, dtype=np.int32)
+    tf = np.asarray([int(x) for x in tlen_filter], dtype=np.int32)
+    names = (C.c_char_p * max(len(levels), 1))(*[s.encode() for s in levels])
+    _lib.check(lib.bsig_coverage_core(os.path.expanduser(str(bampath)).encode(), n, codes.ctypes.data,
+                                      len(levels), names, start.ctypes.data, width.ctypes.data,
+                                      strand.ctypes.data, tf.ctypes.data, len(tf), int(mapqual),
+                                      int(requiredF), int(filteredF), int(bool(tspan)), int(maxgap),
+                                      int(device), out.ctypes.data, off.ctypes.data))
+    return _split(out, off, False)
+
+
+def bamCount(bampath, gr, mapqual=0, shift=0, ss=False, paired_end=("ignore", "filter", "midpoint"),  # noqa: N802
+             tlenFilter=None, filteredFlag=-1, verbose=True):  # noqa: N803
+    """For each range, count the reads whose 5' end maps in it (R/wrappers.R:101-120).
+    Returns an int32 vector, or a 2 x n matrix (rows sense, antisense) with ``ss=True``."""
+    if verbose:
+        _print_sentence(bampath)
+    pe = _match_arg(paired_end, ("ignore", "filter", "midpoint"), "paired.end")
+    pu = pileup_core(os.path.expanduser(str(bampath)), gr, globals()["tlenFilter"](tlenFilter, pe), mapqual, -1,
+                     shift, ss, flagMask(pe), filteredFlag, pe == "midpoint")
+    return pu[0]
+
+
+def bamProfile(bampath, gr, binsize=1, mapqual=0, shift=0, ss=False,  # noqa: N802
+               paired_end=("ignore", "filter", "midpoint"), tlenFilter=None, filteredFlag=-1, verbose=True):  # noqa: N803
+    """For each base pair (or bin) of the ranges, the number of reads whose 5' end maps there
+    (R/wrappers.R:124-151).  Returns a CountSignals."""
+    if verbose:
+        _print_sentence(bampath)
+    if binsize < 1:
+        raise ValueError("provide a binsize greater or equal to 1")
+    _check_gr(gr)
+    if binsize > 1 and np.any(gr.width % binsize != 0):
+        warnings.warn("some ranges' widths are not a multiple of the selected\n"
+                      "             binsize, some bins will correspond to less than binsize basepairs")
+    pe = _match_arg(paired_end, ("ignore", "filter", "midpoint"), "paired.end")
+    pu = pileup_core(os.path.expanduser(str(bampath)), gr, globals()["tlenFilter"](tlenFilter, pe), mapqual,
+                     int(binsize), shift, ss, flagMask(pe), filteredFlag, pe == "midpoint")
+    return CountSignals(pu, bool(ss))
+
+
+def bamCoverage(bampath, gr, mapqual=0, paired_end=("ignore", "extend"), tlenFilter=None,  # noqa: N802,N803
+                filteredFlag=-1, verbose=True):
+    """For each base pair of the ranges, the number of reads covering it (R/wrappers.R:154-173)."""
+    if verbose:
+        _print_sentence(bampath)
+    pe = _match_arg(paired_end, ("ignore", "extend"), "paired.end")
+    pu = coverage_core(os.path.expanduser(str(bampath)), gr, globals()["tlenFilter"](tlenFilter, pe), mapqual,
+                       flagMask(pe), filteredFlag, pe == "extend")
+    return CountSignals(pu, False)

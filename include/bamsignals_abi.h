@@ -154,6 +154,59 @@ int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges
                         const int32_t *strand, const bsig_params *params,
                         int32_t *out_host, const int64_t *off);
 
+/* ------------------------------------------------------------------------------------------
+ * CPU decode stage: BAM (+ BAI) -> columnar arrays.  Replaces what the reference gets from
+ * htslib: sam_open / bam_index_load (ref: src/bamsignals.cpp:200-214), sam_hdr_read +
+ * bam_name2id (ref: :26-28, :95), bam_itr_queryi / bam_itr_next (ref: :267-271).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bsig_bam bsig_bam;
+/* opens <path> and loads <path>.bai; errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the reference's
+ * messages (ref: src/bamsignals.cpp:204,209)                                                  */
+int bsig_bam_open(const char *path, bsig_bam **bam);
+void bsig_bam_close(bsig_bam *bam);
+int32_t bsig_bam_n_ref(const bsig_bam *bam);
+const char *bsig_bam_ref_name(const bsig_bam *bam, int32_t rid);
+int32_t bsig_bam_ref_len(const bsig_bam *bam, int32_t rid);
+int32_t bsig_bam_name2id(const bsig_bam *bam, const char *name);          /* -1 if absent        */
+/* Decode the records the index lists for the regions [beg, end) (0-based) into host columns
+ * owned by the handle (valid until the next decode or close).  n_regions < 0: whole file.
+ * threads <= 0: all hardware threads (env BAMSIGNALS_THREADS).  cols->end is NULL and
+ * cols->cigar_off / cols->cigar are filled: the GPU derives bam_endpos.                        */
+int bsig_bam_decode(bsig_bam *bam, int64_t n_regions, const int32_t *rid, const int64_t *beg,
+                    const int64_t *end, int32_t threads, bsig_columns *cols);
+
+/* ------------------------------------------------------------------------------------------
+ * File-level drop-in entry points: what the R shim's .Call routines bind.
+ * Ranges come as GRanges slots flattened by the shim (ref: parseRegions, src/bamsignals.cpp:
+ * 92-135): seq_code[i] indexes seq_levels (the factor levels of seqnames, mapped to BAM ids BY
+ * NAME), start is 1-based, strand is +1 / -1 / 0.  out/off as in bsig_layout().
+ * device < 0: env BAMSIGNALS_DEVICE or 0.  maxgap is accepted for signature parity with the
+ * reference (ref: src/bamsignals.cpp:446,476) and does not influence the result.
+ * ------------------------------------------------------------------------------------------ */
+/* replaces bamsignals_pileup_core (ref: src/RcppExports.cpp:33-52 -> src/bamsignals.cpp:444-461) */
+int bsig_pileup_core(const char *bampath, int64_t n_ranges, const int32_t *seq_code,
+                     int32_t n_seq_levels, const char *const *seq_levels, const int32_t *start,
+                     const int32_t *width, const int32_t *strand,
+                     const int32_t *tlen_filter, int32_t n_tlen_filter,
+                     int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss,
+                     int32_t requiredF, int32_t filteredF, int32_t pe_mid, int32_t maxgap,
+                     int32_t device, int32_t *out, const int64_t *off);
+/* replaces bamsignals_coverage_core (ref: src/RcppExports.cpp:54-70 -> src/bamsignals.cpp:474-494) */
+int bsig_coverage_core(const char *bampath, int64_t n_ranges, const int32_t *seq_code,
+                       int32_t n_seq_levels, const char *const *seq_levels, const int32_t *start,
+                       const int32_t *width, const int32_t *strand,
+                       const int32_t *tlen_filter, int32_t n_tlen_filter,
+                       int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
+                       int32_t maxgap, int32_t device, int32_t *out, const int64_t *off);
+/* replaces bamsignals_writeSamAsBamAndIndex (ref: src/bamsignals.cpp:496-534): text SAM ->
+ * BAM + <bampath>.bai                                                                          */
+int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath);
+/* columnar writer used for synthetic BAMs: coordinate-sorted columns -> BAM + BAI             */
+int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *const *ref_names,
+                              const bsig_columns *cols, int32_t level);
+/* drops the per-process cache of BAMs decoded to HBM by the file-level entry points           */
+void bsig_cache_clear(void);
+
 #ifdef __cplusplus
 }
 #endif

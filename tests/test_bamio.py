@@ -1,0 +1,242 @@
+"""CPU: the self-contained BGZF/BAM/BAI reader and writer (csrc/bamio.cpp) against the reference's
+fixture BAM (written by htslib) and against known answers built from the SAM/BAM spec."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+BAM = os.path.join(GOLDEN, "randomBam.bam")
+
+
+def _cols_equal(got, fx):
+    assert np.array_equal(got["pos"], fx["bam_pos"])
+    assert np.array_equal(got["flag"], fx["bam_flag"])
+    assert np.array_equal(got["mapq"], fx["bam_mapq"])
+    assert np.array_equal(got["tlen"], fx["bam_tlen"])
+    assert np.array_equal(got["cigar_off"], fx["bam_cigar_off"])
+    assert np.array_equal(got["cigar"], fx["bam_cigar"])
+    assert np.array_equal(got["ref_off"], fx["ref_off"])
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_decode_reference_fixture(fixture_reads, threads):
+    from bamsignals_amd.bamio import BamFile
+    b = BamFile(BAM)
+    assert b.ref_names == ["chr1", "chr2", "chr3"]
+    assert list(b.ref_len) == [10237, 10279, 10238]
+    assert b.name2id("chr3") == 2 and b.name2id("chrX") == -1
+    _cols_equal(b.decode(threads=threads), fixture_reads)
+    b.close()
+
+
+def test_decode_with_zlib_only(fixture_reads, monkeypatch):
+    """the zlib fallback of the inflater gives the same columns as libdeflate"""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from bamsignals_amd.bamio import BamFile; "
+            "c = BamFile(%r).decode(); print(int(c['pos'].sum()), len(c['pos']))" % (os.path.dirname(os.path.dirname(GOLDEN)), BAM))
+    env = dict(os.environ, BAMSIGNALS_NO_LIBDEFLATE="1")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
+    assert int(out[0]) == int(fixture_reads["bam_pos"].astype(np.int64).sum()) and int(out[1]) == 99000
+
+
+def test_region_decode_is_a_superset_in_file_order(fixture_reads):
+    from bamsignals_amd.bamio import BamFile
+    fx = fixture_reads
+    b = BamFile(BAM)
+    rid = np.asarray([2, 0, 0], dtype=np.int32)
+    beg = np.asarray([100, 5000, 5100], dtype=np.int64)
+    end = np.asarray([900, 5200, 5600], dtype=np.int64)
+    got = b.decode(rid, beg, end)
+    key = got["rid"].astype(np.int64) << 32 | got["pos"]
+    assert np.all(np.diff(key) >= 0)
+    # every overlapping record is there, exactly once
+    for r, s, e in zip(rid, beg, end):
+        m = (fx["bam_rid"] == r) & (fx["bam_pos"] < e) & (fx["bam_end"] + 1 > s)
+        gm = (got["rid"] == r) & (got["pos"] < e)
+        want = np.stack([fx["bam_pos"][m], fx["bam_flag"][m], fx["bam_tlen"][m]], 1)
+        have = np.stack([got["pos"][gm], got["flag"][gm].astype(np.int32), got["tlen"][gm]], 1)
+        ws = {tuple(x) for x in want}
+        hs = {tuple(x) for x in have}
+        assert ws <= hs
+    assert got["ref_off"][1] == got["ref_off"][2]          # nothing asked on chr2
+    b.close()
+
+
+def test_errors_match_the_reference(tmp_path):
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    with pytest.raises(_lib.BsigError) as e:
+        BamFile(str(tmp_path / "nope.bam"))
+    assert e.value.code_name == "BSIG_ERR_IO" and "Fail to open BAM file" in str(e.value)      # ref :204
+    p = tmp_path / "noidx.bam"
+    p.write_bytes(open(BAM, "rb").read())
+    with pytest.raises(_lib.BsigError) as e:
+        BamFile(str(p))
+    assert e.value.code_name == "BSIG_ERR_NOINDEX"
+    assert "BAM indexing file is not available for file" in str(e.value)                       # ref :209
+    q = tmp_path / "junk.bam"
+    q.write_bytes(b"this is not a bam file at all, not even close.....")
+    (tmp_path / "junk.bam.bai").write_bytes(open(BAM + ".bai", "rb").read())
+    with pytest.raises(_lib.BsigError) as e:
+        BamFile(str(q))
+    assert e.value.code_name == "BSIG_ERR_FORMAT"
+
+
+def _synth(n=60_000, seed=3):
+    from bamsignals_amd.synth import synth_reads
+    return synth_reads(n, [3_000_000, 40_000, 1_500_000], seed=seed)
+
+
+def test_writer_roundtrip_and_multibin_index(tmp_path):
+    """columns -> BAM+BAI -> columns; the index spans many 16-kbp windows and bins here."""
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    cols = _synth()
+    p = str(tmp_path / "synth.bam")
+    write_columns_as_bam(p, ["chrA", "chrB", "chrC"], cols)
+    # the file is valid BGZF (= concatenated gzip members) with the 28-byte EOF marker
+    raw = open(p, "rb").read()
+    assert raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    stream = gzip.decompress(raw)
+    assert stream[:4] == b"BAM\x01"
+    b = BamFile(p)
+    got = b.decode()
+    for k in ("pos", "flag", "mapq", "tlen", "cigar_off", "cigar", "ref_off"):
+        assert np.array_equal(got[k], cols[k]), k
+    # region queries through our own BAI: superset of the truly overlapping reads, no duplicates
+    rng = np.random.default_rng(1)
+    for _ in range(25):
+        r = int(rng.integers(0, 3))
+        s = int(rng.integers(0, cols["ref_len"][r]))
+        e = s + int(rng.integers(1, 200_000))
+        sub = b.decode([r], [s], [e])
+        m = (cols["rid"] == r) & (cols["pos"] < e) & (cols["end"] + 1 > s)
+        sm = (sub["rid"] == r) & (sub["pos"] < e)
+        from oracle import oracle_np
+        sub_end = oracle_np.cigar_end(sub["pos"], sub["flag"], sub["cigar_off"], sub["cigar"])
+        sm &= sub_end + 1 > s
+        assert int(sm.sum()) == int(m.sum())
+        assert np.array_equal(sub["pos"][sm], cols["pos"][m])
+        assert len(sub["pos"]) < len(cols["pos"])
+    b.close()
+    # BAI structure: magic, n_ref, per-ref linear index of ceil(last_end / 16384) windows
+    bai = open(p + ".bai", "rb").read()
+    assert bai[:4] == b"BAI\x01" and struct.unpack_from("<i", bai, 4)[0] == 3
+
+
+def test_bai_of_fixture_equivalent_bam_matches_htslib_layout(tmp_path, fixture_reads):
+    """Re-emit the reference fixture with our writer: the BAI has the same shape as htslib's
+    (per reference: leaf bin 4681 with one chunk + pseudo-bin 37450 with the mapped counts, one
+    linear-index window, trailing n_no_coor = 0)."""
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    fx = fixture_reads
+    cols = dict(ref_len=fx["ref_len"], ref_off=fx["ref_off"], pos=fx["bam_pos"], flag=fx["bam_flag"],
+                mapq=fx["bam_mapq"], tlen=fx["bam_tlen"], cigar_off=fx["bam_cigar_off"], cigar=fx["bam_cigar"])
+    p = str(tmp_path / "re.bam")
+    write_columns_as_bam(p, ["chr1", "chr2", "chr3"], cols, level=6)
+    _cols_equal(BamFile(p).decode(), fx)
+
+    def parse(bai):
+        o = 8
+        out = []
+        for _ in range(struct.unpack_from("<i", bai, 4)[0]):
+            nb = struct.unpack_from("<i", bai, o)[0]; o += 4
+            bins = {}
+            for _ in range(nb):
+                b, nc = struct.unpack_from("<Ii", bai, o); o += 8
+                bins[b] = [struct.unpack_from("<QQ", bai, o + 16 * k) for k in range(nc)]
+                o += 16 * nc
+            ni = struct.unpack_from("<i", bai, o)[0]; o += 4
+            lin = struct.unpack_from("<%dQ" % ni, bai, o); o += 8 * ni
+            out.append((bins, lin))
+        return out, struct.unpack_from("<Q", bai, o)[0]
+
+    ours, nn = parse(open(p + ".bai", "rb").read())
+    ref, rn = parse(open(BAM + ".bai", "rb").read())
+    assert nn == rn == 0
+    for (b1, l1), (b2, l2) in zip(ours, ref):
+        assert set(b1) == set(b2) == {4681, 37450}
+        assert len(b1[4681]) == len(b2[4681]) == 1 and len(l1) == len(l2) == 1
+        assert b1[37450][1] == b2[37450][1]            # (n_mapped, n_unmapped)
+
+
+def test_sam_to_bam(tmp_path):
+    from bamsignals_amd.bamio import BamFile, writeSamAsBamAndIndex
+    sam = tmp_path / "t.sam"
+    sam.write_text(
+        "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:5000\n@SQ\tSN:chr2\tLN:3000\n"
+        "r1\t99\tchr1\t101\t30\t20M\t=\t201\t120\t*\t*\n"
+        "r2\t16\tchr1\t150\t7\t5S10M2D10M3I5M\t*\t0\t0\tACGTNACGTNACGTNACGTNACGTNACGTNACG\t*\tNM:i:3\tXS:Z:hello\tXB:B:s,1,-2,300\n"
+        "r3\t147\tchr1\t201\t30\t20M\t=\t101\t-120\t*\t*\tXA:A:c\tXF:f:1.5\tXL:i:-70000\n"
+        "r4\t4\tchr2\t10\t0\t*\t*\t0\t0\tACGT\tIIII\n"
+        "r5\t0\tchr2\t500\t60\t10M1000N10M\t*\t0\t0\t*\t*\n")
+    bam = str(tmp_path / "t.bam")
+    assert writeSamAsBamAndIndex(str(sam), bam) is True
+    assert os.path.exists(bam + ".bai")
+    b = BamFile(bam)
+    c = b.decode()
+    assert list(c["pos"]) == [100, 149, 200, 9, 499]
+    assert list(c["flag"]) == [99, 16, 147, 4, 0]
+    assert list(c["mapq"]) == [30, 7, 30, 0, 60]
+    assert list(c["tlen"]) == [120, 0, -120, 0, 0]
+    assert list(c["ref_off"]) == [0, 3, 5]
+    assert list(np.diff(c["cigar_off"])) == [1, 6, 1, 0, 3]
+    from oracle import oracle_np
+    end = oracle_np.cigar_end(c["pos"], c["flag"], c["cigar_off"], c["cigar"])
+    assert list(end) == [119, 149 + 27 - 1, 219, 9, 499 + 1020 - 1]
+    # byte-level check of the second record against the SAM spec (section 4.2)
+    stream = gzip.decompress(open(bam, "rb").read())
+    i = stream.rindex(b"r2\x00") - 36      # the last match: "chr2\0" of the header comes first
+    bs, rid, pos, lrn, mq, bin_, ncig, flag, lseq, nrid, npos, tlen = struct.unpack_from("<iiiBBHHHiiii", stream, i)
+    assert (rid, pos, lrn, mq, ncig, flag, lseq, nrid, npos, tlen) == (0, 149, 3, 7, 6, 16, 33, -1, -1, 0)
+    assert bin_ == 4681
+    seq = stream[i + 36 + 3 + 24:i + 36 + 3 + 24 + 17]
+    assert seq[0] == 0x12 and seq[1] == 0x48           # A=1 C=2 | G=4 T=8
+    aux = stream[i + 36 + 3 + 24 + 17 + 33:i + 4 + bs]
+    assert aux.startswith(b"NMC\x03XSZhello\x00XBBs\x03\x00\x00\x00\x01\x00\xfe\xff\x2c\x01")
+    # sorted check: an unsorted SAM cannot be indexed
+    bad = tmp_path / "bad.sam"
+    bad.write_text("@SQ\tSN:chr1\tLN:5000\nr1\t0\tchr1\t300\t30\t20M\t*\t0\t0\t*\t*\nr2\t0\tchr1\t100\t30\t20M\t*\t0\t0\t*\t*\n")
+    from bamsignals_amd import _lib
+    with pytest.raises(_lib.BsigError):
+        writeSamAsBamAndIndex(str(bad), str(tmp_path / "bad.bam"))
+
+
+def test_long_cigar_cg_tag(tmp_path):
+    """> 65535 operations: kSmN placeholder + CG:B,I tag (SAM spec 4.2.2)."""
+    from bamsignals_amd.bamio import BamFile
+    # hand-build a BAM with one such record
+    ops = [(1 << 4) | 0, (1 << 4) | 2] * 40000      # 1M1D x 40000 = 80000 ops, span 80000
+    lseq = 40000
+    name = b"long\x00"
+    cig_placeholder = struct.pack("<II", lseq << 4 | 4, 80000 << 4 | 3)
+    seq = bytes((lseq + 1) // 2)
+    qual = b"\xff" * lseq
+    aux = b"CGBI" + struct.pack("<I", len(ops)) + struct.pack("<%dI" % len(ops), *ops)
+    body = struct.pack("<iiBBHHHiiii", 0, 1000, len(name), 50, 4681, 2, 0, lseq, -1, -1, 0) + name + cig_placeholder + seq + qual + aux
+    rec = struct.pack("<i", len(body)) + body
+    text = b"@SQ\tSN:c\tLN:200000\n"
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\x00" + struct.pack("<i", 200000)
+    stream = hdr + rec
+
+    def bgzf(data):
+        out = b""
+        for i in range(0, len(data), 60000):
+            import zlib
+            chunk = data[i:i + 60000]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = co.compress(chunk) + co.flush()
+            out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        return out + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+    p = tmp_path / "long.bam"
+    p.write_bytes(bgzf(stream))
+    # minimal BAI: no bins, no linear index
+    (tmp_path / "long.bam.bai").write_bytes(b"BAI\x01" + struct.pack("<i", 1) + struct.pack("<ii", 0, 0) + struct.pack("<Q", 0))
+    c = BamFile(str(p)).decode()
+    assert len(c["pos"]) == 1 and c["cigar_off"][-1] == 80000
+    assert np.array_equal(c["cigar"], np.asarray(ops, dtype=np.uint32))
