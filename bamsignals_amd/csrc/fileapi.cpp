@@ -295,6 +295,20 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
     return w.close();
 }
 
+int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off, int32_t *dst,
+                          const int64_t *dst_off, const int64_t *which)
+{
+    if (n > 0 && (!src_off || !dst_off || !which)) return fail(BSIG_ERR_ARG, "NULL argument");
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t len = src_off[k + 1] - src_off[k];
+        const int64_t i = which[k];
+        if (len < 0 || i < 0) return fail(BSIG_ERR_ARG, "bad segment %lld", (long long)k);
+        if (len != dst_off[i + 1] - dst_off[i]) return fail(BSIG_ERR_ARG, "segment %lld does not fit its destination", (long long)k);
+        if (len) memcpy(dst + dst_off[i], src + src_off[k], (size_t)len * sizeof(int32_t));
+    }
+    return BSIG_OK;
+}
+
 void bsig_cache_clear(void)
 {
     std::lock_guard<std::mutex> lock(g_cache.mu);

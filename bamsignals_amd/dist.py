@@ -1,0 +1,62 @@
+"""Multi-GPU: ranges are independent units (each owns its own output, ref:
+src/bamsignals.cpp:164,181,186), so they are dealt round-robin, in sorted order, to the ranks
+(one process per GPU, ``torch.distributed``; backend "nccl" = RCCL over xGMI).  There is no
+collective on the data path; the only exchange is the final gather of the per-rank results to
+one rank, which reassembles them in the caller's range order.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_indices(rid, loc, rank, world):
+    """Indices of the ranges rank ``rank`` owns: every ``world``-th range of the (rid, loc) order
+    (the order the reference sorts them in, src/bamsignals.cpp:222-226,246)."""
+    order = np.lexsort((np.asarray(loc), np.asarray(rid)))
+    return order[rank::world]
+
+
+def shard_layout(length, binsize, ss, rank, world, rid, loc):
+    """(indices, local offsets) of one rank's shard; every rank can compute everybody's."""
+    from .device import layout
+    idx = shard_indices(rid, loc, rank, world)
+    return idx, layout(np.asarray(length)[idx], binsize, ss)
+
+
+def gather_signals(local_out, ranges, binsize, ss, dst=0, group=None):
+    """Gather the per-rank flat results to ``dst`` and put them back into the caller's range order.
+
+    ``local_out``: this rank's flat int32 result (torch tensor on the backend's device, or numpy).
+    ``ranges``: the FULL range set (dict rid, loc, len) known to every rank.
+    Returns ``(out, off)`` on ``dst`` (numpy int32 / int64), ``(None, off)`` elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+    from .device import layout
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    off = layout(ranges["len"], binsize, ss)
+    shards = [shard_layout(ranges["len"], binsize, ss, r, world, ranges["rid"], ranges["loc"]) for r in range(world)]
+    sizes = [int(o[-1]) for _, o in shards]
+    pad = max(max(sizes), 1)
+    t = local_out if isinstance(local_out, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_out, dtype=np.int32))
+    if t.numel() != sizes[rank]:
+        raise ValueError(f"rank {rank}: result has {t.numel()} cells, its shard needs {sizes[rank]}")
+    buf = torch.zeros(pad, dtype=torch.int32, device=t.device)
+    buf[:t.numel()] = t
+    bufs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None, off
+    lib = _lib.load()
+    out = np.zeros(int(off[-1]), dtype=np.int32)
+    for r in range(world):
+        idx, loff = shards[r]
+        src = bufs[r][:sizes[r]].cpu().numpy()
+        which = np.ascontiguousarray(idx, dtype=np.int64)
+        _lib.check(lib.bsig_scatter_segments(len(which), src.ctypes.data, loff.ctypes.data, out.ctypes.data,
+                                             off.ctypes.data, which.ctypes.data))
+    return out, off

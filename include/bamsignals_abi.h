@@ -207,6 +207,14 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
 /* drops the per-process cache of BAMs decoded to HBM by the file-level entry points           */
 void bsig_cache_clear(void);
 
+/* ------------------------------------------------------------------------------------------
+ * Reassembly of sharded results (multi-GPU): segment k of src (src_off[k] .. src_off[k+1]) is
+ * copied to dst at dst_off[which[k]].  The host half of "each GArray owns its own output
+ * buffer" (ref: src/bamsignals.cpp:164,181,186) once ranges were dealt round-robin to GPUs.
+ * ------------------------------------------------------------------------------------------ */
+int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off, int32_t *dst,
+                          const int64_t *dst_off, const int64_t *which);
+
 #ifdef __cplusplus
 }
 #endif
