@@ -44,13 +44,14 @@ class Params(C.Structure):
                 ("shift", C.c_int32), ("ss", C.c_int32), ("requiredF", C.c_int32),
                 ("filteredF", C.c_int32), ("pe_mid", C.c_int32), ("tspan", C.c_int32),
                 ("n_tlen_filter", C.c_int32), ("tlen_filter", C.c_int32 * 2),
-                ("tile_cells", C.c_int32), ("threads", C.c_int32)]
+                ("tile_cells", C.c_int32), ("threads", C.c_int32), ("resolve", C.c_int32)]
 
 
 class PlanStats(C.Structure):
     _fields_ = [("n_ranges", C.c_int64), ("n_items", C.c_int64), ("cells", C.c_int64),
-                ("visits", C.c_int64), ("streamed", C.c_int64), ("algorithmic_bytes", C.c_int64),
-                ("bytes_per_visit", C.c_int32)]
+                ("visits", C.c_int64), ("visits_short", C.c_int64), ("streamed", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("bytes_per_visit_short", C.c_int32),
+                ("bytes_per_visit_long", C.c_int32)]
 
 
 _lib = None

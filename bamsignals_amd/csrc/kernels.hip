@@ -162,11 +162,14 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
         t4[c] = make_int4(0, 0, 0, 0);
         if (j < win[c].y) {
             p4[c] = *reinterpret_cast<const int4 *>(C.pos + j);
-            e4[c] = *reinterpret_cast<const int4 *>(C.end + j);
             f4[c] = *reinterpret_cast<const uint4 *>(C.fm + j);
+            if (c != 0) e4[c] = *reinterpret_cast<const int4 *>(C.end + j);
             if (P.use_tlen) t4[c] = *reinterpret_cast<const int4 *>(C.tlen + j);
         }
     }
+    // class 0 (span <= 256) has no end column: end = pos + (fm >> 24)
+    e4[0] = make_int4(p4[0].x + (int)(f4[0].x >> 24), p4[0].y + (int)(f4[0].y >> 24),
+                      p4[0].z + (int)(f4[0].z >> 24), p4[0].w + (int)(f4[0].w >> 24));
 #pragma unroll
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         const BsigClassCols &C = R.cls[c];
@@ -183,8 +186,10 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
             one(p4[c].w, e4[c].w, f4[c].w, t4[c].w, dj + 3u < nj);
             for (j += 4u * NT; j < j_hi; j += 4u * NT) {
                 const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
-                const int4 e = *reinterpret_cast<const int4 *>(C.end + j);
                 const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+                int4 e;
+                if (c != 0) e = *reinterpret_cast<const int4 *>(C.end + j);
+                else e = make_int4(p.x + (int)(f.x >> 24), p.y + (int)(f.y >> 24), p.z + (int)(f.z >> 24), p.w + (int)(f.w >> 24));
                 int4 t = make_int4(0, 0, 0, 0);
                 if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
                 dj = j - j_lo;
@@ -197,12 +202,42 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     }
 }
 
-__device__ __forceinline__ void load_windows(const uint2 *__restrict__ windows, uint2 (&win)[BSIG_MAX_CLASSES])
+// The read windows of a tile: taken from k_resolve's output, or (windows == nullptr, the fused
+// form) looked up here with the index loads of all classes issued back to back.
+__device__ __forceinline__ void load_windows(const BsigReadsDev &R, const BsigKParams &P, int mode,
+                                             const BsigWorkItem &w, const BsigWorkItem *__restrict__ items,
+                                             const uint2 *__restrict__ windows, uint2 (&win)[BSIG_MAX_CLASSES])
 {
-    const uint4 *wp = reinterpret_cast<const uint4 *>(windows + (size_t)BSIG_MAX_CLASSES * blockIdx.x);
-    const uint4 a = wp[0], b = wp[1];
-    win[0] = make_uint2(a.x, a.y); win[1] = make_uint2(a.z, a.w);
-    win[2] = make_uint2(b.x, b.y); win[3] = make_uint2(b.z, b.w);
+    if (windows) {
+        const uint4 *wp = reinterpret_cast<const uint4 *>(windows + (size_t)BSIG_MAX_CLASSES * blockIdx.x);
+        const uint4 a = wp[0], b = wp[1];
+        win[0] = make_uint2(a.x, a.y); win[1] = make_uint2(a.z, a.w);
+        win[2] = make_uint2(b.x, b.y); win[3] = make_uint2(b.z, b.w);
+        return;
+    }
+    int64_t tlo, thi;
+    item_interval(w, P, mode, tlo, thi);
+    const uint32_t *alo[BSIG_MAX_CLASSES], *ahi[BSIG_MAX_CLASSES];
+    bool live[BSIG_MAX_CLASSES];
+    const int64_t ref_bp = (int64_t)(w.units_strand & 0x3FFFFFFFu) << BSIG_REF_UNIT_SHIFT;
+    const uint64_t g0 = (uint64_t)w.ref_unit0 << BSIG_REF_UNIT_SHIFT;
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = R.cls[c];
+        int64_t wlo = tlo - P.ext - C.maxspan + 1, whi = thi + P.ext;
+        if (wlo < 0) wlo = 0;
+        if (whi > ref_bp) whi = ref_bp;
+        live[c] = C.n != 0 && wlo < whi;
+        // dead classes read a harmless valid word instead of branching around the load
+        const uint32_t *dummy = reinterpret_cast<const uint32_t *>(items);
+        alo[c] = live[c] ? C.idx + ((g0 + (uint64_t)wlo) >> C.kshift) : dummy;
+        ahi[c] = live[c] ? C.idx + (((g0 + (uint64_t)whi - 1) >> C.kshift) + 1) : dummy;
+    }
+    uint32_t lo[BSIG_MAX_CLASSES], hi[BSIG_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { lo[c] = *alo[c]; hi[c] = *ahi[c]; }
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = live[c] && lo[c] < hi[c] ? make_uint2(lo[c], hi[c]) : make_uint2(0u, 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -220,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
     BSIG_STAMP(0);
     const BsigWorkItem w = items[blockIdx.x];
     uint2 win[BSIG_MAX_CLASSES];
-    load_windows(windows, win);
+    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     // clear the whole tile image: this needs nothing from the work item, so it overlaps its load
     for (int v = tid; v < (P.tile_cells * S + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
@@ -282,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKP
     const int tid = threadIdx.x;
     const BsigWorkItem w = items[blockIdx.x];
     uint2 win[BSIG_MAX_CLASSES];
-    load_windows(windows, win);
+    load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win);
     const bool neg_range = (w.units_strand >> 30) & 1u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
     const int gn = w.nc;
@@ -343,7 +378,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
     const int lane = tid & (kWave - 1);
     const BsigWorkItem w = items[blockIdx.x];
     uint2 win[BSIG_MAX_CLASSES];
-    load_windows(windows, win);
+    load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     for (int v = tid; v < (P.tile_cells + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     const int nv = w.nc;
@@ -525,8 +560,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
             if (pp >= ref_bp) pp = ref_bp - 1;
             const uint64_t g = ((uint64_t)ref_unit0[lo] << BSIG_REF_UNIT_SHIFT) + (uint64_t)pp;
             O.pos[cls][dst] = p;
-            O.end[cls][dst] = e;
-            O.fm[cls][dst] = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 16);
+            uint32_t fmw = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 16);
+            if (cls == 0) fmw |= (uint32_t)(e - p) << 24;      // span - 1 <= 255
+            else O.end[cls][dst] = e;
+            O.fm[cls][dst] = fmw;
             O.tlen[cls][dst] = tlen[i];
             O.gb[cls][dst] = (uint32_t)(g >> O.kshift[cls]);
         }
@@ -556,8 +593,9 @@ __global__ void k_build_idx(int64_t n, const uint32_t *__restrict__ gb, uint64_t
 
 // ------------------------------------------------------------------------------------------
 // read visits of a plan, for the roofline's algorithmic bytes:
-//   acc[0] = reads whose pos lies in the exact candidate window of their tile (SURVEY 8d's V)
-//   acc[1] = reads actually streamed (windows rounded to index buckets and to 4 reads)
+//   acc[c], c = 0..3 = reads of span class c whose pos lies in the exact candidate window of
+//                      their tile (SURVEY 8d's V, per class because class 0 reads are 4 B shorter)
+//   acc[4]           = reads actually streamed (windows rounded to index buckets and to 4 reads)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t lo, uint32_t hi, int64_t key)
 {
@@ -577,7 +615,7 @@ __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
     const BsigWorkItem w = items[t];
     int64_t tlo, thi;
     item_interval(w, P, mode, tlo, thi);
-    unsigned long long exact = 0, streamed = 0;
+    unsigned long long streamed = 0;
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         const BsigClassCols &C = R.cls[c];
         if (C.n == 0) continue;
@@ -588,10 +626,9 @@ __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
         if (wlo < 0) wlo = 0;
         const uint32_t a = lower_bound_pos(C.pos, j_lo, j_hi, wlo);
         const uint32_t b = lower_bound_pos(C.pos, a, j_hi, whi);
-        exact += b - a;
+        if (b > a) atomicAdd(&acc[c], (unsigned long long)(b - a));
     }
-    atomicAdd(&acc[0], exact);
-    atomicAdd(&acc[1], streamed);
+    atomicAdd(&acc[4], streamed);
 }
 
 }  // namespace
@@ -607,8 +644,9 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
                               uint2 *windows, int32_t *out, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
-                       R, P, mode, items, n_items, windows);
+    if (windows)
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
+                           R, P, mode, items, n_items, windows);
     const dim3 grid((unsigned)n_items), block(NT);
     if (mode == BSIG_MODE_PROFILE) {
         const size_t lds = (size_t)(tile_cells * (ss ? 2 : 1) + 8) * sizeof(int32_t);

@@ -278,7 +278,8 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
         int32_t *p, *e, *t;
         uint32_t *f, *gb, *idx;
         HIP_TRY(R->pool.alloc(&p, cap));
-        HIP_TRY(R->pool.alloc(&e, cap));
+        e = nullptr;
+        if (c != 0) HIP_TRY(R->pool.alloc(&e, cap));      // class 0 packs its span into fm
         HIP_TRY(R->pool.alloc(&f, cap));
         HIP_TRY(R->pool.alloc(&t, cap));
         HIP_TRY(tmp.alloc(&gb, cap));
@@ -286,7 +287,7 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
         HIP_TRY(R->pool.alloc(&idx, n_buckets[c] + 2));
         // the tail padding is read by the 16-B loads: keep it defined
         HIP_TRY(hipMemsetAsync(p + cap - 8, 0, 8 * sizeof(int32_t), st));
-        HIP_TRY(hipMemsetAsync(e + cap - 8, 0, 8 * sizeof(int32_t), st));
+        if (e) HIP_TRY(hipMemsetAsync(e + cap - 8, 0, 8 * sizeof(int32_t), st));
         HIP_TRY(hipMemsetAsync(f + cap - 8, 0, 8 * sizeof(int32_t), st));
         HIP_TRY(hipMemsetAsync(t + cap - 8, 0, 8 * sizeof(int32_t), st));
         C.pos = p; C.end = e; C.fm = f; C.tlen = t; C.idx = idx;
@@ -459,7 +460,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     if (P->n_items >= (1ll << 31)) { delete P; return fail(BSIG_ERR_ARG, "too many tiles for one launch"); }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = P->pool.alloc(&P->items, std::max<size_t>(items.size(), 1));
-    if (e == hipSuccess) {
+    if (e == hipSuccess && prm->resolve == 1) {
         uint64_t *wbuf = nullptr;
         e = P->pool.alloc(&wbuf, std::max<size_t>(items.size(), 1) * BSIG_MAX_CLASSES);
         P->windows = wbuf;
@@ -518,7 +519,7 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
     if (!p || !s) return fail(BSIG_ERR_ARG, "NULL argument");
     if (!p->have_stats) {
         hipStream_t st = p->ctx->stream;
-        unsigned long long *d_acc = nullptr, acc[2] = {0, 0};
+        unsigned long long *d_acc = nullptr, acc[BSIG_MAX_CLASSES + 1] = {0, 0, 0, 0, 0};
         HIP_TRY(hipSetDevice(p->ctx->device));
         HIP_TRY(hipMalloc((void **)&d_acc, sizeof acc));
         hipError_t e = hipMemsetAsync(d_acc, 0, sizeof acc, st);
@@ -531,14 +532,18 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         t.n_ranges = p->n_ranges;
         t.n_items = p->n_items;
         t.cells = p->off.back();
-        t.visits = (int64_t)acc[0];
-        t.streamed = (int64_t)acc[1];
-        t.bytes_per_visit = p->kp.use_tlen ? 16 : 12;
-        // reads + work items (read by k_resolve and by the pileup kernel) + index entries +
-        // windows (written once, read once) + result cells
-        t.algorithmic_bytes = t.bytes_per_visit * t.visits + 2 * (int64_t)sizeof(BsigWorkItem) * t.n_items +
-                              8 * t.n_items * p->reads->info.n_classes +
-                              2 * 8 * BSIG_MAX_CLASSES * t.n_items + 4 * t.cells;
+        t.visits_short = (int64_t)acc[0];
+        t.visits = (int64_t)(acc[0] + acc[1] + acc[2] + acc[3]);
+        t.streamed = (int64_t)acc[4];
+        t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // pos + packed flag/mapq/span [+ tlen]
+        t.bytes_per_visit_long = p->kp.use_tlen ? 16 : 12;     // pos + end + flag/mapq [+ tlen]
+        // reads + work items + index entries + result cells; with the separate resolve kernel the
+        // work items are read twice and the windows written once and read once
+        const int64_t per_item = p->windows ? 2 * (int64_t)sizeof(BsigWorkItem) + 2 * 8 * BSIG_MAX_CLASSES
+                                            : (int64_t)sizeof(BsigWorkItem);
+        t.algorithmic_bytes = t.bytes_per_visit_short * t.visits_short +
+                              t.bytes_per_visit_long * (t.visits - t.visits_short) + per_item * t.n_items +
+                              8 * t.n_items * p->reads->info.n_classes + 4 * t.cells;
         p->have_stats = true;
     }
     *s = p->stats;

@@ -111,7 +111,7 @@ class Reads:
 
 
 def make_params(mode, tlen_filter=(), mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
-                filteredF=-1, pe_mid=False, tspan=False, tile_cells=0, threads=0):
+                filteredF=-1, pe_mid=False, tspan=False, tile_cells=0, threads=0, resolve=0):
     p = _lib.Params()
     p.mode = mode
     p.mapqual = int(mapqual)
@@ -130,6 +130,7 @@ def make_params(mode, tlen_filter=(), mapqual=0, binsize=1, shift=0, ss=False, r
         p.tlen_filter[i] = v
     p.tile_cells = int(tile_cells)
     p.threads = int(threads)
+    p.resolve = int(resolve)
     return p
 
 

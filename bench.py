@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--ranges", type=int, default=0, help="override the number of ranges per GPU")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tile-cells", type=int, default=0)
+    ap.add_argument("--resolve", type=int, default=0, help="1: separate k_resolve launch per step")
     ap.add_argument("--batches", type=int, default=8,
                     help="distinct range batches (and result buffers) the steps rotate over, so that the "
                          "working set (8 x ~135 MB at C2) exceeds the 256 MiB Infinity Cache")
@@ -102,7 +103,8 @@ def main():
                       cols["tlen"], end=cols["end"])
         t_upload = time.time() - t0
         t0 = time.time()
-        params = make_params(_lib.MODE_PROFILE, tile_cells=a.tile_cells, threads=a.threads, **cfg["args"])
+        params = make_params(_lib.MODE_PROFILE, tile_cells=a.tile_cells, threads=a.threads, resolve=a.resolve,
+                             **cfg["args"])
         plans = [Plan(ctx, reads, g["rid"], g["loc"], g["len"], g["strand"], params) for g in batches]
         t_plan = (time.time() - t0) / nb
         plan = plans[0]
@@ -124,17 +126,20 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        # HIP events on the launch stream bracket the K launches: (e1 - e0) / K is the average
+        # duration of one launch including the ~1.5 us dependent-launch boundary, i.e. an upper
+        # bound of the kernel time rocprofv3 reports for the same command (profiles/)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t_start = time.perf_counter()
+        e0.record(stream)
         for s in range(a.steps):
-            ev[s][0].record(stream)
             plans[s % nb].run_device(outs[s % nb].data_ptr())
-            ev[s][1].record(stream)
+        e1.record(stream)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start
-        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        kernel_ms = e0.elapsed_time(e1) / a.steps
 
         # whole-job time = max over ranks
         if world > 1:
@@ -191,6 +196,22 @@ def main():
                 gather = dict(ms=t_g * 1e3, bytes=int(shard.numel() * 4 * (world - 1)),
                               GBps=shard.numel() * 4 * (world - 1) / t_g / 1e9, checked=True)
 
+    # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
+    # (profiles/<tag>_pmc.json, made by scripts/profile_round.sh + scripts/summarize_profile.py);
+    # only quoted when that profile was taken on the workload and launch shape being run now
+    traffic, traffic_src = None, None
+    if rank == 0:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+            try:
+                pj = json.load(open(f))
+            except Exception:
+                continue
+            if pj.get("workload") == a.config + ": " + cfg["desc"] and not a.threads and not a.tile_cells and not a.resolve \
+                    and not a.reads and not a.ranges and pj.get("step_hbm_bytes"):
+                traffic, traffic_src = pj["step_hbm_bytes"], os.path.relpath(f, ROOT)
+                break
+
     if rank == 0:
         total_bases = sum(step_bases[s % nb] for s in range(a.steps)) * world
         value = total_bases / elapsed / 1e6
@@ -205,10 +226,12 @@ def main():
                        "parallelism": f"ranges round-robin over {world} GPU(s), reads replicated",
                        "threads": params.threads or 64, "tile_cells": params.tile_cells or 2048},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_profile", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_resolve + k_profile (one step)" if a.resolve else "k_profile", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": stats["algorithmic_bytes"], "visits": stats["visits"],
-                         "streamed_reads": stats["streamed"], "bytes_per_visit": stats["bytes_per_visit"],
+                         "streamed_reads": stats["streamed"], "visits_short": stats["visits_short"],
+                         "bytes_per_visit_short": stats["bytes_per_visit_short"],
+                         "bytes_per_visit_long": stats["bytes_per_visit_long"],
                          "items": stats["n_items"], "cells": stats["cells"]},
             "cpu_baseline": cpu,
             "parity_checked": parity,

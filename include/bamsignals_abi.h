@@ -121,6 +121,8 @@ typedef struct {
     /* tuning knobs, 0 = default */
     int32_t tile_cells;        /* output cells per workgroup tile (default 2048)                */
     int32_t threads;           /* 64, 128 or 256 threads per workgroup (default 64)             */
+    int32_t resolve;           /* 0: index lookup inside the pileup kernel (default);           */
+                               /* 1: separate k_resolve launch in front of it                   */
 } bsig_params;
 
 typedef struct bsig_plan bsig_plan;
@@ -130,9 +132,11 @@ typedef struct {
     int64_t n_items;           /* workgroup tiles                                               */
     int64_t cells;             /* int32 output cells                                            */
     int64_t visits;            /* reads in the exact candidate windows of all tiles (V)         */
+    int64_t visits_short;      /* ... of them in span class 0 (span <= 256, 4 B shorter)        */
     int64_t streamed;          /* reads actually loaded (windows rounded to index buckets)      */
-    int64_t algorithmic_bytes; /* bytes_per_visit*V + 32*items + 8*items*classes + 4*cells      */
-    int32_t bytes_per_visit;   /* 12, or 16 when the tlen column is needed                      */
+    int64_t algorithmic_bytes; /* sum(bytes_per_visit*V) + 32*items + 8*items*classes + 4*cells */
+    int32_t bytes_per_visit_short;   /* 8  (pos + flag|mapq|span), 12 with the tlen column      */
+    int32_t bytes_per_visit_long;    /* 12 (pos + end + flag|mapq), 16 with the tlen column     */
 } bsig_plan_stats;
 
 int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,
