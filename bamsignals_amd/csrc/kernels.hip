@@ -147,16 +147,18 @@ __global__ void k_resolve(const BsigReadsDev R, const BsigKParams P, int mode,
 }
 
 // Stream the reads of all span-class windows of one tile through `one(pos, end, fm, tlen, valid)`.
-// The first 16-B vector of every class is requested before anything is consumed, so the
-// workgroup pays one memory round trip for all classes; longer windows continue in a loop.
+// The first 16-B vector of the two short classes (where nearly all reads live) is requested
+// before anything is consumed, so the workgroup pays one memory round trip for both; longer
+// windows and the two long-span classes continue in plain loops.
 template <int NT, typename F>
 __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
                                               const uint2 (&win)[BSIG_MAX_CLASSES], int tid, F &&one)
 {
-    int4 p4[BSIG_MAX_CLASSES], e4[BSIG_MAX_CLASSES], t4[BSIG_MAX_CLASSES];
-    uint4 f4[BSIG_MAX_CLASSES];
+    constexpr int kPre = 2;      // classes whose first vector is prefetched
+    int4 p4[kPre], e4[kPre], t4[kPre];
+    uint4 f4[kPre];
 #pragma unroll
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+    for (int c = 0; c < kPre; ++c) {
         const BsigClassCols &C = R.cls[c];
         const uint32_t j = (win[c].x & ~3u) + 4u * tid;
         t4[c] = make_int4(0, 0, 0, 0);
@@ -178,26 +180,28 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
         // end after j_hi: only reads in [j_lo, j_hi) count
         const uint32_t nj = j_hi - j_lo;
         uint32_t j = (j_lo & ~3u) + 4u * tid;
-        if (j < j_hi) {
-            uint32_t dj = j - j_lo;
+        if (c < kPre) {
+            if (j >= j_hi) continue;
+            const uint32_t dj = j - j_lo;
             one(p4[c].x, e4[c].x, f4[c].x, t4[c].x, dj < nj);
             one(p4[c].y, e4[c].y, f4[c].y, t4[c].y, dj + 1u < nj);
             one(p4[c].z, e4[c].z, f4[c].z, t4[c].z, dj + 2u < nj);
             one(p4[c].w, e4[c].w, f4[c].w, t4[c].w, dj + 3u < nj);
-            for (j += 4u * NT; j < j_hi; j += 4u * NT) {
-                const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
-                const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
-                int4 e;
-                if (c != 0) e = *reinterpret_cast<const int4 *>(C.end + j);
-                else e = make_int4(p.x + (int)(f.x >> 24), p.y + (int)(f.y >> 24), p.z + (int)(f.z >> 24), p.w + (int)(f.w >> 24));
-                int4 t = make_int4(0, 0, 0, 0);
-                if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
-                dj = j - j_lo;
-                one(p.x, e.x, f.x, t.x, dj < nj);
-                one(p.y, e.y, f.y, t.y, dj + 1u < nj);
-                one(p.z, e.z, f.z, t.z, dj + 2u < nj);
-                one(p.w, e.w, f.w, t.w, dj + 3u < nj);
-            }
+            j += 4u * NT;
+        }
+        for (; j < j_hi; j += 4u * NT) {
+            const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
+            const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 e;
+            if (c != 0) e = *reinterpret_cast<const int4 *>(C.end + j);
+            else e = make_int4(p.x + (int)(f.x >> 24), p.y + (int)(f.y >> 24), p.z + (int)(f.z >> 24), p.w + (int)(f.w >> 24));
+            int4 t = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
+            const uint32_t dj = j - j_lo;
+            one(p.x, e.x, f.x, t.x, dj < nj);
+            one(p.y, e.y, f.y, t.y, dj + 1u < nj);
+            one(p.z, e.z, f.z, t.z, dj + 2u < nj);
+            one(p.w, e.w, f.w, t.w, dj + 3u < nj);
         }
     }
 }

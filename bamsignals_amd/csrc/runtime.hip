@@ -391,7 +391,15 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
 
     bsig_plan *P = new bsig_plan;
     P->ctx = ctx; P->reads = reads; P->mode = mode; P->n_ranges = n;
-    P->tile_cells = prm->tile_cells > 0 ? prm->tile_cells : 2048;
+    // default tile: the widest range if it fits 2048 cells (less LDS per workgroup = more
+    // workgroups per CU), else 2048-cell tiles
+    int64_t widest = 64;
+    {
+        const int64_t bsz = mode == BSIG_MODE_PROFILE ? prm->binsize : 1;
+        for (int64_t i = 0; i < n && mode != BSIG_MODE_COUNT; ++i)
+            widest = std::max<int64_t>(widest, ((int64_t)len[i] + bsz - 1) / bsz);
+    }
+    P->tile_cells = prm->tile_cells > 0 ? prm->tile_cells : (int)std::min<int64_t>(widest, 2048);
     P->tile_cells = std::min(std::max(P->tile_cells, 64), prm->ss && mode == BSIG_MODE_PROFILE ? 16384 : 32768);
     P->tile_cells = (P->tile_cells + 3) & ~3;
     P->threads = prm->threads > 0 ? prm->threads : 64;
