@@ -62,12 +62,14 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
     for r in rows:
         if any(s in r["Name"] for s in ("k_profile", "k_resolve", "k_scatter", "k_span_hist", "k_build_idx", "k_visits")):
             f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
-    f.write("\nbench.py (un-profiled run, HIP events around resolve + profile per step): "
+    f.write("\nbench.py (un-profiled run, HIP events around the K-launch train / K): "
             f"kernel_ms = {bench['roofline']['kernel_ms']:.5f}, ms_per_step = {bench['ms_per_step']:.5f}, "
             f"value = {bench['value']:.0f} {bench['unit']}, roofline.frac = {bench['roofline']['frac']:.3f}\n\n")
     f.write("PMC passes (separate runs; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950):\n\n")
     f.write("| kernel | HBM read B / launch | HBM write B / launch |\n|---|---|---|\n")
     for k, v in out["per_launch"].items():
+        if not v["hbm_bytes"]:
+            continue        # kernel not launched in this configuration
         f.write(f"| {k} | {v['hbm_read_bytes']:.3e} | {v['hbm_write_bytes']:.3e} |\n")
     f.write(f"\nstep HBM traffic = {out['step_hbm_bytes']:.4e} B vs algorithmic {out['algorithmic_bytes']:.4e} B "
             f"(ratio {out['step_hbm_bytes'] / out['algorithmic_bytes']:.3f})\n")
