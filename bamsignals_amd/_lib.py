@@ -81,6 +81,9 @@ def load():
     lib.bsig_ctx_sync.argtypes = [C.c_void_p]
     lib.bsig_ctx_stream.argtypes = [C.c_void_p]
     lib.bsig_ctx_stream.restype = C.c_void_p
+    lib.bsig_host_alloc.argtypes = [C.c_int64, C.POINTER(C.c_void_p)]
+    lib.bsig_host_free.argtypes = [C.c_void_p]
+    lib.bsig_host_free.restype = None
     lib.bsig_reads_upload.argtypes = [C.c_void_p, C.POINTER(Columns), C.POINTER(C.c_void_p)]
     lib.bsig_reads_get_info.argtypes = [C.c_void_p, C.POINTER(ReadsInfo)]
     lib.bsig_reads_free.argtypes = [C.c_void_p]

@@ -220,6 +220,7 @@ public:
     bool reached_limit() const { return done_; }
     bool in_header() const { return in_header_; }
     size_t pending() const { return carry_.size(); }
+    uint64_t position() const { return abs_; }
 
     // returns 0, or a negative BSIG_ERR_* (message recorded)
     int feed(const uint8_t *d, size_t n)
@@ -411,22 +412,64 @@ static int scan_blocks(const MappedFile &f, const std::string &path, std::vector
     return 0;
 }
 
+// inflates blocks [b0, b1) back to back into out[prefix ...]; out is resized to prefix + total
 static int inflate_batch(const MappedFile &f, const std::vector<Block> &blocks, size_t b0, size_t b1,
-                         int threads, std::vector<uint8_t> &out)
+                         int threads, std::vector<uint8_t> &out, size_t prefix = 0)
 {
     std::vector<uint64_t> uoff(b1 - b0 + 1, 0);
     for (size_t k = b0; k < b1; ++k) uoff[k - b0 + 1] = uoff[k - b0] + blocks[k].isize;
-    out.resize(uoff.back());
+    out.resize(prefix + uoff.back());
     std::atomic<int> bad(0);
     std::vector<Inflater> inf((size_t)std::max(1, threads));
     parallel_for((int64_t)(b1 - b0), threads, [&](int64_t i, int t) {
         const Block &b = blocks[b0 + (size_t)i];
-        if (!inf[(size_t)t].run(f.data + b.coff + b.doff, b.dlen, out.data() + uoff[(size_t)i], b.isize)) bad = 1;
+        if (!inf[(size_t)t].run(f.data + b.coff + b.doff, b.dlen, out.data() + prefix + uoff[(size_t)i], b.isize)) bad = 1;
     });
     if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
     return 0;
 }
 
+namespace {
+
+// real CIGAR of a record whose in-record CIGAR is the kSmN placeholder of a > 65535-op alignment
+// (SAM spec 4.2.2): pointer to the CG:B,I payload and its length, or nullptr
+const uint8_t *find_cg_tag(const uint8_t *r, size_t len, uint32_t *n_ops)
+{
+    const uint8_t *c = r + 4;
+    const uint32_t l_name = c[8];
+    const uint32_t n_cig = rd16(c + 12);
+    const int32_t l_seq = rdi32(c + 16);
+    if (n_cig != 2 || l_seq < 0) return nullptr;
+    const uint8_t *cig = c + 32 + l_name;
+    if (36 + (size_t)l_name + 8 > len) return nullptr;
+    if ((rd32(cig) & 0xF) != 4 || (int32_t)(rd32(cig) >> 4) != l_seq || (rd32(cig + 4) & 0xF) != 3) return nullptr;
+    size_t a = 36 + (size_t)l_name + 8 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    while (a + 3 <= len) {
+        const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+        a += 3;
+        size_t sz = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+        else if (ty == 's' || ty == 'S') sz = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+        else if (ty == 'Z' || ty == 'H') { while (a + sz < len && r[a + sz]) ++sz; ++sz; }
+        else if (ty == 'B') {
+            if (a + 5 > len) return nullptr;
+            const uint8_t sub = r[a];
+            const uint32_t cnt = rd32(r + a + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4 * (size_t)cnt <= len) { *n_ops = cnt; return r + a + 5; }
+            sz = 5 + es * cnt;
+        } else return nullptr;
+        a += sz;
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+// Whole file: batches of BGZF blocks are inflated by the thread pool while the previous batch is
+// parsed; parsing a batch = a serial walk over the record lengths (boundaries, sortedness, CIGAR
+// offsets) + a parallel extraction of the columns.
 int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostColumns &cols)
 {
     MappedFile f;
@@ -436,37 +479,132 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
     int rc = scan_blocks(f, path, blocks);
     if (rc) return rc;
     cols = HostColumns();
-    // rough reservation: ~50 bytes of uncompressed BAM per record
-    uint64_t total_u = 0;
-    for (const Block &b : blocks) total_u += b.isize;
-    const size_t guess = (size_t)(total_u / 45) + 16;
-    cols.pos.reserve(guess); cols.tlen.reserve(guess); cols.flag.reserve(guess); cols.mapq.reserve(guess);
-    cols.cigar_off.reserve(guess + 1); cols.cigar.reserve(guess + guess / 4);
+    cols.cigar_off.push_back(0);
 
-    BamParser parser(hdr, cols, true);
-    const size_t batch = 2048;        // blocks per batch (<= 128 MiB uncompressed)
-    std::vector<uint8_t> cur, nxt;
-    size_t b0 = 0;
-    if (!blocks.empty()) {
-        rc = inflate_batch(f, blocks, 0, std::min(batch, blocks.size()), threads, cur);
-        if (rc) return rc;
+    size_t batch = 2048;                    // blocks per batch (<= 128 MiB uncompressed)
+    size_t kPrefix = 8u << 20;              // room in front of a batch for the previous batch's tail
+    if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {      // testing: force many small batches
+        const long v = atol(e);
+        if (v > 0) { batch = (size_t)v; kPrefix = 16; }
     }
+    std::vector<uint8_t> cur, nxt;
+    if (blocks.empty()) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
+    rc = inflate_batch(f, blocks, 0, std::min(batch, blocks.size()), threads, cur, kPrefix);
+    if (rc) return rc;
+    size_t begin = kPrefix;                 // first unparsed byte of `cur`
+    {
+        // the header (must end inside the first batch)
+        HostColumns dummy;
+        BamParser hp(hdr, dummy, true);
+        hp.set_limit(0);
+        rc = hp.feed(cur.data() + kPrefix, cur.size() - kPrefix);
+        if (rc) return rc;
+        if (hp.in_header()) {
+            if (blocks.size() <= batch) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
+            return fail(BSIG_ERR_FORMAT, "BAM header of %s is larger than 128 MiB", path.c_str());
+        }
+        begin = kPrefix + hp.position();
+    }
+    const int n_ref = (int)hdr.names.size();
+    int32_t last_rid = -1, last_pos = -1;
+    std::vector<uint32_t> starts;           // record offsets inside `cur`
+    std::vector<uint32_t> ncig;             // CIGAR operations per record (CG tag resolved)
+    std::vector<uint8_t> has_cg;
+    size_t b0 = 0;
     while (b0 < blocks.size()) {
         const size_t b1 = std::min(b0 + batch, blocks.size());
         const size_t b2 = std::min(b1 + batch, blocks.size());
         int rc_next = 0;
         std::thread producer;
-        if (b1 < b2) producer = std::thread([&] { rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt); });
-        rc = parser.feed(cur.data(), cur.size());
+        if (b1 < b2) producer = std::thread([&] { rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt, kPrefix); });
+
+        // ---- phase 1 (serial): record boundaries ------------------------------------------------
+        const uint8_t *d = cur.data();
+        const size_t n = cur.size();
+        size_t o = begin;
+        starts.clear(); ncig.clear(); has_cg.clear();
+        bool any_cg = false;
+        int err = 0;
+        const int64_t base = cols.size();
+        while (o + 4 <= n) {
+            const int32_t bs = rdi32(d + o);
+            if (bs < 32) { err = fail(BSIG_ERR_FORMAT, "malformed BAM record (block_size %d)", bs); break; }
+            const size_t next = o + 4 + (size_t)bs;
+            if (next > n) break;
+            const int32_t rid = rdi32(d + o + 4), pos = rdi32(d + o + 8);
+            if (rid < 0) { ++cols.n_unplaced; o = next; continue; }
+            if (rid >= n_ref) { err = fail(BSIG_ERR_FORMAT, "BAM record with refID %d out of range", rid); break; }
+            if (rid < last_rid || (rid == last_rid && pos < last_pos)) { err = fail(BSIG_ERR_FORMAT, "BAM file is not sorted by coordinate"); break; }
+            const uint32_t l_name = d[o + 12];
+            uint32_t nc = rd16(d + o + 16);
+            if (36 + (size_t)l_name + 4 * (size_t)nc > 4 + (size_t)bs) { err = fail(BSIG_ERR_FORMAT, "malformed BAM record (fields exceed block_size)"); break; }
+            uint8_t cg = 0;
+            if (nc == 2) {
+                uint32_t real = 0;
+                if (find_cg_tag(d + o, 4 + (size_t)bs, &real)) { nc = real; cg = 1; any_cg = true; }
+            }
+            while ((int)cols.ref_off.size() <= rid) cols.ref_off.push_back(base + (int64_t)starts.size());
+            last_rid = rid; last_pos = pos;
+            starts.push_back((uint32_t)o);
+            ncig.push_back(nc);
+            has_cg.push_back(cg);
+            o = next;
+        }
+        if (err) { if (producer.joinable()) producer.join(); return err; }
+
+        // ---- phase 2 (parallel): columns ----------------------------------------------------------
+        const size_t m = starts.size();
+        cols.pos.resize((size_t)base + m); cols.tlen.resize((size_t)base + m);
+        cols.flag.resize((size_t)base + m); cols.mapq.resize((size_t)base + m);
+        cols.cigar_off.resize((size_t)base + m + 1);
+        int64_t cacc = cols.cigar_off[(size_t)base];
+        for (size_t k = 0; k < m; ++k) { cacc += ncig[k]; cols.cigar_off[(size_t)base + k + 1] = cacc; }
+        cols.cigar.resize((size_t)cacc);
+        const size_t slice = 1 << 16;
+        const int64_t n_slices = (int64_t)((m + slice - 1) / slice);
+        parallel_for(n_slices, producer.joinable() ? std::max(1, threads - 1) : threads, [&](int64_t si, int) {
+            const size_t k0 = (size_t)si * slice, k1 = std::min(m, k0 + slice);
+            for (size_t k = k0; k < k1; ++k) {
+                const uint8_t *r = d + starts[k];
+                const uint8_t *c = r + 4;
+                const size_t i = (size_t)base + k;
+                cols.pos[i] = rdi32(c + 4);
+                cols.mapq[i] = c[9];
+                cols.flag[i] = rd16(c + 14);
+                cols.tlen[i] = rdi32(c + 28);
+                uint32_t *dst = cols.cigar.data() + cols.cigar_off[i];
+                if (any_cg && has_cg[k]) {
+                    uint32_t real = 0;
+                    const uint8_t *src = find_cg_tag(r, 4 + (size_t)rdi32(r), &real);
+                    memcpy(dst, src, 4 * (size_t)real);
+                } else if (ncig[k]) {
+                    memcpy(dst, c + 32 + c[8], 4 * (size_t)ncig[k]);
+                }
+            }
+        });
+
+        // ---- hand the unparsed tail to the next batch ------------------------------------------------
         if (producer.joinable()) producer.join();
-        if (rc) return rc;
         if (rc_next) return rc_next;
-        cur.swap(nxt);
+        const size_t tail = n - o;
+        if (b1 < b2) {
+            if (tail > kPrefix) {
+                std::vector<uint8_t> big(tail + (nxt.size() - kPrefix));
+                memcpy(big.data(), d + o, tail);
+                memcpy(big.data() + tail, nxt.data() + kPrefix, nxt.size() - kPrefix);
+                nxt.swap(big);
+                begin = 0;
+            } else {
+                memcpy(nxt.data() + kPrefix - tail, d + o, tail);
+                begin = kPrefix - tail;
+            }
+            cur.swap(nxt);
+        } else if (tail) {
+            return fail(BSIG_ERR_FORMAT, "truncated BAM record at the end of %s", path.c_str());
+        }
         b0 = b1;
     }
-    if (parser.in_header()) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
-    if (parser.pending()) return fail(BSIG_ERR_FORMAT, "truncated BAM record at the end of %s", path.c_str());
-    parser.finish_refs();
+    while ((int)cols.ref_off.size() < n_ref + 1) cols.ref_off.push_back(cols.size());
     return 0;
 }
 
@@ -599,41 +737,71 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
         else merged.push_back(c);
     }
 
-    // the records of one merged chunk are parsed from consecutively inflated blocks
+    // Every merged chunk becomes a job: its BGZF blocks are inflated (all jobs of a group in one
+    // parallel pass, <= 256 MiB of output per group), then its records are parsed in file order.
+    struct Job {
+        uint64_t ub = 0, limit = 0, next_off = 0;
+        std::vector<Block> bl;
+        std::vector<uint64_t> boff;
+        std::vector<uint8_t> buf;
+    };
     BamParser parser(hdr, cols, false);
     Inflater inf1;
-    for (const BaiChunk &c : merged) {
-        const uint64_t cb = c.beg >> 16, ub = c.beg & 0xFFFF, ce = c.end >> 16, ue = c.end & 0xFFFF;
-        // blocks cb .. ce (ce only if ue > 0), inflated in parallel
-        std::vector<Block> bl;
-        uint64_t off = cb;
-        while (off < f.size && (off < ce || (off == ce && ue > 0))) {
-            Block b;
-            if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "BAI points at a malformed BGZF block in %s", path.c_str());
-            bl.push_back(b);
-            off += b.csize;
+    size_t ci = 0;
+    while (ci < merged.size()) {
+        std::vector<Job> jobs;
+        uint64_t group_bytes = 0;
+        for (; ci < merged.size() && (jobs.empty() || group_bytes < (256ull << 20)); ++ci) {
+            const BaiChunk &c = merged[ci];
+            const uint64_t cb = c.beg >> 16, ce = c.end >> 16, ue = c.end & 0xFFFF;
+            Job j;
+            j.ub = c.beg & 0xFFFF;
+            uint64_t off = cb, total = 0;
+            bool end_seen = false;
+            while (off < f.size && (off < ce || (off == ce && ue > 0))) {
+                Block b;
+                if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "BAI points at a malformed BGZF block in %s", path.c_str());
+                if (b.coff == ce) { j.limit = total + ue; end_seen = true; }
+                j.boff.push_back(total);
+                j.bl.push_back(b);
+                total += b.isize;
+                off += b.csize;
+            }
+            if (j.bl.empty()) continue;
+            if (!end_seen) j.limit = total + ue;      // chunk ends at the start of block ce (ue == 0) or at EOF
+            j.next_off = off;
+            j.buf.resize(total);
+            group_bytes += total;
+            jobs.push_back(std::move(j));
         }
-        if (bl.empty()) continue;
-        std::vector<uint8_t> buf;
-        rc = inflate_batch(f, bl, 0, bl.size(), threads, buf);
-        if (rc) return rc;
-        uint64_t limit = 0;
-        for (const Block &b : bl) { if (b.coff == ce) break; limit += b.isize; }
-        limit += ue;                       // stream position (relative to block cb) of the chunk end
-        if (ub > buf.size()) return fail(BSIG_ERR_FORMAT, "BAI offset beyond its BGZF block in %s", path.c_str());
-        parser.set_position(ub);
-        parser.set_limit(limit);
-        rc = parser.feed(buf.data() + ub, buf.size() - ub);
-        if (rc) return rc;
-        // a record that starts before the chunk end may continue in the following blocks
-        while (parser.pending() && !parser.reached_limit() && off < f.size) {
-            Block b;
-            if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block in %s", path.c_str());
-            std::vector<uint8_t> more(b.isize);
-            if (!inf1.run(f.data + b.coff + b.doff, b.dlen, more.data(), b.isize)) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
-            rc = parser.feed(more.data(), more.size());
+        std::vector<std::pair<uint32_t, uint32_t>> work;
+        for (size_t a = 0; a < jobs.size(); ++a)
+            for (size_t b = 0; b < jobs[a].bl.size(); ++b) work.emplace_back((uint32_t)a, (uint32_t)b);
+        std::atomic<int> bad(0);
+        std::vector<Inflater> inf((size_t)std::max(1, threads));
+        parallel_for((int64_t)work.size(), threads, [&](int64_t w, int t) {
+            Job &j = jobs[work[(size_t)w].first];
+            const Block &b = j.bl[work[(size_t)w].second];
+            if (!inf[(size_t)t].run(f.data + b.coff + b.doff, b.dlen, j.buf.data() + j.boff[work[(size_t)w].second], b.isize)) bad = 1;
+        });
+        if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+        for (Job &j : jobs) {
+            if (j.ub > j.buf.size()) return fail(BSIG_ERR_FORMAT, "BAI offset beyond its BGZF block in %s", path.c_str());
+            parser.set_position(j.ub);
+            parser.set_limit(j.limit);
+            rc = parser.feed(j.buf.data() + j.ub, j.buf.size() - j.ub);
             if (rc) return rc;
-            off += b.csize;
+            // a record that starts before the chunk end may continue in the following blocks
+            uint64_t off = j.next_off;
+            while (parser.pending() && !parser.reached_limit() && off < f.size) {
+                Block b;
+                if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block in %s", path.c_str());
+                std::vector<uint8_t> more(b.isize);
+                if (!inf1.run(f.data + b.coff + b.doff, b.dlen, more.data(), b.isize)) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+                rc = parser.feed(more.data(), more.size());
+                if (rc) return rc;
+                off += b.csize;
+            }
         }
     }
     parser.finish_refs();

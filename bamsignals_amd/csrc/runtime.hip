@@ -178,6 +178,19 @@ int bsig_ctx_sync(bsig_ctx *c)
 
 void *bsig_ctx_stream(bsig_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+int bsig_host_alloc(int64_t bytes, void **ptr)
+{
+    if (!ptr || bytes < 0) return fail(BSIG_ERR_ARG, "bad argument to bsig_host_alloc");
+    *ptr = nullptr;
+    HIP_TRY(hipHostMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault));
+    return BSIG_OK;
+}
+
+void bsig_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // reads -> HBM
 // ---------------------------------------------------------------------------------------------

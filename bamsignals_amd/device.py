@@ -20,6 +20,32 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+class _PinnedBlock:
+    """Owner of one bsig_host_alloc() block; freed when the last numpy view of it is collected."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        p = C.c_void_p()
+        _lib.check(self._lib.bsig_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr = p.value
+        self.buf = (C.c_char * max(int(nbytes), 1)).from_address(self.ptr)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._lib.bsig_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+def pinned_empty(n, dtype):
+    """numpy array of ``n`` elements in page-locked host memory."""
+    dtype = np.dtype(dtype)
+    block = _PinnedBlock(n * dtype.itemsize)
+    arr = np.frombuffer(block.buf, dtype=dtype, count=n)
+    # the ctypes buffer keeps `block` alive through arr.base; tie them explicitly as well
+    block.buf._owner = block
+    return arr
+
+
 class Context:
     """One GPU + the HIP stream the kernels are launched on."""
 
@@ -152,8 +178,14 @@ class Plan:
         self.cells = int(self._lib.bsig_plan_cells(h))
         self.offsets = np.ctypeslib.as_array(self._lib.bsig_plan_offsets(h), shape=(n + 1,)).copy()
 
-    def run_host(self):
-        out = np.empty(self.cells, dtype=np.int32)
+    def run_host(self, out=None, pinned=False):
+        """Run and return the flat int32 result in host memory.  ``out``: a reusable int32 array of
+        ``cells`` elements (e.g. from ``pinned_empty``); ``pinned=True`` allocates a page-locked one
+        (bsig_host_alloc), into which the D2H copy runs at PCIe DMA rate."""
+        if out is None:
+            out = pinned_empty(self.cells, np.int32) if pinned else np.empty(self.cells, dtype=np.int32)
+        elif out.dtype != np.int32 or out.size != self.cells or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous int32 array of plan.cells elements")
         _lib.check(self._lib.bsig_plan_run_host(self._h, _ptr(out)))
         return out
 

@@ -66,6 +66,10 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **ctx);
 void bsig_ctx_destroy(bsig_ctx *ctx);
 int bsig_ctx_sync(bsig_ctx *ctx);
 void *bsig_ctx_stream(bsig_ctx *ctx);
+/* page-locked host memory: results copied into it travel over PCIe by DMA at full rate
+ * (bsig_plan_run_host into pageable memory is staged by the runtime and several times slower)   */
+int bsig_host_alloc(int64_t bytes, void **ptr);
+void bsig_host_free(void *ptr);
 
 /* ------------------------------------------------------------------------------------------
  * Reads resident in HBM.  Input = the columnar arrays the CPU decode stage produces

@@ -63,6 +63,14 @@ def main():
         t = time.time(); out = plan.run_host(); ts.append(time.time() - t)
     res["run_to_host_s"] = min(ts)                     # kernel + D2H of the int32 result over PCIe
     res["run_to_host_Mbases_s"] = bases / min(ts) / 1e6
+    from bamsignals_amd.device import pinned_empty
+    outp = pinned_empty(plan.cells, np.int32)
+    ts = []
+    for _ in range(5):
+        t = time.time(); plan.run_host(out=outp); ts.append(time.time() - t)
+    assert np.array_equal(outp, out)
+    res["run_to_pinned_host_s"] = min(ts)              # ... into a reused page-locked buffer
+    res["run_to_pinned_host_Mbases_s"] = bases / min(ts) / 1e6
 
     # --- file-level API: cold (decode + upload + run) and warm (BAM cached in HBM) ---------------
     gr = GRanges(["chr1"] * a.ranges, rg["loc"] + 1, width=rg["len"],

@@ -44,6 +44,25 @@ def test_decode_with_zlib_only(fixture_reads, monkeypatch):
     assert int(out[0]) == int(fixture_reads["bam_pos"].astype(np.int64).sum()) and int(out[1]) == 99000
 
 
+def test_decode_in_many_small_batches(fixture_reads):
+    """records straddling batch boundaries (BAMSIGNALS_BATCH_BLOCKS forces 3-block batches)"""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from bamsignals_amd.bamio import BamFile; "
+            "c = BamFile(%r).decode(threads=3); "
+            "print(len(c['pos']), int(c['pos'].astype(np.int64).sum()), int(c['tlen'].astype(np.int64).sum()), "
+            "int(c['flag'].astype(np.int64).sum()), int(c['cigar'].astype(np.int64).sum()), [int(x) for x in c['ref_off']])"
+            % (os.path.dirname(os.path.dirname(GOLDEN)), BAM))
+    fx = fixture_reads
+    want = "%d %d %d %d %d %s" % (99000, fx["bam_pos"].astype(np.int64).sum(), fx["bam_tlen"].astype(np.int64).sum(),
+                                  fx["bam_flag"].astype(np.int64).sum(), fx["bam_cigar"].astype(np.int64).sum(),
+                                  [int(x) for x in fx["ref_off"]])
+    for nb in ("1", "3", "7"):
+        env = dict(os.environ, BAMSIGNALS_BATCH_BLOCKS=nb)
+        out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip()
+        assert out == want, nb
+
+
 def test_region_decode_is_a_superset_in_file_order(fixture_reads):
     from bamsignals_amd.bamio import BamFile
     fx = fixture_reads
