@@ -113,6 +113,8 @@ def load():
                                     C.POINTER(Columns)]
     core_head = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p,
                  C.c_void_p, C.c_void_p, C.c_int32]
+    lib.bsig_bam_decode_timing.argtypes = [C.POINTER(C.c_double)]
+    lib.bsig_bam_decode_timing.restype = None
     lib.bsig_pileup_core.argtypes = core_head + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]
     lib.bsig_coverage_core.argtypes = core_head + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
     lib.bsig_write_sam_as_bam_and_index.argtypes = [C.c_char_p, C.c_char_p]

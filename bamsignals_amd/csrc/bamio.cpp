@@ -18,10 +18,20 @@
 #include <sstream>
 #include <thread>
 
+#include <chrono>
+
 #include "../../include/bamsignals_abi.h"
 #include "host_util.h"
 
 namespace bsig {
+
+// stage timers of the last whole-file decode on this thread: block scan, waiting for inflate,
+// boundary scan (serial), column extraction (parallel), total
+thread_local double g_decode_timing[5] = {0, 0, 0, 0, 0};
+static inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ---------------------------------------------------------------------------------------------
 // raw DEFLATE codec: libdeflate through dlopen when present, zlib otherwise
@@ -475,10 +485,22 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
     MappedFile f;
     if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
     threads = n_threads(threads);
+    double *T = g_decode_timing;
+    T[0] = T[1] = T[2] = T[3] = T[4] = 0;
+    const double t_begin = now_s();
     std::vector<Block> blocks;
     int rc = scan_blocks(f, path, blocks);
     if (rc) return rc;
+    T[0] = now_s() - t_begin;
     cols = HostColumns();
+    {
+        // reserve from the uncompressed size (>= 38 bytes per record) so the columns never regrow
+        uint64_t total_u = 0;
+        for (const Block &b : blocks) total_u += b.isize;
+        const size_t guess = (size_t)(total_u / 38) + 16;
+        cols.pos.reserve(guess); cols.tlen.reserve(guess); cols.flag.reserve(guess); cols.mapq.reserve(guess);
+        cols.cigar_off.reserve(guess + 1); cols.cigar.reserve(guess + guess / 2);
+    }
     cols.cigar_off.push_back(0);
 
     size_t batch = 2048;                    // blocks per batch (<= 128 MiB uncompressed)
@@ -489,8 +511,10 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
     }
     std::vector<uint8_t> cur, nxt;
     if (blocks.empty()) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
+    double t0 = now_s();
     rc = inflate_batch(f, blocks, 0, std::min(batch, blocks.size()), threads, cur, kPrefix);
     if (rc) return rc;
+    T[1] += now_s() - t0;
     size_t begin = kPrefix;                 // first unparsed byte of `cur`
     {
         // the header (must end inside the first batch)
@@ -519,6 +543,7 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
         if (b1 < b2) producer = std::thread([&] { rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt, kPrefix); });
 
         // ---- phase 1 (serial): record boundaries ------------------------------------------------
+        t0 = now_s();
         const uint8_t *d = cur.data();
         const size_t n = cur.size();
         size_t o = begin;
@@ -553,6 +578,8 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
         if (err) { if (producer.joinable()) producer.join(); return err; }
 
         // ---- phase 2 (parallel): columns ----------------------------------------------------------
+        T[2] += now_s() - t0;
+        t0 = now_s();
         const size_t m = starts.size();
         cols.pos.resize((size_t)base + m); cols.tlen.resize((size_t)base + m);
         cols.flag.resize((size_t)base + m); cols.mapq.resize((size_t)base + m);
@@ -584,7 +611,10 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
         });
 
         // ---- hand the unparsed tail to the next batch ------------------------------------------------
+        T[3] += now_s() - t0;
+        t0 = now_s();
         if (producer.joinable()) producer.join();
+        T[1] += now_s() - t0;
         if (rc_next) return rc_next;
         const size_t tail = n - o;
         if (b1 < b2) {
@@ -605,6 +635,7 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
         b0 = b1;
     }
     while ((int)cols.ref_off.size() < n_ref + 1) cols.ref_off.push_back(cols.size());
+    T[4] = now_s() - t_begin;
     return 0;
 }
 
