@@ -531,9 +531,60 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
     }
     const int n_ref = (int)hdr.names.size();
     int32_t last_rid = -1, last_pos = -1;
-    std::vector<uint32_t> starts;           // record offsets inside `cur`
-    std::vector<uint32_t> ncig;             // CIGAR operations per record (CG tag resolved)
-    std::vector<uint8_t> has_cg;
+
+    // One segment of a batch: the records found by walking block_size links from `start`.
+    // Segments other than the first start at a BGZF block boundary, which is a record boundary in
+    // files written by htslib/samtools and by BamWriter (records are kept inside a block when they
+    // fit).  That is only an assumption: the serial merge below re-walks a segment whenever the
+    // previous one did not end exactly where this one started.
+    struct Segment {
+        size_t start = 0, limit = 0, end = 0;      // walk [start, ...) until o >= limit; end = o reached
+        std::vector<uint32_t> starts, ncig;
+        std::vector<uint8_t> has_cg;
+        std::vector<std::pair<uint32_t, int32_t>> rid_change;   // (local record index, new rid)
+        int64_t unplaced = 0;
+        int32_t first_rid = -1, first_pos = -1, last_rid = -1, last_pos = -1;
+        bool sorted = true, any_cg = false, incomplete = false;
+        int bad = 0;                               // 1 bad block_size, 2 refID range, 3 field overflow
+        int bad_value = 0;
+    };
+    auto walk = [&](const uint8_t *d, size_t n, Segment &g) {
+        g.starts.clear(); g.ncig.clear(); g.has_cg.clear(); g.rid_change.clear();
+        g.unplaced = 0; g.first_rid = g.last_rid = -1; g.first_pos = g.last_pos = -1;
+        g.sorted = true; g.any_cg = false; g.incomplete = false; g.bad = 0;
+        size_t o = g.start;
+        int32_t prid = -1, ppos = -1;
+        while (o < g.limit) {
+            if (o + 4 > n) { g.incomplete = true; break; }
+            const int32_t bs = rdi32(d + o);
+            if (bs < 32) { g.bad = 1; g.bad_value = bs; break; }
+            const size_t next = o + 4 + (size_t)bs;
+            if (next > n) { g.incomplete = true; break; }
+            const int32_t rid = rdi32(d + o + 4), pos = rdi32(d + o + 8);
+            if (rid < 0) { ++g.unplaced; o = next; continue; }
+            if (rid >= n_ref) { g.bad = 2; g.bad_value = rid; break; }
+            const uint32_t l_name = d[o + 12];
+            uint32_t nc = rd16(d + o + 16);
+            if (36 + (size_t)l_name + 4 * (size_t)nc > 4 + (size_t)bs) { g.bad = 3; break; }
+            uint8_t cg = 0;
+            if (nc == 2) {
+                uint32_t real = 0;
+                if (find_cg_tag(d + o, 4 + (size_t)bs, &real)) { nc = real; cg = 1; g.any_cg = true; }
+            }
+            if (g.starts.empty()) { g.first_rid = rid; g.first_pos = pos; }
+            else if (rid < prid || (rid == prid && pos < ppos)) g.sorted = false;
+            if (rid != prid) g.rid_change.emplace_back((uint32_t)g.starts.size(), rid);
+            prid = rid; ppos = pos;
+            g.starts.push_back((uint32_t)o);
+            g.ncig.push_back(nc);
+            g.has_cg.push_back(cg);
+            o = next;
+        }
+        g.last_rid = prid; g.last_pos = ppos;
+        g.end = o;
+    };
+
+    std::vector<Segment> segs;
     size_t b0 = 0;
     while (b0 < blocks.size()) {
         const size_t b1 = std::min(b0 + batch, blocks.size());
@@ -541,72 +592,100 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
         int rc_next = 0;
         std::thread producer;
         if (b1 < b2) producer = std::thread([&] { rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt, kPrefix); });
+        const int workers = producer.joinable() ? std::max(1, threads - 1) : threads;
 
-        // ---- phase 1 (serial): record boundaries ------------------------------------------------
+        // ---- phase 1: record boundaries, speculatively in parallel ---------------------------------
         t0 = now_s();
         const uint8_t *d = cur.data();
         const size_t n = cur.size();
-        size_t o = begin;
-        starts.clear(); ncig.clear(); has_cg.clear();
-        bool any_cg = false;
-        int err = 0;
-        const int64_t base = cols.size();
-        while (o + 4 <= n) {
-            const int32_t bs = rdi32(d + o);
-            if (bs < 32) { err = fail(BSIG_ERR_FORMAT, "malformed BAM record (block_size %d)", bs); break; }
-            const size_t next = o + 4 + (size_t)bs;
-            if (next > n) break;
-            const int32_t rid = rdi32(d + o + 4), pos = rdi32(d + o + 8);
-            if (rid < 0) { ++cols.n_unplaced; o = next; continue; }
-            if (rid >= n_ref) { err = fail(BSIG_ERR_FORMAT, "BAM record with refID %d out of range", rid); break; }
-            if (rid < last_rid || (rid == last_rid && pos < last_pos)) { err = fail(BSIG_ERR_FORMAT, "BAM file is not sorted by coordinate"); break; }
-            const uint32_t l_name = d[o + 12];
-            uint32_t nc = rd16(d + o + 16);
-            if (36 + (size_t)l_name + 4 * (size_t)nc > 4 + (size_t)bs) { err = fail(BSIG_ERR_FORMAT, "malformed BAM record (fields exceed block_size)"); break; }
-            uint8_t cg = 0;
-            if (nc == 2) {
-                uint32_t real = 0;
-                if (find_cg_tag(d + o, 4 + (size_t)bs, &real)) { nc = real; cg = 1; any_cg = true; }
+        {
+            // segment starts: `begin`, then every seg_blocks-th block boundary behind it
+            const size_t seg_blocks = std::max<size_t>(1, std::min<size_t>(32, (b1 - b0) / (size_t)(4 * workers) + 1));
+            std::vector<size_t> cut;
+            cut.push_back(begin);
+            size_t boundary = n - [&] { uint64_t t = 0; for (size_t k = b0; k < b1; ++k) t += blocks[k].isize; return (size_t)t; }();
+            for (size_t k = b0; k < b1; ++k) {
+                if (k > b0 && (k - b0) % seg_blocks == 0 && boundary > begin) cut.push_back(boundary);
+                boundary += blocks[k].isize;
             }
-            while ((int)cols.ref_off.size() <= rid) cols.ref_off.push_back(base + (int64_t)starts.size());
-            last_rid = rid; last_pos = pos;
-            starts.push_back((uint32_t)o);
-            ncig.push_back(nc);
-            has_cg.push_back(cg);
-            o = next;
+            segs.resize(cut.size());
+            for (size_t k = 0; k < cut.size(); ++k) {
+                segs[k].start = cut[k];
+                segs[k].limit = k + 1 < cut.size() ? cut[k + 1] : n;
+            }
+        }
+        parallel_for((int64_t)segs.size(), workers, [&](int64_t k, int) { walk(d, n, segs[(size_t)k]); });
+        // serial merge: every segment must begin where its predecessor ended
+        size_t o = begin;
+        int err = 0;
+        for (size_t k = 0; k < segs.size() && !err; ++k) {
+            Segment &g = segs[k];
+            if (o >= g.limit && k + 1 < segs.size()) {       // predecessor's last record swallowed this one
+                g.starts.clear(); g.ncig.clear(); g.has_cg.clear(); g.rid_change.clear();
+                g.unplaced = 0; g.sorted = true; g.any_cg = false; g.incomplete = false; g.bad = 0;
+                g.start = g.end = o;
+                continue;
+            }
+            if (g.start != o) { g.start = o; walk(d, n, g); }     // the assumption failed: walk again
+            if (g.bad == 1) err = fail(BSIG_ERR_FORMAT, "malformed BAM record (block_size %d)", g.bad_value);
+            else if (g.bad == 2) err = fail(BSIG_ERR_FORMAT, "BAM record with refID %d out of range", g.bad_value);
+            else if (g.bad == 3) err = fail(BSIG_ERR_FORMAT, "malformed BAM record (fields exceed block_size)");
+            if (err) break;
+            if (!g.starts.empty()) {
+                if (!g.sorted || g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos))
+                    err = fail(BSIG_ERR_FORMAT, "BAM file is not sorted by coordinate");
+                last_rid = g.last_rid; last_pos = g.last_pos;
+            }
+            o = g.end;
+            if (g.incomplete) {
+                // only the tail of the batch may be incomplete; later segments (if any) hold nothing
+                for (size_t q = k + 1; q < segs.size(); ++q) { segs[q].starts.clear(); segs[q].ncig.clear(); segs[q].has_cg.clear(); segs[q].rid_change.clear(); segs[q].unplaced = 0; }
+                break;
+            }
         }
         if (err) { if (producer.joinable()) producer.join(); return err; }
-
-        // ---- phase 2 (parallel): columns ----------------------------------------------------------
         T[2] += now_s() - t0;
+
+        // ---- phase 2 (parallel): columns ------------------------------------------------------------
         t0 = now_s();
-        const size_t m = starts.size();
+        const int64_t base = cols.size();
+        std::vector<int64_t> rec0(segs.size() + 1, 0);
+        for (size_t k = 0; k < segs.size(); ++k) rec0[k + 1] = rec0[k] + (int64_t)segs[k].starts.size();
+        const size_t m = (size_t)rec0.back();
         cols.pos.resize((size_t)base + m); cols.tlen.resize((size_t)base + m);
         cols.flag.resize((size_t)base + m); cols.mapq.resize((size_t)base + m);
         cols.cigar_off.resize((size_t)base + m + 1);
-        int64_t cacc = cols.cigar_off[(size_t)base];
-        for (size_t k = 0; k < m; ++k) { cacc += ncig[k]; cols.cigar_off[(size_t)base + k + 1] = cacc; }
-        cols.cigar.resize((size_t)cacc);
-        const size_t slice = 1 << 16;
-        const int64_t n_slices = (int64_t)((m + slice - 1) / slice);
-        parallel_for(n_slices, producer.joinable() ? std::max(1, threads - 1) : threads, [&](int64_t si, int) {
-            const size_t k0 = (size_t)si * slice, k1 = std::min(m, k0 + slice);
-            for (size_t k = k0; k < k1; ++k) {
-                const uint8_t *r = d + starts[k];
+        std::vector<int64_t> cig0(segs.size() + 1, cols.cigar_off[(size_t)base]);
+        for (size_t k = 0; k < segs.size(); ++k) {
+            int64_t t = 0;
+            for (uint32_t v : segs[k].ncig) t += v;
+            cig0[k + 1] = cig0[k] + t;
+            cols.n_unplaced += segs[k].unplaced;
+            for (const auto &rc_ : segs[k].rid_change)
+                while ((int)cols.ref_off.size() <= rc_.second) cols.ref_off.push_back(base + rec0[k] + rc_.first);
+        }
+        cols.cigar.resize((size_t)cig0.back());
+        parallel_for((int64_t)segs.size(), workers, [&](int64_t si, int) {
+            const Segment &g = segs[(size_t)si];
+            int64_t cacc = cig0[(size_t)si];
+            for (size_t k = 0; k < g.starts.size(); ++k) {
+                const uint8_t *r = d + g.starts[k];
                 const uint8_t *c = r + 4;
-                const size_t i = (size_t)base + k;
+                const size_t i = (size_t)(base + rec0[(size_t)si]) + k;
                 cols.pos[i] = rdi32(c + 4);
                 cols.mapq[i] = c[9];
                 cols.flag[i] = rd16(c + 14);
                 cols.tlen[i] = rdi32(c + 28);
-                uint32_t *dst = cols.cigar.data() + cols.cigar_off[i];
-                if (any_cg && has_cg[k]) {
+                uint32_t *dst = cols.cigar.data() + cacc;
+                if (g.any_cg && g.has_cg[k]) {
                     uint32_t real = 0;
                     const uint8_t *src = find_cg_tag(r, 4 + (size_t)rdi32(r), &real);
                     memcpy(dst, src, 4 * (size_t)real);
-                } else if (ncig[k]) {
-                    memcpy(dst, c + 32 + c[8], 4 * (size_t)ncig[k]);
+                } else if (g.ncig[k]) {
+                    memcpy(dst, c + 32 + c[8], 4 * (size_t)g.ncig[k]);
                 }
+                cacc += g.ncig[k];
+                cols.cigar_off[i + 1] = cacc;
             }
         });
 

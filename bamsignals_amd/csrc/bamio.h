@@ -8,7 +8,9 @@
 #define BSIG_BAMIO_H
 #include <stdint.h>
 
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace bsig {
@@ -25,14 +27,26 @@ struct BamHeader {
     }
 };
 
+// allocator whose resize() leaves new elements uninitialised: the decode threads are the first
+// to touch (and page in) the column memory, instead of a serial zero fill
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+template <typename T> using ColVec = std::vector<T, NoInitAlloc<T>>;
+
 // columns of the placed records (refID >= 0), in file order = sorted by (refID, pos)
 struct HostColumns {
     std::vector<int64_t> ref_off;     // n_ref + 1
-    std::vector<int32_t> pos, tlen;
-    std::vector<uint16_t> flag;
-    std::vector<uint8_t> mapq;
-    std::vector<int64_t> cigar_off;   // n + 1
-    std::vector<uint32_t> cigar;
+    ColVec<int32_t> pos, tlen;
+    ColVec<uint16_t> flag;
+    ColVec<uint8_t> mapq;
+    ColVec<int64_t> cigar_off;        // n + 1
+    ColVec<uint32_t> cigar;
     int64_t n_unplaced = 0;           // records with refID < 0 (skipped)
     int64_t size() const { return (int64_t)pos.size(); }
 };

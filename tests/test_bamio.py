@@ -63,6 +63,41 @@ def test_decode_in_many_small_batches(fixture_reads):
         assert out == want, nb
 
 
+def test_records_straddling_bgzf_blocks(tmp_path, fixture_reads):
+    """The parallel boundary scan assumes that BGZF blocks start at record boundaries and must fall
+    back to a serial walk where they do not: re-block the fixture stream at odd sizes."""
+    import subprocess
+    import sys
+    import zlib
+    stream = gzip.decompress(open(BAM, "rb").read())
+    out = b""
+    rng = np.random.default_rng(8)
+    i = 0
+    while i < len(stream):
+        n = int(rng.integers(500, 9000))
+        chunk = stream[i:i + n]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        dd = co.compress(chunk) + co.flush()
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(dd) + 25) + dd
+                + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        i += n
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    p = tmp_path / "straddle.bam"
+    p.write_bytes(out)
+    (tmp_path / "straddle.bam.bai").write_bytes(b"BAI\x01" + struct.pack("<i", 3) + struct.pack("<ii", 0, 0) * 3 + struct.pack("<Q", 0))
+    from bamsignals_amd.bamio import BamFile
+    _cols_equal(BamFile(str(p)).decode(threads=4), fixture_reads)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from bamsignals_amd.bamio import BamFile; "
+            "c = BamFile(%r).decode(threads=3); print(len(c['pos']), int(c['pos'].astype(np.int64).sum()), "
+            "int(c['cigar'].astype(np.int64).sum()), [int(x) for x in c['ref_off']])" % (os.path.dirname(os.path.dirname(GOLDEN)), str(p)))
+    fx = fixture_reads
+    want = "%d %d %d %s" % (99000, fx["bam_pos"].astype(np.int64).sum(), fx["bam_cigar"].astype(np.int64).sum(),
+                            [int(x) for x in fx["ref_off"]])
+    for nb in ("2", "11"):
+        got = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, BAMSIGNALS_BATCH_BLOCKS=nb)).decode().strip()
+        assert got == want, nb
+
+
 def test_region_decode_is_a_superset_in_file_order(fixture_reads):
     from bamsignals_amd.bamio import BamFile
     fx = fixture_reads
