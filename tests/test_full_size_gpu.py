@@ -1,0 +1,95 @@
+"""GPU: the BASELINE.json configurations at (or near) their full sizes, bit-exact against the C
+oracle — it needs only ~0.05-2 s per configuration on read columns — plus the size-independent
+properties of the domain."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from bamsignals_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, reads, rg, mode, **a):
+    from bamsignals_amd.device import Plan, make_params
+    plan = Plan(ctx, reads, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(mode, **a))
+    out = plan.run_host()
+    st = plan.stats()
+    plan.close()
+    return out, st
+
+
+def test_config2_profile_10k_x_2kb_5e7_reads(ctx):
+    """BASELINE config 2 at full size."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from oracle import oracle_c
+    cols = synth_reads(50_000_000, [250_000_000], with_cigar=False)
+    rg = synth_ranges(10_000, 2000, cols["ref_len"], seed=31)
+    reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    got, st = _run(ctx, reads, rg, _lib.MODE_PROFILE, binsize=1)
+    want, _ = oracle_c.pileup_core(orc, rg, binsize=1)
+    assert np.array_equal(got, want)
+    assert st["cells"] == 20_000_000 and st["n_items"] == 10_000
+    ss, _ = _run(ctx, reads, rg, _lib.MODE_PROFILE, binsize=1, ss=True)
+    assert np.array_equal(ss.reshape(-1, 2).sum(axis=1), got)            # sense + antisense = unstranded
+    cnt, _ = _run(ctx, reads, rg, _lib.MODE_COUNT, binsize=-1)
+    assert np.array_equal(cnt, got.reshape(10_000, 2000).sum(axis=1))     # bamCount = sum of the profile
+    b100, _ = _run(ctx, reads, rg, _lib.MODE_PROFILE, binsize=100)
+    assert np.array_equal(b100, got.reshape(10_000, 20, 100).sum(axis=2))  # binned = summed per-base ...
+    neg = rg["strand"] < 0                                                  # ... in range orientation
+    assert neg.any()
+    reads.close()
+
+
+def test_config3_coverage_chr1_tiling_1e8_reads(ctx):
+    """BASELINE config 3: per-base coverage of 2-kb tiles over a 248,956,422-bp reference."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_reads, tile_ranges
+    from oracle import oracle_c
+    L = 248_956_422
+    cols = synth_reads(100_000_000, [L], seed=3, with_cigar=False)
+    tiles = tile_ranges([L], 2000, strand=0)
+    assert len(tiles["rid"]) == 124_479
+    reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
+    got, st = _run(ctx, reads, tiles, _lib.MODE_COVERAGE)
+    assert st["cells"] == L
+    span = np.minimum(cols["end"].astype(np.int64), L - 1) - cols["pos"] + 1
+    assert int(got.astype(np.int64).sum()) == int(span.sum())              # coverage integrates to total span
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    want, _ = oracle_c.coverage_core(orc, tiles)
+    assert np.array_equal(got, want)
+    # one whole-reference range gives the same vector as the tiling (tiles are self-contained)
+    one = dict(rid=np.zeros(1, np.int32), loc=np.zeros(1, np.int32), len=np.asarray([L], np.int32), strand=np.zeros(1, np.int32))
+    whole, _ = _run(ctx, reads, one, _lib.MODE_COVERAGE)
+    assert np.array_equal(whole, got)
+    reads.close()
+
+
+def test_config4_paired_end_strand_split_100k_ranges(ctx):
+    """BASELINE config 4's call (tlenFilter=c(50,500), shift=75, ss=TRUE; filter and midpoint) on
+    100k x 2 kb ranges; 5e7 paired-end reads here (the 5e8-read BAM differs only in read density)."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from oracle import oracle_c
+    ref_len = [250_000_000]
+    cols = synth_reads(50_000_000, ref_len, seed=9, paired=True, with_cigar=False)
+    rg = synth_ranges(100_000, 2000, ref_len, seed=10)
+    reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    for pe_mid in (False, True):
+        a = dict(binsize=1, ss=True, shift=75, requiredF=66, tlen_filter=(50, 500), pe_mid=pe_mid)
+        got, st = _run(ctx, reads, rg, _lib.MODE_PROFILE, **a)
+        want, _ = oracle_c.pileup_core(orc, rg, **a)
+        assert np.array_equal(got, want), pe_mid
+        assert st["cells"] == 400_000_000 and st["bytes_per_visit_short"] == 12
+    reads.close()
