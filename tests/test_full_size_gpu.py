@@ -43,7 +43,7 @@ def test_config2_profile_10k_x_2kb_5e7_reads(ctx):
     cnt, _ = _run(ctx, reads, rg, _lib.MODE_COUNT, binsize=-1)
     assert np.array_equal(cnt, got.reshape(10_000, 2000).sum(axis=1))     # bamCount = sum of the profile
     b100, _ = _run(ctx, reads, rg, _lib.MODE_PROFILE, binsize=100)
-    assert np.array_equal(b100, got.reshape(10_000, 20, 100).sum(axis=2))  # binned = summed per-base ...
+    assert np.array_equal(b100, got.reshape(10_000, 20, 100).sum(axis=2).reshape(-1))  # binned = summed per-base ...
     neg = rg["strand"] < 0                                                  # ... in range orientation
     assert neg.any()
     reads.close()
