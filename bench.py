@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--batches", type=int, default=8,
                     help="distinct range batches (and result buffers) the steps rotate over, so that the "
                          "working set (8 x ~135 MB at C2) exceeds the 256 MiB Infinity Cache")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise "
+                         "the multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0xBA51)
     a = ap.parse_args()
@@ -69,10 +72,18 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ngpu = torch.cuda.device_count()
+    if a.backend == "nccl" and world > ngpu:
+        raise SystemExit(f"{world} ranks but {ngpu} GPU(s): RCCL needs one GPU per rank")
+    local = local % ngpu
     torch.cuda.set_device(local)
+    cdev = "cuda" if a.backend == "nccl" else "cpu"      # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     from bamsignals_amd import _lib
     from bamsignals_amd.device import Context, Plan, Reads, make_params
@@ -143,7 +154,7 @@ def main():
 
         # whole-job time = max over ranks
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
@@ -179,14 +190,14 @@ def main():
         # ---- final reassembly on rank 0 over RCCL (outside the timed region) -------------------
         gather = None
         if world > 1:
-            shard = out[:plan.cells]
+            shard = out[:plan.cells].to(cdev)
             bufs = [torch.empty_like(shard) for _ in range(world)] if rank == 0 else None
             torch.cuda.synchronize(); dist.barrier()
             t1 = time.perf_counter()
             dist.gather(shard, bufs, dst=0)
             torch.cuda.synchronize()
             t_g = time.perf_counter() - t1
-            sums = torch.tensor([int(got.astype(np.int64).sum())], dtype=torch.int64, device="cuda")
+            sums = torch.tensor([int(got.astype(np.int64).sum())], dtype=torch.int64, device=cdev)
             allsums = [torch.zeros_like(sums) for _ in range(world)]
             dist.all_gather(allsums, sums)
             if rank == 0:
@@ -194,7 +205,7 @@ def main():
                 if not ok:
                     raise SystemExit("gathered shards do not match the per-rank checksums")
                 gather = dict(ms=t_g * 1e3, bytes=int(shard.numel() * 4 * (world - 1)),
-                              GBps=shard.numel() * 4 * (world - 1) / t_g / 1e9, checked=True)
+                              GBps=shard.numel() * 4 * (world - 1) / t_g / 1e9, checked=True, backend=a.backend)
 
     # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
     # (profiles/<tag>_pmc.json, made by scripts/profile_round.sh + scripts/summarize_profile.py);
