@@ -88,6 +88,21 @@ __device__ __forceinline__ void tile_interval(const BsigWorkItem &w, int binsize
     else           { tlo = (int64_t)w.loc + a;         thi = (int64_t)w.loc + b; }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (no LDS traffic): a
+// Hillis-Steele scan inside each row of 16 lanes (row_shr 1,2,4,8; lanes shifted in from outside
+// the row read 0), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then lanes 0-31 ->
+// lanes 32-63 (row_bcast:31).
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 template <int NT>
 __device__ __forceinline__ void block_sync()
 {
@@ -421,14 +436,9 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
         int4 x = v < nvec ? lds4[v] : make_int4(0, 0, 0, 0);
         x.y += x.x; x.z += x.y; x.w += x.z;
         const int tot = x.w;
-        int incl = tot;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const int y = __shfl_up(incl, d);
-            if (lane >= d) incl += y;
-        }
+        const int incl = wave_inclusive_scan(tot);
         int pre = carry;
-        int all = __shfl(incl, kWave - 1);
+        int all = __builtin_amdgcn_readlane(incl, kWave - 1);
         if (NT > kWave) {
             if (lane == kWave - 1) wtot[tid / kWave] = incl;
             __syncthreads();

@@ -413,7 +413,8 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
             widest = std::max<int64_t>(widest, ((int64_t)len[i] + bsz - 1) / bsz);
     }
     P->tile_cells = prm->tile_cells > 0 ? prm->tile_cells : (int)std::min<int64_t>(widest, 2048);
-    P->tile_cells = std::min(std::max(P->tile_cells, 64), prm->ss && mode == BSIG_MODE_PROFILE ? 16384 : 32768);
+    // a tile image is at most 32 KiB of LDS
+    P->tile_cells = std::min(std::max(P->tile_cells, 64), prm->ss && mode == BSIG_MODE_PROFILE ? 4096 : 8192);
     P->tile_cells = (P->tile_cells + 3) & ~3;
     P->threads = prm->threads > 0 ? prm->threads : 64;
     if (P->threads != 64 && P->threads != 128 && P->threads != 256) {

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--reads", type=int, default=0, help="override the number of reads")
     ap.add_argument("--ranges", type=int, default=0, help="override the number of ranges per GPU")
+    ap.add_argument("--width", type=int, default=0, help="override the range width")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tile-cells", type=int, default=0)
     ap.add_argument("--resolve", type=int, default=0, help="1: separate k_resolve launch per step")
@@ -92,13 +93,14 @@ def main():
     cfg = CONFIGS[a.config]
     n_reads = a.reads or cfg["reads"]
     n_ranges = a.ranges or cfg["ranges"]
+    width = a.width or cfg["width"]
 
     # ---- synthetic input (identical reads on every rank; ranges sharded round-robin) ----------
     t0 = time.time()
     cols = synth_reads(n_reads, cfg["ref_len"], seed=a.seed, paired=cfg["paired"], with_cigar=False)
     batches = []
     for b in range(max(a.batches, 1)):
-        all_rg = synth_ranges(n_ranges * world, cfg["width"], cfg["ref_len"], seed=a.seed + 1 + 7919 * b)
+        all_rg = synth_ranges(n_ranges * world, width, cfg["ref_len"], seed=a.seed + 1 + 7919 * b)
         order = np.lexsort((all_rg["loc"], all_rg["rid"]))        # sorted as the reference sorts them
         mine = order[rank::world]                                 # round-robin shard of sorted ranges
         batches.append({k: v[mine] for k, v in all_rg.items()})
@@ -219,7 +221,7 @@ def main():
             except Exception:
                 continue
             if pj.get("workload") == a.config + ": " + cfg["desc"] and not a.threads and not a.tile_cells and not a.resolve \
-                    and not a.reads and not a.ranges and pj.get("step_hbm_bytes"):
+                    and not a.reads and not a.ranges and not a.width and pj.get("step_hbm_bytes"):
                 traffic, traffic_src = pj["step_hbm_bytes"], os.path.relpath(f, ROOT)
                 break
 
@@ -233,7 +235,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": a.config + ": " + cfg["desc"], "reads": n_reads,
-                       "ranges_per_gpu": len(rg["rid"]), "range_width": cfg["width"], "batches": nb,
+                       "ranges_per_gpu": len(rg["rid"]), "range_width": width, "batches": nb,
                        "parallelism": f"ranges round-robin over {world} GPU(s), reads replicated",
                        "threads": params.threads or 64, "tile_cells": params.tile_cells or 2048},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
