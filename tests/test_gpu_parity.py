@@ -274,3 +274,49 @@ def test_error_paths(ctx, synth):
     with pytest.raises(_lib.BsigError) as e:
         Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=0))
     assert "binsize greater or equal to 1" in str(e.value)
+
+
+def test_fuzz_small_inputs(ctx):
+    """Seeded random inputs at the edges: tiny references, reads at position 0 and over the end,
+    extreme spans, every parameter drawn at random.  HIP vs the C oracle, bit for bit."""
+    from bamsignals_amd.device import Reads
+    from oracle import oracle_c
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n_ref = int(rng.integers(1, 4))
+        ref_len = rng.integers(1, 70_000, n_ref).astype(np.int32)
+        n = int(rng.integers(0, 4000))
+        rid = np.sort(rng.integers(0, n_ref, n)).astype(np.int32)
+        pos = (rng.random(n) * ref_len[rid]).astype(np.int32)
+        order = np.lexsort((pos, rid))
+        rid, pos = rid[order], pos[order]
+        span = np.where(rng.random(n) < 0.8, rng.integers(1, 200, n),
+                        np.where(rng.random(n) < 0.7, rng.integers(200, 5000, n), rng.integers(5000, 90_000, n)))
+        end = (pos + span - 1).astype(np.int32)
+        flag = (rng.integers(0, 2, n) * 16 + rng.integers(0, 2, n) * 1024 + rng.integers(0, 2, n) * 64
+                + rng.integers(0, 2, n) * 2 + (rng.random(n) < 0.02) * 4).astype(np.uint16)
+        mapq = rng.integers(0, 256, n).astype(np.uint8)
+        tlen = rng.integers(-700, 700, n).astype(np.int32)
+        ref_off = np.searchsorted(rid, np.arange(n_ref + 1)).astype(np.int64)
+        gpu = Reads(ctx, ref_len, ref_off, pos, flag, mapq, tlen, end=end)
+        orc = oracle_c.OracleReads(ref_off, pos, end, flag, mapq, tlen)
+        m = int(rng.integers(1, 40))
+        rg = dict(rid=rng.integers(0, n_ref, m).astype(np.int32), loc=rng.integers(-300, 70_300, m).astype(np.int32),
+                  len=np.where(rng.random(m) < 0.1, 0, rng.integers(1, 9000, m)).astype(np.int32),
+                  strand=rng.integers(-1, 2, m).astype(np.int32))
+        pe = rng.random() < 0.5
+        tf = tuple(sorted(int(x) for x in rng.integers(0, 700, 2))) if pe else ()
+        common = dict(mapqual=int(rng.integers(0, 80)), requiredF=int(rng.choice([0, 2, 66])),
+                      filteredF=int(rng.choice([-1, 0, 16, 1024, 1040])), tlen_filter=tf)
+        pile = dict(common, binsize=int(rng.choice([-1, 1, 1, 2, 3, 10, 147, 5000])), shift=int(rng.integers(-150, 150)),
+                    ss=bool(rng.integers(0, 2)), pe_mid=bool(pe and rng.integers(0, 2)))
+        want, woff = oracle_c.pileup_core(orc, rg, **pile)
+        got, off = _gpu(ctx, gpu, rg, "pileup", tile_cells=int(rng.choice([0, 64, 256, 1000])),
+                        threads=int(rng.choice([0, 64, 128, 256])), **dict(pile))
+        assert np.array_equal(off, woff) and np.array_equal(got, want), (case, pile)
+        cov = dict(common, tspan=bool(pe and rng.integers(0, 2)))
+        want, woff = oracle_c.coverage_core(orc, rg, **cov)
+        got, off = _gpu(ctx, gpu, rg, "coverage", tile_cells=int(rng.choice([0, 64, 256, 1000])),
+                        threads=int(rng.choice([0, 64, 128, 256])), **dict(cov))
+        assert np.array_equal(off, woff) and np.array_equal(got, want), (case, cov)
+        gpu.close()
