@@ -15,15 +15,37 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <new>
 #include <sstream>
 #include <thread>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 
 #include "../../include/bamsignals_abi.h"
 #include "host_util.h"
 
 namespace bsig {
+
+void *column_alloc(size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    if (bytes >= (4u << 20)) {
+        void *p = nullptr;
+        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        if (posix_memalign(&p, 2u << 20, rounded) != 0) throw std::bad_alloc();
+        madvise(p, rounded, MADV_HUGEPAGE);
+        return p;
+    }
+    void *p = malloc(bytes);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+void column_free(void *p) { free(p); }
 
 // stage timers of the last whole-file decode on this thread: block scan, waiting for inflate,
 // boundary scan (serial), column extraction (parallel), total
@@ -137,22 +159,93 @@ int n_threads(int t)
     return (int)std::max(1u, std::min(hc, 32u));
 }
 
+// A small persistent worker pool: the decode runs dozens of short parallel sections per file and
+// spawning threads for each of them costs more than the sections themselves.
+class Pool {
+public:
+    static Pool &get()
+    {
+        static Pool p;
+        return p;
+    }
+    // runs body(i, slot) for i in [0, n) on up to `threads` workers (the caller is one of them)
+    template <typename F>
+    void run(int64_t n, int threads, F &&body)
+    {
+        if (n <= 0) return;
+        threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
+        if (threads == 1) { for (int64_t i = 0; i < n; ++i) body(i, 0); return; }
+        ensure(threads - 1);
+        struct Job {
+            std::atomic<int64_t> next{0};
+            std::atomic<int> pending{0};
+            int64_t n;
+            std::function<void(int64_t, int)> fn;
+            std::mutex m;
+            std::condition_variable done;
+        };
+        auto job = std::make_shared<Job>();
+        job->n = n;
+        job->fn = body;
+        job->pending = threads - 1;
+        auto work = [job](int slot) {
+            for (;;) {
+                const int64_t i = job->next.fetch_add(1);
+                if (i >= job->n) break;
+                job->fn(i, slot);
+            }
+        };
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (int t = 1; t < threads; ++t)
+                q_.emplace_back([job, work, t] {
+                    work(t);
+                    if (job->pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> l2(job->m); job->done.notify_all(); }
+                });
+        }
+        cv_.notify_all();
+        work(0);
+        std::unique_lock<std::mutex> lk(job->m);
+        job->done.wait(lk, [&] { return job->pending.load() == 0; });
+    }
+
+private:
+    Pool() = default;
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void ensure(int workers)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        while ((int)th_.size() < workers)
+            th_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> task;
+                    {
+                        std::unique_lock<std::mutex> lk(m_);
+                        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                        if (stop_ && q_.empty()) return;
+                        task = std::move(q_.front());
+                        q_.pop_front();
+                    }
+                    task();
+                }
+            });
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
 template <typename F>
 void parallel_for(int64_t n, int threads, F &&body)
 {
-    threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
-    if (threads == 1) { for (int64_t i = 0; i < n; ++i) body(i, 0); return; }
-    std::atomic<int64_t> next(0);
-    std::vector<std::thread> ts;
-    for (int t = 0; t < threads; ++t)
-        ts.emplace_back([&, t] {
-            for (;;) {
-                const int64_t i = next.fetch_add(1);
-                if (i >= n) break;
-                body(i, t);
-            }
-        });
-    for (auto &t : ts) t.join();
+    Pool::get().run(n, threads, std::forward<F>(body));
 }
 
 // read-only memory map of a file
@@ -430,10 +523,10 @@ static int inflate_batch(const MappedFile &f, const std::vector<Block> &blocks, 
     for (size_t k = b0; k < b1; ++k) uoff[k - b0 + 1] = uoff[k - b0] + blocks[k].isize;
     out.resize(prefix + uoff.back());
     std::atomic<int> bad(0);
-    std::vector<Inflater> inf((size_t)std::max(1, threads));
-    parallel_for((int64_t)(b1 - b0), threads, [&](int64_t i, int t) {
+    parallel_for((int64_t)(b1 - b0), threads, [&](int64_t i, int) {
+        static thread_local Inflater inf;          // one decompressor per worker thread
         const Block &b = blocks[b0 + (size_t)i];
-        if (!inf[(size_t)t].run(f.data + b.coff + b.doff, b.dlen, out.data() + prefix + uoff[(size_t)i], b.isize)) bad = 1;
+        if (!inf.run(f.data + b.coff + b.doff, b.dlen, out.data() + prefix + uoff[(size_t)i], b.isize)) bad = 1;
     });
     if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
     return 0;
@@ -888,11 +981,11 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
         for (size_t a = 0; a < jobs.size(); ++a)
             for (size_t b = 0; b < jobs[a].bl.size(); ++b) work.emplace_back((uint32_t)a, (uint32_t)b);
         std::atomic<int> bad(0);
-        std::vector<Inflater> inf((size_t)std::max(1, threads));
-        parallel_for((int64_t)work.size(), threads, [&](int64_t w, int t) {
+        parallel_for((int64_t)work.size(), threads, [&](int64_t w, int) {
+            static thread_local Inflater inf;
             Job &j = jobs[work[(size_t)w].first];
             const Block &b = j.bl[work[(size_t)w].second];
-            if (!inf[(size_t)t].run(f.data + b.coff + b.doff, b.dlen, j.buf.data() + j.boff[work[(size_t)w].second], b.isize)) bad = 1;
+            if (!inf.run(f.data + b.coff + b.doff, b.dlen, j.buf.data() + j.boff[work[(size_t)w].second], b.isize)) bad = 1;
         });
         if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
         for (Job &j : jobs) {

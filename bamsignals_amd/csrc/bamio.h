@@ -28,12 +28,22 @@ struct BamHeader {
 };
 
 // allocator whose resize() leaves new elements uninitialised: the decode threads are the first
-// to touch (and page in) the column memory, instead of a serial zero fill
+// to touch (and page in) the column memory, instead of a serial zero fill; big buffers ask for
+// transparent huge pages so that paging in 1+ GB of columns is thousands, not hundreds of
+// thousands, of faults
+void *column_alloc(size_t bytes);      // 2-MiB aligned + MADV_HUGEPAGE for large buffers
+void column_free(void *p);
+
 template <typename T>
-struct NoInitAlloc : std::allocator<T> {
+struct NoInitAlloc {
+    using value_type = T;
     template <typename U> struct rebind { using other = NoInitAlloc<U>; };
     NoInitAlloc() = default;
     template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(column_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { column_free(p); }
+    bool operator==(const NoInitAlloc &) const { return true; }
+    bool operator!=(const NoInitAlloc &) const { return false; }
     template <typename U> void construct(U *p) noexcept { ::new ((void *)p) U; }
     template <typename U, typename... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
 };
