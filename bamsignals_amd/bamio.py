@@ -36,9 +36,9 @@ class BamFile:
     def decode_timing(self):
         """Stage seconds of this thread's last whole-file decode (scan, inflate wait, boundary scan,
         column extraction, total)."""
-        t = (C.c_double * 5)()
+        t = (C.c_double * 6)()
         self._lib.bsig_bam_decode_timing(t)
-        return dict(zip(("block_scan", "inflate_wait", "boundary_scan", "extract", "total"), list(t)))
+        return dict(zip(("block_scan", "inflate_wait", "boundary_scan", "extract", "total", "inflate_busy"), list(t)))
 
     def decode(self, rid=None, beg=None, end=None, threads=0):
         """Columns of the records the index lists for regions [beg, end) (0-based); all if rid is None."""

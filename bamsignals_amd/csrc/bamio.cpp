@@ -49,7 +49,7 @@ void column_free(void *p) { free(p); }
 
 // stage timers of the last whole-file decode on this thread: block scan, waiting for inflate,
 // boundary scan (serial), column extraction (parallel), total
-thread_local double g_decode_timing[5] = {0, 0, 0, 0, 0};
+thread_local double g_decode_timing[6] = {0, 0, 0, 0, 0, 0};
 static inline double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -175,7 +175,9 @@ public:
         if (n <= 0) return;
         threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
         if (threads == 1) { for (int64_t i = 0; i < n; ++i) body(i, 0); return; }
-        ensure(threads - 1);
+        // two sections may run at once (inflate of the next batch beside the parse of this one):
+        // keep enough workers for the tasks already queued or running plus the new ones
+        ensure(outstanding_.load() + threads - 1);
         struct Job {
             std::atomic<int64_t> next{0};
             std::atomic<int> pending{0};
@@ -197,9 +199,11 @@ public:
         };
         {
             std::lock_guard<std::mutex> lk(m_);
+            outstanding_ += threads - 1;
             for (int t = 1; t < threads; ++t)
-                q_.emplace_back([job, work, t] {
+                q_.emplace_back([this, job, work, t] {
                     work(t);
+                    --outstanding_;
                     if (job->pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> l2(job->m); job->done.notify_all(); }
                 });
         }
@@ -220,6 +224,7 @@ private:
     void ensure(int workers)
     {
         std::lock_guard<std::mutex> lk(m_);
+        workers = std::min(workers, 512);
         while ((int)th_.size() < workers)
             th_.emplace_back([this] {
                 for (;;) {
@@ -239,6 +244,7 @@ private:
     std::deque<std::function<void()>> q_;
     std::mutex m_;
     std::condition_variable cv_;
+    std::atomic<int> outstanding_{0};
     bool stop_ = false;
 };
 
@@ -261,7 +267,9 @@ struct MappedFile {
         if (fstat(fd, &st) != 0) return -1;
         size = (size_t)st.st_size;
         if (size == 0) { data = nullptr; return 0; }
-        void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        int flags = MAP_PRIVATE;
+        if (getenv("BAMSIGNALS_MMAP_POPULATE")) flags |= MAP_POPULATE;
+        void *p = mmap(nullptr, size, PROT_READ, flags, fd, 0);
         if (p == MAP_FAILED) return -1;
         data = (const uint8_t *)p;
         madvise(p, size, MADV_SEQUENTIAL);
@@ -579,7 +587,7 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
     if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
     threads = n_threads(threads);
     double *T = g_decode_timing;
-    T[0] = T[1] = T[2] = T[3] = T[4] = 0;
+    T[0] = T[1] = T[2] = T[3] = T[4] = T[5] = 0;
     const double t_begin = now_s();
     std::vector<Block> blocks;
     int rc = scan_blocks(f, path, blocks);
@@ -604,6 +612,13 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
     }
     std::vector<uint8_t> cur, nxt;
     if (blocks.empty()) return fail(BSIG_ERR_FORMAT, "truncated BAM header in %s", path.c_str());
+    {
+        // both batch buffers get their final capacity now: a later, slightly larger batch must not
+        // reallocate (and page in) 128 MiB again
+        const size_t cap = kPrefix + std::min(batch, blocks.size()) * (size_t)0x10000;
+        cur.reserve(cap);
+        nxt.reserve(cap);
+    }
     double t0 = now_s();
     rc = inflate_batch(f, blocks, 0, std::min(batch, blocks.size()), threads, cur, kPrefix);
     if (rc) return rc;
@@ -684,7 +699,11 @@ int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostCol
         const size_t b2 = std::min(b1 + batch, blocks.size());
         int rc_next = 0;
         std::thread producer;
-        if (b1 < b2) producer = std::thread([&] { rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt, kPrefix); });
+        if (b1 < b2) producer = std::thread([&, T] {
+            const double ti = now_s();
+            rc_next = inflate_batch(f, blocks, b1, b2, std::max(1, threads - 1), nxt, kPrefix);
+            T[5] += now_s() - ti;            // producer-side inflate time (this thread's timer array)
+        });
         const int workers = producer.joinable() ? std::max(1, threads - 1) : threads;
 
         // ---- phase 1: record boundaries, speculatively in parallel ---------------------------------

@@ -82,7 +82,7 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
 int bam_read_header(const std::string &path, BamHeader &hdr);
 // seconds of the last bam_decode_all on this thread: block scan, inflate wait, boundary scan,
 // column extraction, total
-extern thread_local double g_decode_timing[5];
+extern thread_local double g_decode_timing[6];
 int bai_load(const std::string &bai_path, BaiIndex &idx);
 
 // One alignment for the writer

@@ -228,9 +228,9 @@ int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const in
     return BSIG_OK;
 }
 
-void bsig_bam_decode_timing(double *t5)
+void bsig_bam_decode_timing(double *t6)
 {
-    for (int k = 0; k < 5; ++k) t5[k] = bsig::g_decode_timing[k];
+    for (int k = 0; k < 6; ++k) t6[k] = bsig::g_decode_timing[k];
 }
 
 int bsig_pileup_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,

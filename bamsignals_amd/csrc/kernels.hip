@@ -103,6 +103,16 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
     return v;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share an L2), tiles are sorted
+// by position: give every XCD one contiguous run of the tile list, so that neighbouring tiles,
+// whose read windows overlap, meet in the same L2.  A bijection of [0, n); any mapping would be
+// correct, this one is only faster (no assumption about WHICH XCD a block lands on).
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t n)
+{
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u, k = b >> 3;
+    return x * q + (x < r ? x : r) + k;
+}
+
 template <int NT>
 __device__ __forceinline__ void block_sync()
 {
@@ -225,10 +235,11 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
 // form) looked up here with the index loads of all classes issued back to back.
 __device__ __forceinline__ void load_windows(const BsigReadsDev &R, const BsigKParams &P, int mode,
                                              const BsigWorkItem &w, const BsigWorkItem *__restrict__ items,
-                                             const uint2 *__restrict__ windows, uint2 (&win)[BSIG_MAX_CLASSES])
+                                             const uint2 *__restrict__ windows, uint2 (&win)[BSIG_MAX_CLASSES],
+                                             uint32_t tile)
 {
     if (windows) {
-        const uint4 *wp = reinterpret_cast<const uint4 *>(windows + (size_t)BSIG_MAX_CLASSES * blockIdx.x);
+        const uint4 *wp = reinterpret_cast<const uint4 *>(windows + (size_t)BSIG_MAX_CLASSES * tile);
         const uint4 a = wp[0], b = wp[1];
         win[0] = make_uint2(a.x, a.y); win[1] = make_uint2(a.z, a.w);
         win[2] = make_uint2(b.x, b.y); win[3] = make_uint2(b.z, b.w);
@@ -272,9 +283,10 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
     constexpr int S = SS ? 2 : 1;
     const int tid = threadIdx.x;
     BSIG_STAMP(0);
-    const BsigWorkItem w = items[blockIdx.x];
+    const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x);
+    const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win);
+    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     // clear the whole tile image: this needs nothing from the work item, so it overlaps its load
     for (int v = tid; v < (P.tile_cells * S + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
@@ -334,9 +346,10 @@ __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKP
 {
     __shared__ int32_t wsum[2 * (NT / kWave)];
     const int tid = threadIdx.x;
-    const BsigWorkItem w = items[blockIdx.x];
+    const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x);
+    const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win);
+    load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win, tile);
     const bool neg_range = (w.units_strand >> 30) & 1u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
     const int gn = w.nc;
@@ -395,9 +408,10 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
     int32_t *wtot = lds + P.tile_cells + 8;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const BsigWorkItem w = items[blockIdx.x];
+    const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x);
+    const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win);
+    load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win, tile);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     for (int v = tid; v < (P.tile_cells + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     const int nv = w.nc;

@@ -237,7 +237,8 @@ def main():
             "config": {"workload": a.config + ": " + cfg["desc"], "reads": n_reads,
                        "ranges_per_gpu": len(rg["rid"]), "range_width": width, "batches": nb,
                        "parallelism": f"ranges round-robin over {world} GPU(s), reads replicated",
-                       "threads": params.threads or 64, "tile_cells": params.tile_cells or 2048},
+                       "threads": params.threads or 64,
+                       "tile_cells": params.tile_cells or "auto (widest range, at most 2048)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_resolve + k_profile (one step)" if a.resolve else "k_profile", "kernel_ms": kernel_ms,

@@ -183,8 +183,8 @@ int32_t bsig_bam_name2id(const bsig_bam *bam, const char *name);          /* -1 
 int bsig_bam_decode(bsig_bam *bam, int64_t n_regions, const int32_t *rid, const int64_t *beg,
                     const int64_t *end, int32_t threads, bsig_columns *cols);
 /* stage timers (seconds) of the calling thread's last whole-file decode: BGZF block scan, waiting
- * for inflate, record-boundary scan (serial), column extraction (parallel), total               */
-void bsig_bam_decode_timing(double *t5);
+ * for inflate, record-boundary scan, column extraction, total, inflate time on the producer side */
+void bsig_bam_decode_timing(double *t6);
 
 /* ------------------------------------------------------------------------------------------
  * File-level drop-in entry points: what the R shim's .Call routines bind.

@@ -16,15 +16,15 @@ def ctx():
     c.close()
 
 
-def _gpu(ctx, reads, ranges, kind, tile_cells=0, threads=0, **a):
+def _gpu(ctx, reads, ranges, kind, tile_cells=0, threads=0, resolve=0, **a):
     from bamsignals_amd import _lib
     from bamsignals_amd.device import Plan, make_params
     if kind == "coverage":
-        p = make_params(_lib.MODE_COVERAGE, tile_cells=tile_cells, threads=threads, **a)
+        p = make_params(_lib.MODE_COVERAGE, tile_cells=tile_cells, threads=threads, resolve=resolve, **a)
     else:
         bs = a.pop("binsize", 1)
         mode = _lib.MODE_COUNT if bs <= 0 else _lib.MODE_PROFILE
-        p = make_params(mode, binsize=bs, tile_cells=tile_cells, threads=threads, **a)
+        p = make_params(mode, binsize=bs, tile_cells=tile_cells, threads=threads, resolve=resolve, **a)
     plan = Plan(ctx, reads, ranges["rid"], ranges["loc"], ranges["len"], ranges["strand"], p)
     out = plan.run_host()
     off = plan.offsets
@@ -312,11 +312,11 @@ def test_fuzz_small_inputs(ctx):
                     ss=bool(rng.integers(0, 2)), pe_mid=bool(pe and rng.integers(0, 2)))
         want, woff = oracle_c.pileup_core(orc, rg, **pile)
         got, off = _gpu(ctx, gpu, rg, "pileup", tile_cells=int(rng.choice([0, 64, 256, 1000])),
-                        threads=int(rng.choice([0, 64, 128, 256])), **dict(pile))
+                        threads=int(rng.choice([0, 64, 128, 256])), resolve=int(rng.integers(0, 2)), **dict(pile))
         assert np.array_equal(off, woff) and np.array_equal(got, want), (case, pile)
         cov = dict(common, tspan=bool(pe and rng.integers(0, 2)))
         want, woff = oracle_c.coverage_core(orc, rg, **cov)
         got, off = _gpu(ctx, gpu, rg, "coverage", tile_cells=int(rng.choice([0, 64, 256, 1000])),
-                        threads=int(rng.choice([0, 64, 128, 256])), **dict(cov))
+                        threads=int(rng.choice([0, 64, 128, 256])), resolve=int(rng.integers(0, 2)), **dict(cov))
         assert np.array_equal(off, woff) and np.array_equal(got, want), (case, cov)
         gpu.close()
