@@ -121,6 +121,8 @@ def load():
     lib.bsig_write_columns_as_bam.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Columns),
                                               C.c_int32]
     lib.bsig_cache_clear.restype = None
+    lib.bsig_last_call_timing.argtypes = [C.POINTER(C.c_double)]
+    lib.bsig_last_call_timing.restype = None
     lib.bsig_scatter_segments.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib

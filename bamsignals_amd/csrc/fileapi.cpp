@@ -3,6 +3,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -24,6 +25,15 @@ struct bsig_bam {
 };
 
 namespace {
+
+// stage seconds of the calling thread's last file-level call: open (header + BAI), decode,
+// upload + HBM layout, plan + kernels + result download, total; [5] = 1 if the BAM was already
+// resident in HBM
+thread_local double g_call_timing[6] = {0, 0, 0, 0, 0, 0};
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 void fill_columns(const bsig_bam *b, bsig_columns *c)
 {
@@ -82,9 +92,13 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (!bampath) return fail(BSIG_ERR_ARG, "bampath is NULL");
     if (n < 0 || (n > 0 && (!seq_code || !start || !width || !strand || !levels)))
         return fail(BSIG_ERR_ARG, "range arrays missing");
+    double *T = g_call_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
     bsig_bam *bam = nullptr;
     int rc = bsig_bam_open(bampath, &bam);                       // ref: Bamfile ctor :200-214
     if (rc) return rc;
+    T[0] = now_s() - t_begin;
     std::unique_ptr<bsig_bam, void (*)(bsig_bam *)> guard(bam, bsig_bam_close);
 
     // seqnames -> BAM reference ids, by name (ref: parseRegions :113-120)
@@ -137,7 +151,9 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (force && !strcmp(force, "regions")) whole = false;
     if (!key.empty() && key == g_cache.key && g_cache.reads) {
         reads = g_cache.reads;
+        T[5] = 1;
     } else {
+        const double t_dec = now_s();
         bsig_columns cols;
         if (whole) {
             rc = bsig_bam_decode(bam, -1, nullptr, nullptr, nullptr, 0, &cols);
@@ -150,8 +166,11 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             rc = bsig_bam_decode(bam, n, rid.data(), beg.data(), end.data(), 0, &cols);
         }
         if (rc) return rc;
+        T[1] = now_s() - t_dec;
+        const double t_up = now_s();
         rc = bsig_reads_upload(g_cache.ctx, &cols, &reads);
         if (rc) return rc;
+        T[2] = now_s() - t_up;
         if (whole && !key.empty()) {
             g_cache.clear();
             g_cache.reads = reads;
@@ -160,8 +179,11 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             owned = true;
         }
     }
+    const double t_run = now_s();
     rc = bsig_pileup_columns(g_cache.ctx, reads, n, rid.data(), loc.data(), width, strand, &prm, out, off);
+    T[3] = now_s() - t_run;
     if (owned) bsig_reads_free(reads);
+    T[4] = now_s() - t_begin;
     return rc;
 }
 
@@ -226,6 +248,11 @@ int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const in
     if (rc) return rc;
     fill_columns(b, cols);
     return BSIG_OK;
+}
+
+void bsig_last_call_timing(double *t6)
+{
+    for (int k = 0; k < 6; ++k) t6[k] = g_call_timing[k];
 }
 
 void bsig_bam_decode_timing(double *t6)

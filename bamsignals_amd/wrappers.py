@@ -126,6 +126,14 @@ def coverage_core(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1
     return _split(out, off, False)
 
 
+def last_call_timing():
+    """Stage seconds of this thread's last bamCount/bamProfile/bamCoverage call."""
+    t = (C.c_double * 6)()
+    _lib.load().bsig_last_call_timing(t)
+    return dict(open=t[0], decode=t[1], upload_and_layout=t[2], plan_run_download=t[3], total=t[4],
+                bam_was_resident=bool(t[5]))
+
+
 def bamCount(bampath, gr, mapqual=0, shift=0, ss=False, paired_end=("ignore", "filter", "midpoint"),  # noqa: N802
              tlenFilter=None, filteredFlag=-1, verbose=True):  # noqa: N803
     """For each range, count the reads whose 5' end maps in it (R/wrappers.R:101-120).

@@ -217,6 +217,10 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
                               const bsig_columns *cols, int32_t level);
 /* drops the per-process cache of BAMs decoded to HBM by the file-level entry points           */
 void bsig_cache_clear(void);
+/* stage seconds of the calling thread's last bsig_pileup_core / bsig_coverage_core: open (header +
+ * BAI), decode, upload + HBM layout, plan + kernels + download, total; t6[5] = 1 if the BAM was
+ * already resident in HBM                                                                      */
+void bsig_last_call_timing(double *t6);
 
 /* ------------------------------------------------------------------------------------------
  * Reassembly of sharded results (multi-GPU): segment k of src (src_off[k] .. src_off[k+1]) is

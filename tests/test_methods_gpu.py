@@ -112,3 +112,6 @@ def test_errors(regions, tmp_path, capsys):
         bamProfile(str(tmp_path / "none.bam"), regions, verbose=False)
     bamCount(bampath, regions, verbose=True)
     assert "Processing " + bampath in capsys.readouterr().err                                    # R/wrappers.R:182-184
+    from bamsignals_amd.wrappers import last_call_timing
+    t = last_call_timing()
+    assert t["total"] > 0 and t["total"] >= t["plan_run_download"] > 0
