@@ -504,8 +504,11 @@ __device__ __forceinline__ int span_class(int span)
 constexpr int kPrepThreads = 256;
 constexpr int kPrepChunk = 2048;     // reads per workgroup in k_span_hist / k_scatter
 
-// per-chunk class counts + per-class max span
-__global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, const int32_t *__restrict__ pos,
+// per-chunk class counts + per-class max span; also checks that the reads are sorted by position
+// inside every reference (maxspan[BSIG_MAX_CLASSES] is set to 1 otherwise)
+__global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n_ref,
+                                                            const int64_t *__restrict__ ref_off,
+                                                            const int32_t *__restrict__ pos,
                                                             const int32_t *__restrict__ end,
                                                             uint32_t *__restrict__ chunk_counts,
                                                             int32_t *__restrict__ maxspan)
@@ -523,6 +526,15 @@ __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, const int
             const int c = span_class(span);
             atomicAdd(&cnt[c], 1u);
             atomicMax(&mx[c], span);
+            if (i > 0 && pos[i] < pos[i - 1]) {
+                // allowed only where a new reference starts: is i one of ref_off[1..n_ref-1]?
+                int lo = 0, hi = n_ref;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ref_off[mid] <= i) lo = mid; else hi = mid;
+                }
+                if (ref_off[lo] != i) maxspan[BSIG_MAX_CLASSES] = 1;
+            }
         }
     }
     __syncthreads();
@@ -712,12 +724,12 @@ hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag,
 
 int64_t prep_chunks(int64_t n) { return (n + kPrepChunk - 1) / kPrepChunk; }
 
-hipError_t launch_span_hist(int64_t n, const int32_t *pos, const int32_t *end, uint32_t *chunk_counts,
-                            int32_t *maxspan, hipStream_t st)
+hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, const int32_t *pos,
+                            const int32_t *end, uint32_t *chunk_counts, int32_t *maxspan, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_span_hist, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
-                       n, pos, end, chunk_counts, maxspan);
+                       n, n_ref, ref_off, pos, end, chunk_counts, maxspan);
     return hipGetLastError();
 }
 

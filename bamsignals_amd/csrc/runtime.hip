@@ -256,14 +256,19 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
     uint32_t *d_counts;
     int32_t *d_maxspan;
     HIP_TRY(tmp.alloc(&d_counts, n_chunks * BSIG_MAX_CLASSES));
-    HIP_TRY(tmp.alloc(&d_maxspan, BSIG_MAX_CLASSES));
-    HIP_TRY(hipMemsetAsync(d_maxspan, 0, BSIG_MAX_CLASSES * sizeof(int32_t), st));
-    HIP_TRY(bsig::launch_span_hist(n, d_pos, d_end, d_counts, d_maxspan, st));
+    HIP_TRY(tmp.alloc(&d_maxspan, BSIG_MAX_CLASSES + 1));
+    HIP_TRY(hipMemsetAsync(d_maxspan, 0, (BSIG_MAX_CLASSES + 1) * sizeof(int32_t), st));
+    int64_t *d_ref_off;
+    HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
+    HIP_TRY(hipMemcpyAsync(d_ref_off, cols->ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_pos, d_end, d_counts, d_maxspan, st));
     std::vector<uint32_t> counts(n_chunks * BSIG_MAX_CLASSES);
-    int32_t maxspan[BSIG_MAX_CLASSES];
+    int32_t maxspan[BSIG_MAX_CLASSES + 1];
     HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(maxspan, d_maxspan, sizeof maxspan, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (maxspan[BSIG_MAX_CLASSES])
+        return fail(BSIG_ERR_ARG, "reads must be sorted by position inside every reference (coordinate-sorted BAM order)");
     std::vector<uint64_t> base(n_chunks * BSIG_MAX_CLASSES);
     uint64_t class_n[BSIG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int64_t k = 0; k < n_chunks; ++k)
@@ -312,14 +317,11 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
         R->info.n_classes += 1;
     }
 
-    int64_t *d_ref_off;
     uint32_t *d_unit0, *d_units;
     uint64_t *d_base;
-    HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
     HIP_TRY(tmp.alloc(&d_unit0, n_ref));
     HIP_TRY(tmp.alloc(&d_units, n_ref));
     HIP_TRY(tmp.alloc(&d_base, base.size()));
-    HIP_TRY(hipMemcpyAsync(d_ref_off, cols->ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_unit0, R->ref_unit0.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_units, R->ref_units.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_base, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));

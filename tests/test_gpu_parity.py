@@ -270,10 +270,15 @@ def test_error_paths(ctx, synth):
     with pytest.raises(_lib.BsigError) as e:
         _gpu(ctx, gpu, dict(rg, rid=np.asarray([9], np.int32)), "pileup", binsize=1)
     assert e.value.code_name == "BSIG_ERR_CHROM"
-    from bamsignals_amd.device import Plan, make_params
+    from bamsignals_amd.device import Plan, Reads, make_params
     with pytest.raises(_lib.BsigError) as e:
         Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=0))
     assert "binsize greater or equal to 1" in str(e.value)
+    # unsorted columns are refused (a decrease is only allowed where the next reference starts)
+    ok = Reads(ctx, [100, 100], [0, 2, 4], [50, 60, 10, 20], [0] * 4, [9] * 4, [0] * 4, end=[55, 65, 15, 25])
+    ok.close()
+    with pytest.raises(_lib.BsigError, match="sorted"):
+        Reads(ctx, [100, 100], [0, 2, 4], [60, 50, 10, 20], [0] * 4, [9] * 4, [0] * 4, end=[65, 55, 15, 25])
 
 
 def test_fuzz_small_inputs(ctx):
