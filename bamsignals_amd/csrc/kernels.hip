@@ -335,6 +335,58 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
 #endif
 }
 
+// Wide bins (binsize >~ 64): a tile has few cells and thousands of reads, and the position-sorted
+// reads of one wave instruction fall into one or two bins, so plain LDS atomics serialise on a
+// bank.  Here every lane pair adds into its own replica of the tile image (32 replicas, odd stride:
+// the same cell of different replicas lies in different banks); the replicas are summed at the end.
+constexpr int kSmallCells = 256;     // at most this many values (cells * S) per tile
+constexpr int kReplicas = 32;
+template <int NT, bool SS>
+__global__ __launch_bounds__(NT) void k_profile_small(const BsigReadsDev R, const BsigKParams P,
+                                                      const BsigWorkItem *__restrict__ items,
+                                                      const uint2 *__restrict__ windows,
+                                                      int32_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    constexpr int S = SS ? 2 : 1;
+    const int tid = threadIdx.x;
+    const uint32_t tile = tile_of_block(blockIdx.x, gridDim.x);
+    const BsigWorkItem w = items[tile];
+    uint2 win[BSIG_MAX_CLASSES];
+    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile);
+    const int stride = (P.tile_cells * S) | 1;                 // odd: replicas shift by one bank
+    for (int v = tid; v < kReplicas * stride; v += NT) lds[v] = 0;
+    block_sync<NT>();
+    const bool neg_range = (w.units_strand >> 30) & 1u;
+    int32_t *mine = lds + (tid & (kReplicas - 1)) * stride;
+
+    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
+        if (!valid || read_rejected(P, fm, tl)) return;
+        const bool neg = (fm & 0x10u) != 0u;
+        const int a = tl < 0 ? -tl : tl;
+        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
+        const int p5 = neg ? e - offset : p + offset;
+        int rel = p5 - w.loc;
+        if ((unsigned)rel >= (unsigned)w.len) return;
+        int anti = neg ? 1 : 0;
+        if (neg_range) { rel = w.len - rel - 1; anti ^= 1; }
+        const int cell = P.binsize == 1 ? rel
+                                        : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
+        const int lc = cell - w.c0;
+        if ((unsigned)lc < (unsigned)w.nc) atomicAdd(&mine[lc * S + (SS ? anti : 0)], 1);
+    };
+    for_each_read<NT>(R, P, win, tid, one);
+    block_sync<NT>();
+
+    const int nv = w.nc * S;
+    for (int v = tid; v < nv; v += NT) {
+        int acc = 0;
+#pragma unroll 8
+        for (int r = 0; r < kReplicas; ++r) acc += lds[r * stride + v];
+        out[w.out_off + v] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // bamCount: one (or two, strand-specific) counters per range
 // ------------------------------------------------------------------------------------------
@@ -688,7 +740,11 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
                            R, P, mode, items, n_items, windows);
     const dim3 grid((unsigned)n_items), block(NT);
-    if (mode == BSIG_MODE_PROFILE) {
+    if (mode == BSIG_MODE_PROFILE && tile_cells * (ss ? 2 : 1) <= kSmallCells && P.binsize > 1) {
+        const size_t lds = (size_t)kReplicas * ((tile_cells * (ss ? 2 : 1)) | 1) * sizeof(int32_t);
+        if (ss) hipLaunchKernelGGL((k_profile_small<NT, true>), grid, block, lds, st, R, P, items, windows, out);
+        else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, R, P, items, windows, out);
+    } else if (mode == BSIG_MODE_PROFILE) {
         const size_t lds = (size_t)(tile_cells * (ss ? 2 : 1) + 8) * sizeof(int32_t);
         if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, R, P, items, windows, out);
         else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, R, P, items, windows, out);

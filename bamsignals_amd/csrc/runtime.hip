@@ -95,7 +95,9 @@ struct bsig_reads {
 struct bsig_plan {
     bsig_ctx *ctx = nullptr;
     const bsig_reads *reads = nullptr;
-    int mode = 0;
+    int mode = 0;                  // what the caller asked for (fixes the result layout)
+    int kernel_mode = 0;           // which kernel family runs: profile with very wide bins is
+                                   // executed as a bamCount over the bins' sub-intervals
     BsigKParams kp{};
     int tile_cells = 0, threads = 0;
     int64_t n_ranges = 0, n_items = 0;
@@ -415,8 +417,16 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
             widest = std::max<int64_t>(widest, ((int64_t)len[i] + bsz - 1) / bsz);
     }
     P->tile_cells = prm->tile_cells > 0 ? prm->tile_cells : (int)std::min<int64_t>(widest, 2048);
+    int min_cells = 64;
+    if (mode == BSIG_MODE_PROFILE && prm->binsize > 1 && prm->tile_cells <= 0) {
+        // wide bins: a tile of 2048 cells would span megabases and one wave would stream all of
+        // its reads; keep a tile to about 16 kbp so that genome-wide binning still fills the chip
+        const int64_t by_span = std::max<int64_t>(4, (16384 + prm->binsize - 1) / prm->binsize);
+        P->tile_cells = (int)std::min<int64_t>(P->tile_cells, by_span);
+        min_cells = 4;
+    }
     // a tile image is at most 32 KiB of LDS
-    P->tile_cells = std::min(std::max(P->tile_cells, 64), prm->ss && mode == BSIG_MODE_PROFILE ? 4096 : 8192);
+    P->tile_cells = std::min(std::max(P->tile_cells, min_cells), prm->ss && mode == BSIG_MODE_PROFILE ? 4096 : 8192);
     P->tile_cells = (P->tile_cells + 3) & ~3;
     P->threads = prm->threads > 0 ? prm->threads : 64;
     if (P->threads != 64 && P->threads != 128 && P->threads != 256) {
@@ -454,6 +464,10 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     items.reserve(n);
     const int64_t mult = K.ss ? 2 : 1;
     const int count_split = 1 << 15;      // count mode: bases per workgroup
+    // bins wider than a workgroup should stream on its own: every bin becomes bamCount-style
+    // sub-intervals that add into the (zeroed) result with integer atomics
+    const bool wide_bins = mode == BSIG_MODE_PROFILE && prm->tile_cells <= 0 && K.binsize > count_split / 2;
+    P->kernel_mode = wide_bins ? BSIG_MODE_COUNT : mode;
     for (int64_t k = 0; k < n; ++k) {
         const int64_t i = order[k];
         if (len[i] <= 0) continue;
@@ -461,7 +475,21 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
         w.loc = loc[i]; w.len = len[i];
         w.ref_unit0 = reads->ref_unit0[rid[i]];
         w.units_strand = reads->ref_units[rid[i]] | (strand[i] < 0 ? (1u << 30) : 0u);
-        if (mode == BSIG_MODE_COUNT) {
+        if (wide_bins) {
+            const int64_t cells = (P->off[i + 1] - P->off[i]) / mult;
+            for (int64_t c = 0; c < cells; ++c) {
+                // cell c covers [c*bs, (c+1)*bs) in range orientation (ref: src/bamsignals.cpp:356-362)
+                const int64_t ra = c * (int64_t)K.binsize, rb = std::min<int64_t>(len[i], ra + K.binsize);
+                const int64_t g0 = strand[i] < 0 ? len[i] - rb : ra, g1 = strand[i] < 0 ? len[i] - ra : rb;
+                for (int64_t a = g0; a < g1; a += count_split) {
+                    w.c0 = (int32_t)a;
+                    w.nc = (int32_t)std::min<int64_t>(count_split, g1 - a);
+                    w.out_off = P->off[i] + c * mult;
+                    w.units_strand |= 1u << 31;
+                    items.push_back(w);
+                }
+            }
+        } else if (mode == BSIG_MODE_COUNT) {
             const bool split = len[i] > count_split;
             for (int64_t a = 0; a < len[i]; a += count_split) {
                 w.c0 = (int32_t)a;
@@ -512,9 +540,9 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (!out_dev) return fail(BSIG_ERR_ARG, "output buffer is NULL");
     if (((uintptr_t)out_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device output buffer must be 16-byte aligned");
     hipStream_t st = p->ctx->stream;
-    if (p->mode == BSIG_MODE_COUNT)
+    if (p->kernel_mode == BSIG_MODE_COUNT)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
-    HIP_TRY(bsig::launch_pileup(p->mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
+    HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
                                 p->tile_cells, p->windows, out_dev, st));
     return BSIG_OK;
 }
@@ -547,7 +575,7 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         HIP_TRY(hipSetDevice(p->ctx->device));
         HIP_TRY(hipMalloc((void **)&d_acc, sizeof acc));
         hipError_t e = hipMemsetAsync(d_acc, 0, sizeof acc, st);
-        if (e == hipSuccess) e = bsig::launch_visits(p->reads->dev, p->kp, p->mode, p->items, p->n_items, d_acc, st);
+        if (e == hipSuccess) e = bsig::launch_visits(p->reads->dev, p->kp, p->kernel_mode, p->items, p->n_items, d_acc, st);
         if (e == hipSuccess) e = hipMemcpyAsync(acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         (void)hipFree(d_acc);

@@ -43,6 +43,8 @@ def main():
         cases.append(("count on the same tiling", reads, tiles, make_params(_lib.MODE_COUNT, binsize=-1)))
         one = dict(rid=np.zeros(1, np.int32), loc=np.zeros(1, np.int32), len=np.asarray([L], np.int32), strand=np.zeros(1, np.int32))
         cases.append(("coverage of ONE whole-chromosome range (tiled internally)", reads, one, make_params(_lib.MODE_COVERAGE)))
+        cases.append(("genome-wide 1-kb bins: ONE chr1 range, binsize=1000", reads, one, make_params(_lib.MODE_PROFILE, binsize=1000)))
+        cases.append(("genome-wide 100-kb bins: ONE chr1 range, binsize=100000", reads, one, make_params(_lib.MODE_PROFILE, binsize=100000)))
         for name, rd, rg, prm in cases:
             plan = Plan(ctx, rd, rg["rid"], rg["loc"], rg["len"], rg["strand"], prm)
             out = torch.empty(max(plan.cells, 4), dtype=torch.int32, device="cuda")
