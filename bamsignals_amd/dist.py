@@ -60,3 +60,58 @@ def gather_signals(local_out, ranges, binsize, ss, dst=0, group=None):
         _lib.check(lib.bsig_scatter_segments(len(which), src.ctypes.data, loff.ctypes.data, out.ctypes.data,
                                              off.ctypes.data, which.ctypes.data))
     return out, off
+
+
+def _sharded(kind, bampath, gr, dst, group, **kw):
+    """Run one of the user-level calls on this rank's shard of ``gr`` and gather on ``dst``."""
+    import torch
+    import torch.distributed as dist
+
+    from . import wrappers
+    from .countsignals import CountSignals
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    levels, codes, start, width, strand = gr.flatten()
+    ranges = dict(rid=codes, loc=start - 1, len=width)          # any consistent (seq, start) order works
+    mine = shard_indices(ranges["rid"], ranges["loc"], rank, world)
+    sub = gr[mine]
+    ss = bool(kw.get("ss", False))
+    if kind == "count":
+        res = wrappers.bamCount(bampath, sub, verbose=False, **kw)
+        local = (res.T.reshape(-1) if ss else res).astype(np.int32, copy=False)
+        binsize = -1
+    else:
+        fn = wrappers.bamProfile if kind == "profile" else wrappers.bamCoverage
+        sig = fn(bampath, sub, verbose=False, **kw)
+        parts = [(m.T.reshape(-1) if ss else m) for m in sig.as_list()]
+        local = np.concatenate(parts).astype(np.int32, copy=False) if parts else np.zeros(0, np.int32)
+        binsize = int(kw.get("binsize", 1)) if kind == "profile" else 1
+    backend = dist.get_backend(group)
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    if backend == "nccl":
+        t = t.cuda()
+    out, off = gather_signals(t, ranges, binsize, ss and kind != "coverage", dst=dst, group=group)
+    if rank != dst:
+        return None
+    if kind == "count":
+        return out.reshape(-1, 2).T if ss else out
+    sigs = [out[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    if ss and kind == "profile":
+        sigs = [v.reshape(-1, 2).T for v in sigs]
+    return CountSignals(sigs, ss and kind == "profile")
+
+
+def bamProfile_sharded(bampath, gr, dst=0, group=None, **kw):  # noqa: N802
+    """``bamProfile`` over all ranks of the process group (one process per GPU): ranges dealt
+    round-robin, every rank reads the BAM, results gathered to ``dst`` (a CountSignals there,
+    ``None`` elsewhere).  Keyword arguments as ``bamProfile`` (without ``verbose``)."""
+    return _sharded("profile", bampath, gr, dst, group, **kw)
+
+
+def bamCount_sharded(bampath, gr, dst=0, group=None, **kw):  # noqa: N802
+    return _sharded("count", bampath, gr, dst, group, **kw)
+
+
+def bamCoverage_sharded(bampath, gr, dst=0, group=None, **kw):  # noqa: N802
+    return _sharded("coverage", bampath, gr, dst, group, **kw)
