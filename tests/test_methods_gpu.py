@@ -115,3 +115,42 @@ def test_errors(regions, tmp_path, capsys):
     from bamsignals_amd.wrappers import last_call_timing
     t = last_call_timing()
     assert t["total"] > 0 and t["total"] >= t["plan_run_download"] > 0
+
+
+def test_file_level_on_synthetic_bam_with_gapped_cigars(tmp_path):
+    """BAM written by our writer (D/N/S/I CIGARs, three references, 0x400 duplicates) -> the user
+    API end to end (decode, CIGAR->end on the GPU, span classes, kernels) vs the C oracle on the
+    generator's columns; both decode modes."""
+    from bamsignals_amd import GRanges, _lib, bamCount, bamCoverage, bamProfile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from oracle import oracle_c
+    names = ["chrA", "chrB", "chrC"]
+    cols = synth_reads(300_000, [900_000, 70_000, 400_000], seed=21, paired=True)
+    bam = str(tmp_path / "syn.bam")
+    write_columns_as_bam(bam, names, cols)
+    rg = synth_ranges(400, 1500, cols["ref_len"], seed=5, jitter=700)
+    gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"],
+                 strand=[{1: "+", -1: "-", 0: "*"}[int(s)] for s in rg["strand"]])
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    old = os.environ.get("BAMSIGNALS_DECODE")
+    try:
+        for mode in ("regions", "all"):
+            os.environ["BAMSIGNALS_DECODE"] = mode
+            _lib.load().bsig_cache_clear()
+            sig = bamProfile(bam, gr, binsize=1, ss=True, shift=30, paired_end="midpoint", tlenFilter=(60, 400),
+                             mapqual=10, verbose=False)
+            want, _ = oracle_c.pileup_core(orc, rg, binsize=1, ss=True, shift=30, pe_mid=True, tlen_filter=(60, 400),
+                                           requiredF=66, mapqual=10)
+            assert np.array_equal(np.concatenate([m.T.reshape(-1) for m in sig]), want), mode
+            cov = bamCoverage(bam, gr, paired_end="extend", filteredFlag=1024, verbose=False)
+            want, _ = oracle_c.coverage_core(orc, rg, tspan=True, tlen_filter=(0, 1000), requiredF=66, filteredF=1024)
+            assert np.array_equal(np.concatenate(cov.as_list()), want), mode
+            cnt = bamCount(bam, gr, shift=-25, verbose=False)
+            want, _ = oracle_c.pileup_core(orc, rg, binsize=-1, shift=-25)
+            assert np.array_equal(cnt, want), mode
+    finally:
+        if old is None:
+            os.environ.pop("BAMSIGNALS_DECODE", None)
+        else:
+            os.environ["BAMSIGNALS_DECODE"] = old
+        _lib.load().bsig_cache_clear()
