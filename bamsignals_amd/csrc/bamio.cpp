@@ -959,74 +959,83 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
         else merged.push_back(c);
     }
 
-    // Every merged chunk becomes a job: its BGZF blocks are inflated (all jobs of a group in one
-    // parallel pass, <= 256 MiB of output per group), then its records are parsed in file order.
+    // Every merged chunk is an independent job (it starts at a record boundary the index vouches
+    // for): a worker inflates its blocks, parses its records into job-local columns, and the jobs
+    // are concatenated in file order afterwards.
     struct Job {
-        uint64_t ub = 0, limit = 0, next_off = 0;
-        std::vector<Block> bl;
-        std::vector<uint64_t> boff;
-        std::vector<uint8_t> buf;
+        HostColumns c;
+        int err = 0;
+        std::string msg;
     };
-    BamParser parser(hdr, cols, false);
-    Inflater inf1;
-    size_t ci = 0;
-    while (ci < merged.size()) {
-        std::vector<Job> jobs;
-        uint64_t group_bytes = 0;
-        for (; ci < merged.size() && (jobs.empty() || group_bytes < (256ull << 20)); ++ci) {
-            const BaiChunk &c = merged[ci];
-            const uint64_t cb = c.beg >> 16, ce = c.end >> 16, ue = c.end & 0xFFFF;
-            Job j;
-            j.ub = c.beg & 0xFFFF;
-            uint64_t off = cb, total = 0;
-            bool end_seen = false;
-            while (off < f.size && (off < ce || (off == ce && ue > 0))) {
-                Block b;
-                if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "BAI points at a malformed BGZF block in %s", path.c_str());
-                if (b.coff == ce) { j.limit = total + ue; end_seen = true; }
-                j.boff.push_back(total);
-                j.bl.push_back(b);
-                total += b.isize;
-                off += b.csize;
+    std::vector<Job> jobs(merged.size());
+    const BamHeader &H = hdr;
+    parallel_for((int64_t)merged.size(), threads, [&](int64_t ji, int) {
+        static thread_local Inflater inf;
+        Job &J = jobs[(size_t)ji];
+        const BaiChunk &c = merged[(size_t)ji];
+        const uint64_t cb = c.beg >> 16, ub = c.beg & 0xFFFF, ce = c.end >> 16, ue = c.end & 0xFFFF;
+        BamHeader h = H;                       // the parser only reads names.size()
+        BamParser parser(h, J.c, false);
+        std::vector<uint8_t> buf;
+        uint64_t off = cb, upos = 0;           // upos: stream position (relative to block cb) of buf's start
+        bool first = true;
+        auto bail = [&](int code) { J.err = code; J.msg = g_last_error; };
+        // chunk end as a stream position: known once block ce has been reached
+        uint64_t limit = ~0ull;
+        if (ce == cb) limit = ue;
+        parser.set_position(ub);
+        parser.set_limit(limit);
+        while (off < f.size) {
+            if (limit != ~0ull && upos >= limit && !parser.pending()) break;
+            Block b;
+            if (!parse_block(f, off, b)) { bail(fail(BSIG_ERR_FORMAT, "BAI points at a malformed BGZF block in %s", path.c_str())); return; }
+            if (b.coff == ce && limit == ~0ull) { limit = upos + ue; parser.set_limit(limit); }
+            if (limit != ~0ull && upos >= limit && !parser.pending()) break;
+            buf.resize(b.isize);
+            if (!inf.run(f.data + b.coff + b.doff, b.dlen, buf.data(), b.isize)) { bail(fail(BSIG_ERR_FORMAT, "BGZF inflate failed")); return; }
+            size_t skip = 0;
+            if (first) {
+                if (ub > buf.size()) { bail(fail(BSIG_ERR_FORMAT, "BAI offset beyond its BGZF block in %s", path.c_str())); return; }
+                skip = (size_t)ub;
+                first = false;
             }
-            if (j.bl.empty()) continue;
-            if (!end_seen) j.limit = total + ue;      // chunk ends at the start of block ce (ue == 0) or at EOF
-            j.next_off = off;
-            j.buf.resize(total);
-            group_bytes += total;
-            jobs.push_back(std::move(j));
+            const int rc2 = parser.feed(buf.data() + skip, buf.size() - skip);
+            if (rc2) { bail(rc2); return; }
+            upos += b.isize;
+            off += b.csize;
+            if (parser.reached_limit()) break;
         }
-        std::vector<std::pair<uint32_t, uint32_t>> work;
-        for (size_t a = 0; a < jobs.size(); ++a)
-            for (size_t b = 0; b < jobs[a].bl.size(); ++b) work.emplace_back((uint32_t)a, (uint32_t)b);
-        std::atomic<int> bad(0);
-        parallel_for((int64_t)work.size(), threads, [&](int64_t w, int) {
-            static thread_local Inflater inf;
-            Job &j = jobs[work[(size_t)w].first];
-            const Block &b = j.bl[work[(size_t)w].second];
-            if (!inf.run(f.data + b.coff + b.doff, b.dlen, j.buf.data() + j.boff[work[(size_t)w].second], b.isize)) bad = 1;
-        });
-        if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
-        for (Job &j : jobs) {
-            if (j.ub > j.buf.size()) return fail(BSIG_ERR_FORMAT, "BAI offset beyond its BGZF block in %s", path.c_str());
-            parser.set_position(j.ub);
-            parser.set_limit(j.limit);
-            rc = parser.feed(j.buf.data() + j.ub, j.buf.size() - j.ub);
-            if (rc) return rc;
-            // a record that starts before the chunk end may continue in the following blocks
-            uint64_t off = j.next_off;
-            while (parser.pending() && !parser.reached_limit() && off < f.size) {
-                Block b;
-                if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block in %s", path.c_str());
-                std::vector<uint8_t> more(b.isize);
-                if (!inf1.run(f.data + b.coff + b.doff, b.dlen, more.data(), b.isize)) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
-                rc = parser.feed(more.data(), more.size());
-                if (rc) return rc;
-                off += b.csize;
-            }
-        }
+    });
+    for (Job &J : jobs)
+        if (J.err) return fail(J.err, "%s", J.msg.c_str());
+
+    // concatenate in file order
+    std::vector<int64_t> rec0(jobs.size() + 1, 0), cig0(jobs.size() + 1, 0);
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        rec0[k + 1] = rec0[k] + jobs[k].c.size();
+        cig0[k + 1] = cig0[k] + (int64_t)jobs[k].c.cigar.size();
+        cols.n_unplaced += jobs[k].c.n_unplaced;
+        while (cols.ref_off.size() < jobs[k].c.ref_off.size())
+            cols.ref_off.push_back(rec0[k] + jobs[k].c.ref_off[cols.ref_off.size()]);
     }
-    parser.finish_refs();
+    const size_t m = (size_t)rec0.back();
+    cols.pos.resize(m); cols.tlen.resize(m); cols.flag.resize(m); cols.mapq.resize(m);
+    cols.cigar_off.resize(m + 1);
+    cols.cigar.resize((size_t)cig0.back());
+    cols.cigar_off[0] = 0;
+    parallel_for((int64_t)jobs.size(), threads, [&](int64_t k, int) {
+        const HostColumns &c = jobs[(size_t)k].c;
+        const size_t n = (size_t)c.size(), r0 = (size_t)rec0[(size_t)k];
+        if (!n) return;
+        memcpy(cols.pos.data() + r0, c.pos.data(), n * sizeof(int32_t));
+        memcpy(cols.tlen.data() + r0, c.tlen.data(), n * sizeof(int32_t));
+        memcpy(cols.flag.data() + r0, c.flag.data(), n * sizeof(uint16_t));
+        memcpy(cols.mapq.data() + r0, c.mapq.data(), n);
+        memcpy(cols.cigar.data() + cig0[(size_t)k], c.cigar.data(), c.cigar.size() * sizeof(uint32_t));
+        for (size_t i = 0; i < n; ++i) cols.cigar_off[r0 + i + 1] = cig0[(size_t)k] + c.cigar_off[i + 1];
+    });
+    const int n_ref = (int)hdr.names.size();
+    while ((int)cols.ref_off.size() < n_ref + 1) cols.ref_off.push_back(cols.size());
     return 0;
 }
 
