@@ -260,7 +260,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_resolve + k_profile (one step)" if a.resolve else "k_profile", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes": stats["algorithmic_bytes"], "visits": stats["visits"],
+                         "algorithmic_bytes": stats["algorithmic_bytes"],
+                         # SURVEY 8(d)'s layout-agnostic figure 15*V + 16*I + 4*S*C for the same launch
+                         # (not used for `achieved`: the packed HBM layout moves fewer bytes per visit)
+                         "algorithmic_bytes_survey_formula": 15 * stats["visits"] + 16 * stats["n_ranges"]
+                         + 4 * stats["cells"],
+                         "visits": stats["visits"],
                          "streamed_reads": stats["streamed"], "visits_short": stats["visits_short"],
                          "bytes_per_visit_short": stats["bytes_per_visit_short"],
                          "bytes_per_visit_long": stats["bytes_per_visit_long"],
