@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise "
                          "the multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the collectives even with one rank (exercises RCCL "
+                         "on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0xBA51)
     a = ap.parse_args()
@@ -79,8 +82,17 @@ def main():
     local = local % ngpu
     torch.cuda.set_device(local)
     cdev = "cuda" if a.backend == "nccl" else "cpu"      # where collective payloads live
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist and os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        # RCCL prints its version banner to STDOUT at communicator creation; this program's stdout is
+        # one JSON line
+        os.environ["NCCL_DEBUG"] = "WARN"
+    if use_dist:
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # RCCL's own messages: not on stdout
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -129,7 +141,7 @@ def main():
         bases = step_bases[0]
 
         def barrier():
-            if world > 1:
+            if use_dist:
                 dist.barrier()
 
         for b in range(nb):                      # every result buffer is produced at least once
@@ -155,7 +167,7 @@ def main():
         kernel_ms = e0.elapsed_time(e1) / a.steps
 
         # whole-job time = max over ranks
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -209,7 +221,7 @@ def main():
 
         # ---- final reassembly on rank 0 over RCCL (outside the timed region) -------------------
         gather = None
-        if world > 1:
+        if use_dist:
             shard = out[:plan.cells].to(cdev)
             bufs = [torch.empty_like(shard) for _ in range(world)] if rank == 0 else None
             torch.cuda.synchronize(); dist.barrier()
@@ -225,7 +237,8 @@ def main():
                 if not ok:
                     raise SystemExit("gathered shards do not match the per-rank checksums")
                 gather = dict(ms=t_g * 1e3, bytes=int(shard.numel() * 4 * (world - 1)),
-                              GBps=shard.numel() * 4 * (world - 1) / t_g / 1e9, checked=True, backend=a.backend)
+                              GBps=shard.numel() * 4 * (world - 1) / t_g / 1e9, checked=True, backend=a.backend,
+                              ranks=world)
 
     # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
     # (profiles/<tag>_pmc.json, made by scripts/profile_round.sh + scripts/summarize_profile.py);
@@ -276,10 +289,15 @@ def main():
             "setup_s": {"generate": t_gen, "upload_and_layout": t_upload, "plan": t_plan},
             "reads_in_hbm": reads.info(),
         }
-        print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # anything native code left in C stdio buffers goes out first: the JSON line is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
