@@ -105,6 +105,7 @@ struct bsig_plan {
     DevPool pool;
     BsigWorkItem *items = nullptr;
     void *windows = nullptr;       // [n_items][BSIG_MAX_CLASSES] read windows, rewritten by every run
+    int32_t *d_out = nullptr;      // device result buffer of bsig_plan_run_host, kept between calls
     bool have_stats = false;
     bsig_plan_stats stats{};
 };
@@ -554,15 +555,13 @@ int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
     if (cells == 0) return BSIG_OK;
     if (!out_host) return fail(BSIG_ERR_ARG, "output buffer is NULL");
     HIP_TRY(hipSetDevice(p->ctx->device));
-    int32_t *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, cells * sizeof(int32_t)));
-    int rc = bsig_plan_run(p, d_out);
+    if (!p->d_out) HIP_TRY(p->pool.alloc(&p->d_out, (size_t)cells));
+    int rc = bsig_plan_run(p, p->d_out);
     if (rc == BSIG_OK) {
-        hipError_t e = hipMemcpyAsync(out_host, d_out, cells * sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream);
+        hipError_t e = hipMemcpyAsync(out_host, p->d_out, cells * sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
         if (e != hipSuccess) rc = fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d_out);
     return rc;
 }
 
