@@ -172,54 +172,78 @@ __global__ void k_resolve(const BsigReadsDev R, const BsigKParams P, int mode,
 }
 
 // Stream the reads of all span-class windows of one tile through `one(pos, end, fm, tlen, valid)`.
-// The first 16-B vector of the two short classes (where nearly all reads live) is requested
-// before anything is consumed, so the workgroup pays one memory round trip for both; longer
-// windows and the two long-span classes continue in plain loops.
+// Everything a typical tile needs is requested before anything is consumed, so the workgroup pays
+// ONE memory round trip for its reads: the first kPre0 passes (kPre0 * 4 * NT reads) of class 0,
+// where nearly all reads live, and the first pass of class 1.  Longer windows and the two
+// long-span classes continue in plain loops.
 template <int NT, typename F>
 __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
                                               const uint2 (&win)[BSIG_MAX_CLASSES], int tid, F &&one)
 {
-    constexpr int kPre = 2;      // classes whose first vector is prefetched
-    int4 p4[kPre], e4[kPre], t4[kPre];
-    uint4 f4[kPre];
+    constexpr int kPre0 = 4;
+    int4 p0[kPre0], t0[kPre0], p1, e1, t1 = make_int4(0, 0, 0, 0);
+    uint4 f0[kPre0], f1;
+    const uint32_t jb0 = (win[0].x & ~3u) + 4u * tid;
 #pragma unroll
-    for (int c = 0; c < kPre; ++c) {
-        const BsigClassCols &C = R.cls[c];
-        const uint32_t j = (win[c].x & ~3u) + 4u * tid;
-        t4[c] = make_int4(0, 0, 0, 0);
-        if (j < win[c].y) {
-            p4[c] = *reinterpret_cast<const int4 *>(C.pos + j);
-            f4[c] = *reinterpret_cast<const uint4 *>(C.fm + j);
-            if (c != 0) e4[c] = *reinterpret_cast<const int4 *>(C.end + j);
-            if (P.use_tlen) t4[c] = *reinterpret_cast<const int4 *>(C.tlen + j);
+    for (int k = 0; k < kPre0; ++k) {
+        const uint32_t j = jb0 + 4u * NT * k;
+        t0[k] = make_int4(0, 0, 0, 0);
+        if (j < win[0].y) {
+            p0[k] = *reinterpret_cast<const int4 *>(R.cls[0].pos + j);
+            f0[k] = *reinterpret_cast<const uint4 *>(R.cls[0].fm + j);
+            if (P.use_tlen) t0[k] = *reinterpret_cast<const int4 *>(R.cls[0].tlen + j);
         }
     }
-    // class 0 (span <= 256) has no end column: end = pos + (fm >> 24)
-    e4[0] = make_int4(p4[0].x + (int)(f4[0].x >> 24), p4[0].y + (int)(f4[0].y >> 24),
-                      p4[0].z + (int)(f4[0].z >> 24), p4[0].w + (int)(f4[0].w >> 24));
+    const uint32_t jb1 = (win[1].x & ~3u) + 4u * tid;
+    if (jb1 < win[1].y) {
+        p1 = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
+        f1 = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
+        e1 = *reinterpret_cast<const int4 *>(R.cls[1].end + jb1);
+        if (P.use_tlen) t1 = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
+    }
+    // The 16-B aligned loads may start before j_lo (possibly on the previous reference) and end
+    // after j_hi: only reads in [j_lo, j_hi) count -> `dj < nj` with unsigned wrap-around.
+    {   // ---- class 0 (span <= 256): no end column, end = pos + (fm >> 24) ------------------------
+        const BsigClassCols &C = R.cls[0];
+        const uint32_t j_lo = win[0].x, j_hi = win[0].y, nj = j_hi - j_lo;
+        auto four = [&](const int4 &p, const uint4 &f, const int4 &t, uint32_t j) {
+            const uint32_t dj = j - j_lo;
+            one(p.x, p.x + (int)(f.x >> 24), f.x, t.x, dj < nj);
+            one(p.y, p.y + (int)(f.y >> 24), f.y, t.y, dj + 1u < nj);
+            one(p.z, p.z + (int)(f.z >> 24), f.z, t.z, dj + 2u < nj);
+            one(p.w, p.w + (int)(f.w >> 24), f.w, t.w, dj + 3u < nj);
+        };
 #pragma unroll
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        for (int k = 0; k < kPre0; ++k) {
+            const uint32_t j = jb0 + 4u * NT * k;
+            if (j < j_hi) four(p0[k], f0[k], t0[k], j);
+        }
+        for (uint32_t j = jb0 + 4u * NT * kPre0; j < j_hi; j += 4u * NT) {
+            const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
+            const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
+            four(p, f, t, j);
+        }
+    }
+#pragma unroll
+    for (int c = 1; c < BSIG_MAX_CLASSES; ++c) {   // ---- classes 1-3: pos, end, fm columns ---------
         const BsigClassCols &C = R.cls[c];
-        const uint32_t j_lo = win[c].x, j_hi = win[c].y;
-        // the 16-B aligned loads may start before j_lo (possibly on the previous reference) and
-        // end after j_hi: only reads in [j_lo, j_hi) count
-        const uint32_t nj = j_hi - j_lo;
+        const uint32_t j_lo = win[c].x, j_hi = win[c].y, nj = j_hi - j_lo;
         uint32_t j = (j_lo & ~3u) + 4u * tid;
-        if (c < kPre) {
+        if (c == 1) {
             if (j >= j_hi) continue;
             const uint32_t dj = j - j_lo;
-            one(p4[c].x, e4[c].x, f4[c].x, t4[c].x, dj < nj);
-            one(p4[c].y, e4[c].y, f4[c].y, t4[c].y, dj + 1u < nj);
-            one(p4[c].z, e4[c].z, f4[c].z, t4[c].z, dj + 2u < nj);
-            one(p4[c].w, e4[c].w, f4[c].w, t4[c].w, dj + 3u < nj);
+            one(p1.x, e1.x, f1.x, t1.x, dj < nj);
+            one(p1.y, e1.y, f1.y, t1.y, dj + 1u < nj);
+            one(p1.z, e1.z, f1.z, t1.z, dj + 2u < nj);
+            one(p1.w, e1.w, f1.w, t1.w, dj + 3u < nj);
             j += 4u * NT;
         }
         for (; j < j_hi; j += 4u * NT) {
             const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
             const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
-            int4 e;
-            if (c != 0) e = *reinterpret_cast<const int4 *>(C.end + j);
-            else e = make_int4(p.x + (int)(f.x >> 24), p.y + (int)(f.y >> 24), p.z + (int)(f.z >> 24), p.w + (int)(f.w >> 24));
+            const int4 e = *reinterpret_cast<const int4 *>(C.end + j);
             int4 t = make_int4(0, 0, 0, 0);
             if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
             const uint32_t dj = j - j_lo;
