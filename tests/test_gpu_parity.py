@@ -325,3 +325,21 @@ def test_fuzz_small_inputs(ctx):
                         threads=int(rng.choice([0, 64, 128, 256])), resolve=int(rng.integers(0, 2)), **dict(cov))
         assert np.array_equal(off, woff) and np.array_equal(got, want), (case, cov)
         gpu.close()
+
+
+def test_very_wide_bins(ctx, synth):
+    """binsize > 16384: bins are executed as bamCount sub-intervals with global atomics; strand
+    mirror, partial last bin, strand-split and paired-end midpoint must survive that path."""
+    from oracle import oracle_c
+    rng = np.random.default_rng(77)
+    for which, extra in (("se", dict()), ("pe", dict(requiredF=66, tlen_filter=(0, 800), pe_mid=True))):
+        gpu, orc, cols, _ = synth[which]
+        m = 30
+        rid = rng.integers(0, len(cols["ref_len"]), m).astype(np.int32)
+        rg = dict(rid=rid, loc=(rng.random(m) * cols["ref_len"][rid] * 0.5).astype(np.int32) - 100,
+                  len=rng.integers(1, 400_000, m).astype(np.int32), strand=rng.integers(-1, 2, m).astype(np.int32))
+        for bs, ss, shift in ((16385, True, 0), (50_000, False, -40), (50_000, True, 120), (1_000_000, True, 7)):
+            a = dict(binsize=bs, ss=ss, shift=shift, **extra)
+            want, woff = oracle_c.pileup_core(orc, rg, **a)
+            got, off = _gpu(ctx, gpu, rg, "pileup", **dict(a))
+            assert np.array_equal(off, woff) and np.array_equal(got, want), (which, a)
