@@ -19,16 +19,18 @@ def _check_list(signals, ss):
 
 
 class CountSignals:
-    def __init__(self, signals, ss):
+    def __init__(self, signals, ss, _trusted=False):
         if not isinstance(ss, (bool, np.bool_)):
             raise ValueError("invalid ss slot")                      # R/zzzCountSignals.R:36
         signals = list(signals)
-        if not _check_list(signals, bool(ss)):
+        # _trusted: lists produced by the native call itself (views of one read-only int32 buffer)
+        if not _trusted and not _check_list(signals, bool(ss)):
             raise ValueError("invalid list")                         # R/zzzCountSignals.R:38
         self._signals = signals
         self.ss = bool(ss)
-        for s in self._signals:
-            s.setflags(write=False)
+        if not _trusted:
+            for s in self._signals:
+                s.setflags(write=False)
 
     def __len__(self):                                               # length(), :46
         return len(self._signals)

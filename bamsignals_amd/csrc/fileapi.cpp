@@ -59,11 +59,17 @@ struct Cache {
     int device = -1;
     bsig_ctx *ctx = nullptr;
     bsig_reads *reads = nullptr;
+    // the last opened BAM (header + parsed BAI), so that repeated calls do not re-read the index
+    std::string bam_key;
+    bsig_bam *bam = nullptr;
     void clear()
     {
         if (reads) bsig_reads_free(reads);
         reads = nullptr;
         key.clear();
+        if (bam) bsig_bam_close(bam);
+        bam = nullptr;
+        bam_key.clear();
     }
 };
 Cache g_cache;
@@ -95,11 +101,22 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     double *T = g_call_timing;
     for (int k = 0; k < 6; ++k) T[k] = 0;
     const double t_begin = now_s();
-    bsig_bam *bam = nullptr;
-    int rc = bsig_bam_open(bampath, &bam);                       // ref: Bamfile ctor :200-214
-    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    // ref: Bamfile ctor :200-214 opens file + index on every call; here an unchanged file (same
+    // size and mtime of the BAM and of its index) reuses the parsed header and BAI
+    const std::string key = file_key(bampath);
+    const std::string bkey = key.empty() ? std::string() : key + "#" + file_key(std::string(bampath) + ".bai");
+    int rc = BSIG_OK;
+    if (bkey.empty() || !g_cache.bam || g_cache.bam_key != bkey) {
+        bsig_bam *fresh = nullptr;
+        rc = bsig_bam_open(bampath, &fresh);
+        if (rc) return rc;
+        if (g_cache.bam) bsig_bam_close(g_cache.bam);
+        g_cache.bam = fresh;
+        g_cache.bam_key = bkey;
+    }
+    bsig_bam *bam = g_cache.bam;
     T[0] = now_s() - t_begin;
-    std::unique_ptr<bsig_bam, void (*)(bsig_bam *)> guard(bam, bsig_bam_close);
 
     // seqnames -> BAM reference ids, by name (ref: parseRegions :113-120)
     std::vector<int32_t> level_rid((size_t)n_levels, -2);
@@ -124,9 +141,10 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (ext < 0) return fail(BSIG_ERR_EXT, "negative 'ext' values don't make sense");             // ref: :243
 
     const int dev = pick_device(device);
-    std::lock_guard<std::mutex> lock(g_cache.mu);
     if (g_cache.ctx && g_cache.device != dev) {
-        g_cache.clear();
+        if (g_cache.reads) bsig_reads_free(g_cache.reads);
+        g_cache.reads = nullptr;
+        g_cache.key.clear();
         bsig_ctx_destroy(g_cache.ctx);
         g_cache.ctx = nullptr;
     }
@@ -142,7 +160,6 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     int64_t genome = 0, wanted = 0;
     for (int32_t l : bam->hdr.lens) genome += l;
     for (int64_t i = 0; i < n; ++i) wanted += (int64_t)width[i] + 2 * ext + 16384;
-    const std::string key = file_key(bampath);
     bsig_reads *reads = nullptr;
     bool owned = false;
     const char *force = getenv("BAMSIGNALS_DECODE");   // "all" | "regions" (testing / tuning)
@@ -172,7 +189,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         if (rc) return rc;
         T[2] = now_s() - t_up;
         if (whole && !key.empty()) {
-            g_cache.clear();
+            if (g_cache.reads) bsig_reads_free(g_cache.reads);
             g_cache.reads = reads;
             g_cache.key = key;
         } else {

@@ -75,11 +75,11 @@ def _check_gr(gr):
 
 
 def _split(out, off, ss):
-    sigs = []
-    for i in range(len(off) - 1):
-        v = out[off[i]:off[i + 1]]
-        sigs.append(v.reshape(-1, 2).T if ss else v)
-    return sigs
+    out.setflags(write=False)          # the signals are views of this buffer: read-only container
+    off = off.tolist()
+    if ss:
+        return [out[a:b].reshape(-1, 2).T for a, b in zip(off[:-1], off[1:])]
+    return [out[a:b] for a, b in zip(off[:-1], off[1:])]
 
 
 def pileup_core(bampath, gr, tlen_filter, mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
@@ -161,7 +161,7 @@ def bamProfile(bampath, gr, binsize=1, mapqual=0, shift=0, ss=False,  # noqa: N8
     pe = _match_arg(paired_end, ("ignore", "filter", "midpoint"), "paired.end")
     pu = pileup_core(os.path.expanduser(str(bampath)), gr, globals()["tlenFilter"](tlenFilter, pe), mapqual,
                      int(binsize), shift, ss, flagMask(pe), filteredFlag, pe == "midpoint")
-    return CountSignals(pu, bool(ss))
+    return CountSignals(pu, bool(ss), _trusted=True)
 
 
 def bamCoverage(bampath, gr, mapqual=0, paired_end=("ignore", "extend"), tlenFilter=None,  # noqa: N802,N803
@@ -172,4 +172,4 @@ def bamCoverage(bampath, gr, mapqual=0, paired_end=("ignore", "extend"), tlenFil
     pe = _match_arg(paired_end, ("ignore", "extend"), "paired.end")
     pu = coverage_core(os.path.expanduser(str(bampath)), gr, globals()["tlenFilter"](tlenFilter, pe), mapqual,
                        flagMask(pe), filteredFlag, pe == "extend")
-    return CountSignals(pu, False)
+    return CountSignals(pu, False, _trusted=True)
