@@ -540,6 +540,7 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (cells == 0) return BSIG_OK;
     if (!out_dev) return fail(BSIG_ERR_ARG, "output buffer is NULL");
     if (((uintptr_t)out_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device output buffer must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(p->ctx->device));      // the caller's thread may have another GPU current
     hipStream_t st = p->ctx->stream;
     if (p->kernel_mode == BSIG_MODE_COUNT)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
