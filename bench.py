@@ -35,6 +35,13 @@ CONFIGS = {
                args=dict(binsize=1), desc="bamProfile binsize=1, 10k x 2kb ranges, 5e7 SE reads, 250 Mbp"),
     "C2small": dict(reads=2_000_000, ref_len=[10_000_000], ranges=10_000, width=2000, paired=False,
                     args=dict(binsize=1), desc="bamProfile binsize=1, 10k x 2kb ranges, 2e6 SE reads, 10 Mbp"),
+    # hg38-like: 24 references, 3.1 Gbp; per GPU 125,000 x 1 kb ranges (1M over 8 GPUs)
+    "C5": dict(reads=1_000_000_000,
+               ref_len=[248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+                        138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+                        83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415],
+               ranges=125_000, width=1000, paired=False, args=dict(binsize=1),
+               desc="bamProfile binsize=1, 1M x 1kb ranges over 8 GPUs (125k per GPU), 1e9 SE reads, 24 refs / 3.1 Gbp"),
     "C4": dict(reads=500_000_000, ref_len=[250_000_000] * 10, ranges=100_000, width=2000, paired=True,
                args=dict(binsize=1, ss=True, shift=75, requiredF=66, tlen_filter=(50, 500)),
                desc="bamProfile PE filter tlenFilter=c(50,500) shift=75 ss=TRUE, 100k x 2kb, 5e8 PE reads"),
