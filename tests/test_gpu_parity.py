@@ -286,8 +286,9 @@ def test_fuzz_small_inputs(ctx):
     extreme spans, every parameter drawn at random.  HIP vs the C oracle, bit for bit."""
     from bamsignals_amd.device import Reads
     from oracle import oracle_c
-    rng = np.random.default_rng(2024)
-    for case in range(60):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("BSIG_FUZZ_SEED", "2024")))
+    for case in range(int(os.environ.get("BSIG_FUZZ_CASES", "60"))):
         n_ref = int(rng.integers(1, 4))
         ref_len = rng.integers(1, 70_000, n_ref).astype(np.int32)
         n = int(rng.integers(0, 4000))
