@@ -218,12 +218,21 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
             const uint32_t j = jb0 + 4u * NT * k;
             if (j < j_hi) four(p0[k], f0[k], t0[k], j);
         }
-        for (uint32_t j = jb0 + 4u * NT * kPre0; j < j_hi; j += 4u * NT) {
-            const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
-            const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
-            int4 t = make_int4(0, 0, 0, 0);
-            if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
-            four(p, f, t, j);
+        // deeper windows: two passes per trip, both requested before either is consumed
+        for (uint32_t j = jb0 + 4u * NT * kPre0; j < j_hi; j += 8u * NT) {
+            const uint32_t j2 = j + 4u * NT;
+            const int4 pa = *reinterpret_cast<const int4 *>(C.pos + j);
+            const uint4 fa = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 ta = make_int4(0, 0, 0, 0), tb = make_int4(0, 0, 0, 0), pb = make_int4(0, 0, 0, 0);
+            uint4 fb = make_uint4(0, 0, 0, 0);
+            if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(C.tlen + j);
+            if (j2 < j_hi) {
+                pb = *reinterpret_cast<const int4 *>(C.pos + j2);
+                fb = *reinterpret_cast<const uint4 *>(C.fm + j2);
+                if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(C.tlen + j2);
+            }
+            four(pa, fa, ta, j);
+            if (j2 < j_hi) four(pb, fb, tb, j2);
         }
     }
 #pragma unroll
