@@ -48,9 +48,12 @@ struct BsigWorkItem {
     int32_t nc;         // profile/coverage: cells in the tile; count: bases in the sub-interval
     int64_t out_off;    // flat int32 offset of the tile's first output cell
     uint32_t ref_unit0; // first 64-kbp unit of the range's reference in the global coordinate
-    uint32_t units_strand;  // bits 0..29: units of the reference; bit 30: range is on '-';
-                            // bit 31 (count mode): add with a global atomic (range was split)
+    uint32_t units_strand;  // BSIG_ITEM_* bits below
 };
+#define BSIG_ITEM_UNITS_MASK 0x0FFFFFFFu   // 64-kbp units of the range's reference
+#define BSIG_ITEM_HEAVY (1u << 29)         // its reads are piled up by slice items of a second launch
+#define BSIG_ITEM_NEG (1u << 30)           // range is on the '-' strand
+#define BSIG_ITEM_ATOMIC (1u << 31)        // count mode: add with a global atomic (range was split)
 
 struct BsigKParams {
     int32_t mapqual;
@@ -68,6 +71,8 @@ struct BsigKParams {
     int32_t div_shift;      //   __umulhi(n, div_magic) >> div_shift        (binsize >= 2)
     int32_t ext;            // window extension on both sides (src/bamsignals.cpp:457,487)
     int32_t tile_cells;     // output cells per tile (sizes the dynamic LDS image)
+    int32_t accumulate;     // 1: add the tile image into the result with integer atomics (slices of
+                            // a heavy tile) instead of storing it
 };
 
 #endif

@@ -65,7 +65,7 @@ __device__ __forceinline__ bool class_window(const BsigClassCols &C, const BsigW
 {
     int64_t wlo = tlo - ext - C.maxspan + 1;
     int64_t whi = thi + ext;
-    const int64_t ref_bp = (int64_t)(w.units_strand & 0x3FFFFFFFu) << BSIG_REF_UNIT_SHIFT;
+    const int64_t ref_bp = (int64_t)(w.units_strand & BSIG_ITEM_UNITS_MASK) << BSIG_REF_UNIT_SHIFT;
     if (wlo < 0) wlo = 0;
     if (whi > ref_bp) whi = ref_bp;
     if (wlo >= whi) return false;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void store_vec(int32_t *__restrict__ gbase, int v, in
 __device__ __forceinline__ void item_interval(const BsigWorkItem &w, const BsigKParams &P, int mode,
                                               int64_t &tlo, int64_t &thi)
 {
-    const bool neg_range = (w.units_strand >> 30) & 1u;
+    const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     if (mode == BSIG_MODE_COUNT) { tlo = (int64_t)w.loc + w.c0; thi = tlo + w.nc; }
     else tile_interval(w, mode == BSIG_MODE_COVERAGE ? 1 : P.binsize, neg_range, tlo, thi);
 }
@@ -276,13 +276,17 @@ __device__ __forceinline__ void load_windows(const BsigReadsDev &R, const BsigKP
         const uint4 a = wp[0], b = wp[1];
         win[0] = make_uint2(a.x, a.y); win[1] = make_uint2(a.z, a.w);
         win[2] = make_uint2(b.x, b.y); win[3] = make_uint2(b.z, b.w);
+        if (w.units_strand & BSIG_ITEM_HEAVY) {
+#pragma unroll
+            for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = make_uint2(0u, 0u);
+        }
         return;
     }
     int64_t tlo, thi;
     item_interval(w, P, mode, tlo, thi);
     const uint32_t *alo[BSIG_MAX_CLASSES], *ahi[BSIG_MAX_CLASSES];
     bool live[BSIG_MAX_CLASSES];
-    const int64_t ref_bp = (int64_t)(w.units_strand & 0x3FFFFFFFu) << BSIG_REF_UNIT_SHIFT;
+    const int64_t ref_bp = (int64_t)(w.units_strand & BSIG_ITEM_UNITS_MASK) << BSIG_REF_UNIT_SHIFT;
     const uint64_t g0 = (uint64_t)w.ref_unit0 << BSIG_REF_UNIT_SHIFT;
 #pragma unroll
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
@@ -301,6 +305,21 @@ __device__ __forceinline__ void load_windows(const BsigReadsDev &R, const BsigKP
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { lo[c] = *alo[c]; hi[c] = *ahi[c]; }
 #pragma unroll
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = live[c] && lo[c] < hi[c] ? make_uint2(lo[c], hi[c]) : make_uint2(0u, 0u);
+    // a heavy tile only zero-fills its cells here; its reads come through slice items afterwards
+    if (w.units_strand & BSIG_ITEM_HEAVY) {
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = make_uint2(0u, 0u);
+    }
+}
+
+// the accumulating form of store_vec: slices of a heavy tile add their (partial) image
+__device__ __forceinline__ void add_vec(int32_t *__restrict__ gbase, int v, int4 x, int sh, int nv)
+{
+    const int e0 = 4 * v, lo = sh, hi = sh + nv;
+    if (x.x && e0 + 0 >= lo && e0 + 0 < hi) atomicAdd(gbase + e0 + 0, x.x);
+    if (x.y && e0 + 1 >= lo && e0 + 1 < hi) atomicAdd(gbase + e0 + 1, x.y);
+    if (x.z && e0 + 2 >= lo && e0 + 2 < hi) atomicAdd(gbase + e0 + 2, x.z);
+    if (x.w && e0 + 3 >= lo && e0 + 3 < hi) atomicAdd(gbase + e0 + 3, x.w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
     block_sync<NT>();
     BSIG_STAMP(1);
 
-    const bool neg_range = (w.units_strand >> 30) & 1u;
+    const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
         if (!valid || read_rejected(P, fm, tl)) return;
@@ -352,8 +371,11 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
     BSIG_STAMP(2);
 
     int32_t *gbase = out + (w.out_off - sh);
-    if (!BSIG_ABLATE(2))
+    if (P.accumulate) {
+        for (int v = tid; v < nvec; v += NT) add_vec(gbase, v, lds4[v], sh, nv);
+    } else if (!BSIG_ABLATE(2)) {
         for (int v = tid; v < nvec; v += NT) store_vec(gbase, v, lds4[v], sh, nv);
+    }
     BSIG_STAMP(3);
 #ifdef BSIG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigReadsDev R, cons
     const int stride = (P.tile_cells * S) | 1;                 // odd: replicas shift by one bank
     for (int v = tid; v < kReplicas * stride; v += NT) lds[v] = 0;
     block_sync<NT>();
-    const bool neg_range = (w.units_strand >> 30) & 1u;
+    const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     int32_t *mine = lds + (tid & (kReplicas - 1)) * stride;
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
@@ -416,7 +438,8 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigReadsDev R, cons
         int acc = 0;
 #pragma unroll 8
         for (int r = 0; r < kReplicas; ++r) acc += lds[r * stride + v];
-        out[w.out_off + v] = acc;
+        if (!P.accumulate) out[w.out_off + v] = acc;
+        else if (acc) atomicAdd(out + w.out_off + v, acc);
     }
 }
 
@@ -435,7 +458,7 @@ __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKP
     const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES];
     load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win, tile);
-    const bool neg_range = (w.units_strand >> 30) & 1u;
+    const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
     const int gn = w.nc;
     int c_sense = 0, c_anti = 0;
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(NT) void k_count(const BsigReadsDev R, const BsigKP
         }
     }
     if (tid == 0) {
-        const bool atomic = (w.units_strand >> 31) & 1u;
+        const bool atomic = (w.units_strand & BSIG_ITEM_ATOMIC) != 0u;
         int32_t *o = out + w.out_off;
         if (P.ss) {
             if (atomic) { if (c_sense) atomicAdd(o, c_sense); if (c_anti) atomicAdd(o + 1, c_anti); }
@@ -504,7 +527,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
     const int nvec = (sh + nv + 3) >> 2;
     block_sync<NT>();
 
-    const bool neg_range = (w.units_strand >> 30) & 1u;
+    const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int rend1 = w.loc + w.len - 1;     // last base of the range
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
@@ -551,7 +574,10 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigReadsDev R, const Bsi
         }
         const int add = pre + incl - tot;
         x.x += add; x.y += add; x.z += add; x.w += add;
-        if (v < nvec) store_vec(gbase, v, x, sh, nv);
+        if (v < nvec) {
+            if (P.accumulate) add_vec(gbase, v, x, sh, nv);
+            else store_vec(gbase, v, x, sh, nv);
+        }
         carry += all;
     }
 }
@@ -766,10 +792,10 @@ namespace bsig {
 template <int NT>
 static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const BsigKParams &P,
                               const BsigWorkItem *items, int64_t n_items, int tile_cells,
-                              uint2 *windows, int32_t *out, hipStream_t st)
+                              uint2 *windows, bool resolve_first, int32_t *out, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
-    if (windows)
+    if (windows && resolve_first)
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
                            R, P, mode, items, n_items, windows);
     const dim3 grid((unsigned)n_items), block(NT);
@@ -792,14 +818,23 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
 
 hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, const BsigKParams &P,
                          const BsigWorkItem *items, int64_t n_items, int tile_cells,
-                         void *windows, int32_t *out, hipStream_t st)
+                         void *windows, bool resolve_first, int32_t *out, hipStream_t st)
 {
     switch (threads) {
-    case 64:  return launch_mode<64>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, out, st);
-    case 128: return launch_mode<128>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, out, st);
-    case 256: return launch_mode<256>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, out, st);
+    case 64:  return launch_mode<64>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, resolve_first, out, st);
+    case 128: return launch_mode<128>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, resolve_first, out, st);
+    case 256: return launch_mode<256>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, resolve_first, out, st);
     default:  return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_resolve(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
+                          int64_t n_items, void *windows, hipStream_t st)
+{
+    if (n_items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
+                       R, P, mode, items, n_items, (uint2 *)windows);
+    return hipGetLastError();
 }
 
 hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag, const int64_t *cigar_off,

@@ -106,6 +106,11 @@ struct bsig_plan {
     BsigWorkItem *items = nullptr;
     void *windows = nullptr;       // [n_items][BSIG_MAX_CLASSES] read windows, rewritten by every run
     int32_t *d_out = nullptr;      // device result buffer of bsig_plan_run_host, kept between calls
+    // slices of heavy tiles (tiles whose read windows hold more than kHeavyReads reads): the same
+    // kernels run a second time over these items with fixed windows and accumulate = 1
+    BsigWorkItem *heavy_items = nullptr;
+    void *heavy_windows = nullptr;
+    int64_t n_heavy_slices = 0, n_heavy_tiles = 0;
     bool have_stats = false;
     bsig_plan_stats stats{};
 };
@@ -475,7 +480,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
         BsigWorkItem w{};
         w.loc = loc[i]; w.len = len[i];
         w.ref_unit0 = reads->ref_unit0[rid[i]];
-        w.units_strand = reads->ref_units[rid[i]] | (strand[i] < 0 ? (1u << 30) : 0u);
+        w.units_strand = reads->ref_units[rid[i]] | (strand[i] < 0 ? BSIG_ITEM_NEG : 0u);
         if (wide_bins) {
             const int64_t cells = (P->off[i + 1] - P->off[i]) / mult;
             for (int64_t c = 0; c < cells; ++c) {
@@ -486,7 +491,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
                     w.c0 = (int32_t)a;
                     w.nc = (int32_t)std::min<int64_t>(count_split, g1 - a);
                     w.out_off = P->off[i] + c * mult;
-                    w.units_strand |= 1u << 31;
+                    w.units_strand |= BSIG_ITEM_ATOMIC;
                     items.push_back(w);
                 }
             }
@@ -496,7 +501,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
                 w.c0 = (int32_t)a;
                 w.nc = (int32_t)std::min<int64_t>(count_split, len[i] - a);
                 w.out_off = P->off[i];
-                if (split) w.units_strand |= 1u << 31;
+                if (split) w.units_strand |= BSIG_ITEM_ATOMIC;
                 items.push_back(w);
             }
         } else {
@@ -521,6 +526,55 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     if (e == hipSuccess && !items.empty())
         e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+
+    // ---- heavy tiles --------------------------------------------------------------------------
+    // One wave streams a tile's reads; a tile on a read hotspot (chrM, rDNA, an amplicon) can hold
+    // millions and would keep the whole launch waiting.  Probe the window sizes once per plan and
+    // cut the windows of heavy tiles into slices that separate workgroups add up with atomics.
+    int64_t heavy_reads = 32768, slice_reads = 8192;
+    if (const char *v = getenv("BAMSIGNALS_HEAVY_READS")) { heavy_reads = std::max<long long>(4, atoll(v)); slice_reads = std::max<int64_t>(4, heavy_reads / 4); }
+    if (e == hipSuccess && !items.empty()) {
+        DevPool tmp;
+        uint2 *d_win = nullptr;
+        e = tmp.alloc(&d_win, items.size() * BSIG_MAX_CLASSES);
+        std::vector<uint2> win(items.size() * BSIG_MAX_CLASSES);
+        if (e == hipSuccess) e = bsig::launch_resolve(reads->dev, K, P->kernel_mode, P->items, P->n_items, d_win, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(win.data(), d_win, win.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        std::vector<BsigWorkItem> hitems;
+        std::vector<uint2> hwin;
+        if (e == hipSuccess) {
+            for (size_t t = 0; t < items.size(); ++t) {
+                int64_t total = 0;
+                for (int c = 0; c < BSIG_MAX_CLASSES; ++c) total += (int64_t)win[t * BSIG_MAX_CLASSES + c].y - win[t * BSIG_MAX_CLASSES + c].x;
+                if (total <= heavy_reads) continue;
+                ++P->n_heavy_tiles;
+                BsigWorkItem sl = items[t];
+                if (P->kernel_mode == BSIG_MODE_COUNT) sl.units_strand |= BSIG_ITEM_ATOMIC;
+                for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+                    const uint2 wc = win[t * BSIG_MAX_CLASSES + c];
+                    for (int64_t j0 = wc.x; j0 < (int64_t)wc.y; j0 += slice_reads) {
+                        hitems.push_back(sl);
+                        for (int k = 0; k < BSIG_MAX_CLASSES; ++k)
+                            hwin.push_back(k == c ? make_uint2((uint32_t)j0, (uint32_t)std::min<int64_t>(j0 + slice_reads, wc.y)) : make_uint2(0u, 0u));
+                    }
+                }
+                items[t].units_strand |= BSIG_ITEM_HEAVY;
+            }
+        }
+        if (e == hipSuccess && !hitems.empty()) {
+            P->n_heavy_slices = (int64_t)hitems.size();
+            uint2 *hw = nullptr;
+            e = P->pool.alloc(&P->heavy_items, hitems.size());
+            if (e == hipSuccess) e = P->pool.alloc(&hw, hwin.size());
+            P->heavy_windows = hw;
+            if (e == hipSuccess) e = hipMemcpyAsync(P->heavy_items, hitems.data(), hitems.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hw, hwin.data(), hwin.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream);
+            // the heavy flags of the main items
+            if (e == hipSuccess) e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    }
     if (e != hipSuccess) {
         delete P;
         return fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "plan upload failed: %s", hipGetErrorString(e));
@@ -545,7 +599,14 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (p->kernel_mode == BSIG_MODE_COUNT)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
     HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
-                                p->tile_cells, p->windows, out_dev, st));
+                                p->tile_cells, p->windows, true, out_dev, st));
+    if (p->n_heavy_slices) {
+        // the first launch zero-filled the heavy tiles; their slices now add their partial images
+        BsigKParams acc = p->kp;
+        acc.accumulate = 1;
+        HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, acc, p->heavy_items,
+                                    p->n_heavy_slices, p->tile_cells, p->heavy_windows, false, out_dev, st));
+    }
     return BSIG_OK;
 }
 

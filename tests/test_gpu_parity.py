@@ -344,3 +344,48 @@ def test_very_wide_bins(ctx, synth):
             want, woff = oracle_c.pileup_core(orc, rg, **a)
             got, off = _gpu(ctx, gpu, rg, "pileup", **dict(a))
             assert np.array_equal(off, woff) and np.array_equal(got, want), (which, a)
+
+
+def test_heavy_tile_slices(ctx, synth, monkeypatch):
+    """Tiles on read hotspots are cut into slices that a second launch adds up with atomics.  With
+    the threshold forced down (BAMSIGNALS_HEAVY_READS) nearly every tile takes that path; results
+    must not change.  Then a real hotspot at the default threshold."""
+    from bamsignals_amd.device import Reads
+    from oracle import oracle_c
+    gpu, orc, cols, _ = synth["pe"]
+    rng = np.random.default_rng(5)
+    rg = _rand_ranges(rng, cols["ref_len"], 120, 6000)
+    for thr in ("8", "300"):
+        monkeypatch.setenv("BAMSIGNALS_HEAVY_READS", thr)
+        for a in (dict(binsize=1, ss=True, shift=20), dict(binsize=40, requiredF=66, tlen_filter=(0, 900), pe_mid=True),
+                  dict(binsize=-1, ss=True), dict(binsize=3000), dict(binsize=70_000, ss=True)):
+            want, _ = oracle_c.pileup_core(orc, rg, **a)
+            for resolve in (0, 1):
+                got, _ = _gpu(ctx, gpu, rg, "pileup", resolve=resolve, **dict(a))
+                assert np.array_equal(got, want), (thr, a, resolve)
+        for a in (dict(), dict(requiredF=66, tlen_filter=(0, 900), tspan=True)):
+            want, _ = oracle_c.coverage_core(orc, rg, **a)
+            got, _ = _gpu(ctx, gpu, rg, "coverage", threads=128, **dict(a))
+            assert np.array_equal(got, want), (thr, a)
+        monkeypatch.setenv("BSIG_FUZZ_CASES", "25")
+        test_fuzz_small_inputs(ctx)
+    monkeypatch.delenv("BAMSIGNALS_HEAVY_READS")
+    monkeypatch.delenv("BSIG_FUZZ_CASES")
+    # 300,000 reads piled on 1.5 kb of a small reference, default threshold (32,768 reads)
+    n = 300_000
+    pos = np.sort(rng.integers(2000, 3500, n)).astype(np.int32)
+    end = (pos + rng.integers(30, 150, n) - 1).astype(np.int32)
+    flag = (rng.integers(0, 2, n) * 16).astype(np.uint16)
+    mapq = rng.integers(0, 60, n).astype(np.uint8)
+    tlen = np.zeros(n, np.int32)
+    hot = Reads(ctx, [10_000], [0, n], pos, flag, mapq, tlen, end=end)
+    horc = oracle_c.OracleReads([0, n], pos, end, flag, mapq, tlen)
+    hr = dict(rid=np.zeros(4, np.int32), loc=np.asarray([0, 1900, 2500, 2600], np.int32),
+              len=np.asarray([10_000, 2000, 300, 0], np.int32), strand=np.asarray([1, -1, 0, 1], np.int32))
+    for kind, a in (("pileup", dict(binsize=1, ss=True)), ("pileup", dict(binsize=-1)), ("pileup", dict(binsize=250)),
+                    ("coverage", dict(mapqual=10))):
+        fn = oracle_c.coverage_core if kind == "coverage" else oracle_c.pileup_core
+        want, _ = fn(horc, hr, **a)
+        got, _ = _gpu(ctx, hot, hr, kind, **dict(a))
+        assert np.array_equal(got, want), (kind, a)
+    hot.close()
