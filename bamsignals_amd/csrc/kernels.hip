@@ -392,10 +392,16 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigReadsDev R, const Bsig
 
 // Wide bins (binsize >~ 64): a tile has few cells and thousands of reads, and the position-sorted
 // reads of one wave instruction fall into one or two bins, so plain LDS atomics serialise on a
-// bank.  Here every lane pair adds into its own replica of the tile image (32 replicas, odd stride:
+// bank.  Here the lanes add into replicas of the tile image (up to 32, odd stride:
 // the same cell of different replicas lies in different banks); the replicas are summed at the end.
 constexpr int kSmallCells = 256;     // at most this many values (cells * S) per tile
-constexpr int kReplicas = 32;
+// replicas of the image: as many as keep it near 8 KiB (more LDS would cost resident workgroups)
+__host__ __device__ inline int small_replicas(int stride)
+{
+    int r = 32;
+    while (r > 2 && r * stride * 4 > 8448) r >>= 1;
+    return r;
+}
 template <int NT, bool SS>
 __global__ __launch_bounds__(NT) void k_profile_small(const BsigReadsDev R, const BsigKParams P,
                                                       const BsigWorkItem *__restrict__ items,
@@ -410,10 +416,11 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigReadsDev R, cons
     uint2 win[BSIG_MAX_CLASSES];
     load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile);
     const int stride = (P.tile_cells * S) | 1;                 // odd: replicas shift by one bank
-    for (int v = tid; v < kReplicas * stride; v += NT) lds[v] = 0;
+    const int n_rep = small_replicas(stride);
+    for (int v = tid; v < n_rep * stride; v += NT) lds[v] = 0;
     block_sync<NT>();
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
-    int32_t *mine = lds + (tid & (kReplicas - 1)) * stride;
+    int32_t *mine = lds + (tid & (n_rep - 1)) * stride;
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
         if (!valid || read_rejected(P, fm, tl)) return;
@@ -436,8 +443,7 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigReadsDev R, cons
     const int nv = w.nc * S;
     for (int v = tid; v < nv; v += NT) {
         int acc = 0;
-#pragma unroll 8
-        for (int r = 0; r < kReplicas; ++r) acc += lds[r * stride + v];
+        for (int r = 0; r < n_rep; ++r) acc += lds[r * stride + v];
         if (!P.accumulate) out[w.out_off + v] = acc;
         else if (acc) atomicAdd(out + w.out_off + v, acc);
     }
@@ -800,7 +806,8 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
                            R, P, mode, items, n_items, windows);
     const dim3 grid((unsigned)n_items), block(NT);
     if (mode == BSIG_MODE_PROFILE && tile_cells * (ss ? 2 : 1) <= kSmallCells && P.binsize > 1) {
-        const size_t lds = (size_t)kReplicas * ((tile_cells * (ss ? 2 : 1)) | 1) * sizeof(int32_t);
+        const int stride = (tile_cells * (ss ? 2 : 1)) | 1;
+        const size_t lds = (size_t)small_replicas(stride) * stride * sizeof(int32_t);
         if (ss) hipLaunchKernelGGL((k_profile_small<NT, true>), grid, block, lds, st, R, P, items, windows, out);
         else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, R, P, items, windows, out);
     } else if (mode == BSIG_MODE_PROFILE) {
