@@ -43,6 +43,8 @@ def main():
         cases.append(("count on the same tiling", reads, tiles, make_params(_lib.MODE_COUNT, binsize=-1)))
         one = dict(rid=np.zeros(1, np.int32), loc=np.zeros(1, np.int32), len=np.asarray([L], np.int32), strand=np.zeros(1, np.int32))
         cases.append(("coverage of ONE whole-chromosome range (tiled internally)", reads, one, make_params(_lib.MODE_COVERAGE)))
+        cases.append(("genome-wide 8-bp bins: ONE chr1 range, binsize=8", reads, one, make_params(_lib.MODE_PROFILE, binsize=8)))
+        cases.append(("genome-wide 32-bp bins: ONE chr1 range, binsize=32", reads, one, make_params(_lib.MODE_PROFILE, binsize=32)))
         cases.append(("genome-wide 64-bp bins: ONE chr1 range, binsize=64", reads, one, make_params(_lib.MODE_PROFILE, binsize=64)))
         cases.append(("genome-wide 200-bp bins, ss: ONE chr1 range, binsize=200", reads, one, make_params(_lib.MODE_PROFILE, binsize=200, ss=True)))
         cases.append(("genome-wide 1-kb bins: ONE chr1 range, binsize=1000", reads, one, make_params(_lib.MODE_PROFILE, binsize=1000)))
