@@ -7,6 +7,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 cd $R
 timeout 900 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json

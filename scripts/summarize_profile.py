@@ -19,7 +19,7 @@ def one(pattern):
     f = glob.glob(os.path.join(G, pattern))
     if not f:
         raise SystemExit("missing " + pattern)
-    return f[0]
+    return max(f, key=os.path.getmtime)      # gpurun merges runs into the same directory: newest wins
 
 
 stats = one(f"{tag}_trace/*/*_kernel_stats.csv")
@@ -50,7 +50,11 @@ for k in ("k_profile", "k_resolve"):
     out["per_launch"][k] = {"FETCH_SIZE_raw_KB": fetch.get(k), "WRITE_SIZE_raw_KB": write.get(k),
                             "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
                             "launches_sampled": [nf.get(k), nw.get(k)]}
-out["step_hbm_bytes"] = sum(v["hbm_bytes"] for v in out["per_launch"].values())
+# k_resolve belongs to a step only when it is launched once per step (resolve=1); by default it
+# runs once per plan (the heavy-tile probe of bsig_plan_create), outside the steps
+per_step = ["k_profile"] + (["k_resolve"] if (nf.get("k_resolve") or 0) >= (nf.get("k_profile") or 1) else [])
+out["step_kernels"] = per_step
+out["step_hbm_bytes"] = sum(out["per_launch"][k]["hbm_bytes"] for k in per_step)
 out["algorithmic_bytes"] = bench["roofline"]["algorithmic_bytes"]
 json.dump(out, open(os.path.join(P, f"{tag}_pmc.json"), "w"), indent=1)
 shutil.copyfile(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_bench.json"))
@@ -68,8 +72,8 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
     f.write("PMC passes (separate runs; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950):\n\n")
     f.write("| kernel | HBM read B / launch | HBM write B / launch |\n|---|---|---|\n")
     for k, v in out["per_launch"].items():
-        if not v["hbm_bytes"]:
-            continue        # kernel not launched in this configuration
+        if not v["hbm_bytes"] or k not in per_step:
+            continue        # kernel not launched per step in this configuration
         f.write(f"| {k} | {v['hbm_read_bytes']:.3e} | {v['hbm_write_bytes']:.3e} |\n")
     f.write(f"\nstep HBM traffic = {out['step_hbm_bytes']:.4e} B vs algorithmic {out['algorithmic_bytes']:.4e} B "
             f"(ratio {out['step_hbm_bytes'] / out['algorithmic_bytes']:.3f})\n")
