@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise "
                          "the multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the same steps issued alternately on two streams (informational; off by "
+                         "default so that a profiler sees only the one-stream launches the metric is defined on)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even with one rank (exercises RCCL "
                          "on a 1-GPU box)")
@@ -183,7 +186,7 @@ def main():
         # one launch overlaps the ramp of the next (independent batches).  NOT the reported metric:
         # `value`, `kernel_ms` and the roofline figure above are the one-stream numbers.
         pipelined = None
-        if rank == 0 and nb >= 2:
+        if rank == 0 and nb >= 2 and a.pipelined:
             stream2 = torch.cuda.Stream()
             ctx2 = Context(local, stream=stream2.cuda_stream)
             plans2 = {b: Plan(ctx2, reads, batches[b]["rid"], batches[b]["loc"], batches[b]["len"],
