@@ -25,6 +25,8 @@ hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, c
                          int32_t *out, hipStream_t st);
 hipError_t launch_resolve(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
                           int64_t n_items, void *windows, hipStream_t st);
+hipError_t launch_count_heavy(const void *windows, int64_t n_items, int64_t heavy_reads,
+                              unsigned long long *count, hipStream_t st);
 hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag, const int64_t *cigar_off,
                             const uint32_t *cigar, int32_t *end_out, hipStream_t st);
 int64_t prep_chunks(int64_t n);

@@ -171,6 +171,21 @@ __global__ void k_resolve(const BsigReadsDev R, const BsigKParams P, int mode,
     windows[g] = make_uint2(j_lo, j_hi);
 }
 
+// how many tiles hold more reads in their windows than `heavy_reads` (plan-time probe)
+__global__ void k_count_heavy(const uint2 *__restrict__ windows, int64_t n_items, int64_t heavy_reads,
+                              unsigned long long *__restrict__ count)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    int64_t total = 0;
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const uint2 w = windows[t * BSIG_MAX_CLASSES + c];
+        total += (int64_t)w.y - w.x;
+    }
+    if (total > heavy_reads) atomicAdd(count, 1ull);
+}
+
 // Stream the reads of all span-class windows of one tile through `one(pos, end, fm, tlen, valid)`.
 // Everything a typical tile needs is requested before anything is consumed, so the workgroup pays
 // ONE memory round trip for its reads: the first kPre0 passes (kPre0 * 4 * NT reads) of class 0,
@@ -841,6 +856,15 @@ hipError_t launch_resolve(const BsigReadsDev &R, const BsigKParams &P, int mode,
     if (n_items <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
                        R, P, mode, items, n_items, (uint2 *)windows);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_heavy(const void *windows, int64_t n_items, int64_t heavy_reads,
+                              unsigned long long *count, hipStream_t st)
+{
+    if (n_items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_count_heavy, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st,
+                       (const uint2 *)windows, n_items, heavy_reads, count);
     return hipGetLastError();
 }
 

@@ -465,10 +465,35 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     // neighbouring workgroups then stream neighbouring reads
     std::vector<int64_t> order(n);
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-        if (rid[a] != rid[b]) return rid[a] < rid[b];
-        return loc[a] < loc[b];
-    });
+    {
+        bool sorted = true;
+        for (int64_t i = 1; i < n && sorted; ++i)
+            sorted = rid[i - 1] < rid[i] || (rid[i - 1] == rid[i] && loc[i - 1] <= loc[i]);
+        if (!sorted) {
+            // sort (key, index) pairs: one contiguous array instead of a comparator chasing three
+            std::vector<std::pair<uint64_t, int64_t>> keyed(n);
+            for (int64_t i = 0; i < n; ++i)
+                keyed[i] = {(uint64_t)(uint32_t)rid[i] << 32 | (uint32_t)(loc[i] ^ INT32_MIN), i};
+            if (n < 4096) {
+                std::sort(keyed.begin(), keyed.end());    // index as tie-break = stable
+            } else {
+                // LSD radix sort, 16 bits per pass; passes whose digit is constant are skipped
+                std::vector<std::pair<uint64_t, int64_t>> tmp2(n);
+                std::vector<uint32_t> hist(65536);
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int sh = 16 * pass;
+                    std::fill(hist.begin(), hist.end(), 0u);
+                    for (int64_t i = 0; i < n; ++i) ++hist[(keyed[i].first >> sh) & 0xFFFF];
+                    if (hist[(keyed[0].first >> sh) & 0xFFFF] == (uint32_t)n) continue;
+                    uint32_t acc = 0;
+                    for (uint32_t &h : hist) { const uint32_t c = h; h = acc; acc += c; }
+                    for (int64_t i = 0; i < n; ++i) tmp2[hist[(keyed[i].first >> sh) & 0xFFFF]++] = keyed[i];
+                    keyed.swap(tmp2);
+                }
+            }
+            for (int64_t i = 0; i < n; ++i) order[i] = keyed[i].second;
+        }
+    }
     std::vector<BsigWorkItem> items;
     items.reserve(n);
     const int64_t mult = K.ss ? 2 : 1;
@@ -540,13 +565,23 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
         DevPool tmp;
         uint2 *d_win = nullptr;
         e = tmp.alloc(&d_win, items.size() * BSIG_MAX_CLASSES);
-        std::vector<uint2> win(items.size() * BSIG_MAX_CLASSES);
+        std::vector<uint2> win;
+        unsigned long long *d_heavy = nullptr, n_heavy_dev = 0;
+        if (e == hipSuccess) e = tmp.alloc(&d_heavy, 1);
+        if (e == hipSuccess) e = hipMemsetAsync(d_heavy, 0, sizeof(unsigned long long), ctx->stream);
         if (e == hipSuccess) e = bsig::launch_resolve(reads->dev, K, P->kernel_mode, P->items, P->n_items, d_win, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(win.data(), d_win, win.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = bsig::launch_count_heavy(d_win, P->n_items, heavy_reads, d_heavy, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_heavy_dev, d_heavy, sizeof n_heavy_dev, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        // the windows themselves are only fetched when there is something to slice
+        if (e == hipSuccess && n_heavy_dev) {
+            win.resize(items.size() * BSIG_MAX_CLASSES);
+            e = hipMemcpyAsync(win.data(), d_win, win.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
         std::vector<BsigWorkItem> hitems;
         std::vector<uint2> hwin;
-        if (e == hipSuccess) {
+        if (e == hipSuccess && n_heavy_dev) {
             for (size_t t = 0; t < items.size(); ++t) {
                 int64_t total = 0;
                 for (int c = 0; c < BSIG_MAX_CLASSES; ++c) total += (int64_t)win[t * BSIG_MAX_CLASSES + c].y - win[t * BSIG_MAX_CLASSES + c].x;
