@@ -53,20 +53,35 @@ void fill_columns(const bsig_bam *b, bsig_columns *c)
 
 // one BAM decoded to HBM, kept between file-level calls (the reference re-opens file and index on
 // every call, src/bamsignals.cpp:449,479; here the expensive part is the decode + upload)
-struct Cache {
-    std::mutex mu;
-    std::string key;
+struct DevSlot {
     int device = -1;
     bsig_ctx *ctx = nullptr;
-    bsig_reads *reads = nullptr;
+    bsig_reads *reads = nullptr;    // the cached whole-file reads of `key`
+    std::string key;
+    void drop_reads()
+    {
+        if (reads) bsig_reads_free(reads);
+        reads = nullptr;
+        key.clear();
+    }
+    void destroy()
+    {
+        drop_reads();
+        if (ctx) bsig_ctx_destroy(ctx);
+        ctx = nullptr;
+        device = -1;
+    }
+};
+
+struct Cache {
+    std::mutex mu;
+    std::vector<DevSlot> slots;     // one per GPU the file-level calls drive
     // the last opened BAM (header + parsed BAI), so that repeated calls do not re-read the index
     std::string bam_key;
     bsig_bam *bam = nullptr;
     void clear()
     {
-        if (reads) bsig_reads_free(reads);
-        reads = nullptr;
-        key.clear();
+        for (DevSlot &d : slots) d.drop_reads();
         if (bam) bsig_bam_close(bam);
         bam = nullptr;
         bam_key.clear();
@@ -82,11 +97,23 @@ std::string file_key(const std::string &path)
            "|" + std::to_string((long long)st.st_mtim.tv_nsec);
 }
 
-int pick_device(int device)
+// GPUs a file-level call uses: the `device` argument if >= 0, else BAMSIGNALS_DEVICES ("0,1,2,3":
+// ranges are dealt round-robin to them), else BAMSIGNALS_DEVICE, else GPU 0
+std::vector<int> pick_devices(int device)
 {
-    if (device >= 0) return device;
-    if (const char *e = getenv("BAMSIGNALS_DEVICE")) return atoi(e);
-    return 0;
+    std::vector<int> d;
+    if (device >= 0) return {device};
+    if (const char *e = getenv("BAMSIGNALS_DEVICES")) {
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            d.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (d.empty()) d.push_back(getenv("BAMSIGNALS_DEVICE") ? atoi(getenv("BAMSIGNALS_DEVICE")) : 0);
+    return d;
 }
 
 // the common body of pileup_core / coverage_core
@@ -140,19 +167,24 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                                                  : std::llabs((long long)prm.shift) + (mid ? prm.tlen_filter[1] : 0);
     if (ext < 0) return fail(BSIG_ERR_EXT, "negative 'ext' values don't make sense");             // ref: :243
 
-    const int dev = pick_device(device);
-    if (g_cache.ctx && g_cache.device != dev) {
-        if (g_cache.reads) bsig_reads_free(g_cache.reads);
-        g_cache.reads = nullptr;
-        g_cache.key.clear();
-        bsig_ctx_destroy(g_cache.ctx);
-        g_cache.ctx = nullptr;
+    const std::vector<int> devs = pick_devices(device);
+    {
+        bool same = devs.size() == g_cache.slots.size();
+        for (size_t k = 0; same && k < devs.size(); ++k) same = g_cache.slots[k].device == devs[k];
+        if (!same) {
+            for (DevSlot &d : g_cache.slots) d.destroy();
+            g_cache.slots.assign(devs.size(), DevSlot());
+        }
+        for (size_t k = 0; k < devs.size(); ++k) {
+            DevSlot &d = g_cache.slots[k];
+            if (!d.ctx) {
+                rc = bsig_ctx_create(devs[k], nullptr, &d.ctx);
+                if (rc) return rc;
+                d.device = devs[k];
+            }
+        }
     }
-    if (!g_cache.ctx) {
-        rc = bsig_ctx_create(dev, nullptr, &g_cache.ctx);
-        if (rc) return rc;
-        g_cache.device = dev;
-    }
+    const size_t nd = devs.size();
 
     // How much of the file do the ranges need?  Small queries decode only the BGZF blocks the
     // index lists (ref: one bam_itr_queryi per chunk of ranges, :252-267); large ones decode the
@@ -160,14 +192,19 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     int64_t genome = 0, wanted = 0;
     for (int32_t l : bam->hdr.lens) genome += l;
     for (int64_t i = 0; i < n; ++i) wanted += (int64_t)width[i] + 2 * ext + 16384;
-    bsig_reads *reads = nullptr;
-    bool owned = false;
     const char *force = getenv("BAMSIGNALS_DECODE");   // "all" | "regions" (testing / tuning)
     bool whole = wanted * 4 > genome;
     if (force && !strcmp(force, "all")) whole = true;
     if (force && !strcmp(force, "regions")) whole = false;
-    if (!key.empty() && key == g_cache.key && g_cache.reads) {
-        reads = g_cache.reads;
+
+    // reads of this call on every device: cached, or decoded once and uploaded to each
+    std::vector<bsig_reads *> reads(nd, nullptr);
+    std::vector<char> owned(nd, 0);
+    bool all_cached = !key.empty();
+    for (size_t k = 0; k < nd; ++k) all_cached = all_cached && g_cache.slots[k].reads && g_cache.slots[k].key == key;
+    auto release = [&]() { for (size_t k = 0; k < nd; ++k) if (owned[k] && reads[k]) bsig_reads_free(reads[k]); };
+    if (all_cached) {
+        for (size_t k = 0; k < nd; ++k) reads[k] = g_cache.slots[k].reads;
         T[5] = 1;
     } else {
         const double t_dec = now_s();
@@ -185,21 +222,75 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         if (rc) return rc;
         T[1] = now_s() - t_dec;
         const double t_up = now_s();
-        rc = bsig_reads_upload(g_cache.ctx, &cols, &reads);
-        if (rc) return rc;
-        T[2] = now_s() - t_up;
-        if (whole && !key.empty()) {
-            if (g_cache.reads) bsig_reads_free(g_cache.reads);
-            g_cache.reads = reads;
-            g_cache.key = key;
-        } else {
-            owned = true;
+        for (size_t k = 0; k < nd; ++k) {
+            DevSlot &d = g_cache.slots[k];
+            if (whole && !key.empty() && d.reads && d.key == key) { reads[k] = d.reads; continue; }
+            rc = bsig_reads_upload(d.ctx, &cols, &reads[k]);
+            if (rc) { release(); return rc; }
+            if (whole && !key.empty()) {
+                d.drop_reads();
+                d.reads = reads[k];
+                d.key = key;
+            } else {
+                owned[k] = 1;
+            }
         }
+        T[2] = now_s() - t_up;
     }
+
     const double t_run = now_s();
-    rc = bsig_pileup_columns(g_cache.ctx, reads, n, rid.data(), loc.data(), width, strand, &prm, out, off);
+    if (nd == 1) {
+        rc = bsig_pileup_columns(g_cache.slots[0].ctx, reads[0], n, rid.data(), loc.data(), width, strand, &prm, out, off);
+    } else {
+        // ranges are independent (each owns its output, ref: :164,181,186): the (rid, loc)-sorted
+        // ranges are dealt round-robin to the GPUs, every GPU runs its shard on its own stream, the
+        // shards come back over each GPU's own PCIe link and are put back at the ranges' offsets
+        std::vector<int64_t> order((size_t)n);
+        for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            if (rid[(size_t)a] != rid[(size_t)b]) return rid[(size_t)a] < rid[(size_t)b];
+            return loc[(size_t)a] < loc[(size_t)b];
+        });
+        struct Shard {
+            std::vector<int64_t> which;
+            std::vector<int32_t> rid, loc, len, strand;
+            bsig_plan *plan = nullptr;
+            int32_t *host = nullptr;
+        };
+        std::vector<Shard> sh(nd);
+        for (int64_t k = 0; k < n; ++k) {
+            Shard &S = sh[(size_t)(k % (int64_t)nd)];
+            const int64_t i = order[(size_t)k];
+            S.which.push_back(i);
+            S.rid.push_back(rid[(size_t)i]); S.loc.push_back(loc[(size_t)i]);
+            S.len.push_back(width[i]); S.strand.push_back(strand[i]);
+        }
+        auto cleanup = [&]() {
+            for (Shard &S : sh) {
+                if (S.plan) bsig_plan_free(S.plan);
+                if (S.host) bsig_host_free(S.host);
+            }
+        };
+        for (size_t k = 0; k < nd && rc == BSIG_OK; ++k) {
+            Shard &S = sh[k];
+            rc = bsig_plan_create(g_cache.slots[k].ctx, reads[k], (int64_t)S.which.size(), S.rid.data(), S.loc.data(),
+                                  S.len.data(), S.strand.data(), &prm, &S.plan);
+            if (rc) break;
+            rc = bsig_host_alloc(bsig_plan_cells(S.plan) * (int64_t)sizeof(int32_t), (void **)&S.host);
+            if (rc) break;
+            rc = bsig_plan_run_host_async(S.plan, S.host);        // all GPUs work concurrently
+        }
+        for (size_t k = 0; k < nd; ++k) {
+            const int rc2 = bsig_ctx_sync(g_cache.slots[k].ctx);
+            if (rc == BSIG_OK) rc = rc2;
+        }
+        for (size_t k = 0; k < nd && rc == BSIG_OK; ++k)
+            rc = bsig_scatter_segments((int64_t)sh[k].which.size(), sh[k].host, bsig_plan_offsets(sh[k].plan), out, off,
+                                       sh[k].which.data());
+        cleanup();
+    }
     T[3] = now_s() - t_run;
-    if (owned) bsig_reads_free(reads);
+    release();
     T[4] = now_s() - t_begin;
     return rc;
 }
@@ -362,9 +453,8 @@ void bsig_cache_clear(void)
 {
     std::lock_guard<std::mutex> lock(g_cache.mu);
     g_cache.clear();
-    if (g_cache.ctx) bsig_ctx_destroy(g_cache.ctx);
-    g_cache.ctx = nullptr;
-    g_cache.device = -1;
+    for (DevSlot &d : g_cache.slots) d.destroy();
+    g_cache.slots.clear();
 }
 
 }  // extern "C"

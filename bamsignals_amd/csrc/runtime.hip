@@ -665,6 +665,20 @@ int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
     return rc;
 }
 
+int bsig_plan_run_host_async(bsig_plan *p, int32_t *out_host)
+{
+    if (!p) return fail(BSIG_ERR_ARG, "plan is NULL");
+    const int64_t cells = p->off.back();
+    if (cells == 0) return BSIG_OK;
+    if (!out_host) return fail(BSIG_ERR_ARG, "output buffer is NULL");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    if (!p->d_out) HIP_TRY(p->pool.alloc(&p->d_out, (size_t)cells));
+    const int rc = bsig_plan_run(p, p->d_out);
+    if (rc != BSIG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, p->d_out, cells * sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream));
+    return BSIG_OK;
+}
+
 int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
 {
     if (!p || !s) return fail(BSIG_ERR_ARG, "NULL argument");

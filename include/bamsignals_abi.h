@@ -154,6 +154,9 @@ int bsig_plan_get_stats(bsig_plan *plan, bsig_plan_stats *stats);
 int bsig_plan_run(bsig_plan *plan, int32_t *out_dev);
 /* run + copy to host memory + synchronise                                                      */
 int bsig_plan_run_host(bsig_plan *plan, int32_t *out_host);
+/* the same without the final synchronisation (out_host should be page-locked, bsig_host_alloc):
+ * lets one host thread keep several GPUs busy; finish with bsig_ctx_sync() on the plan's context */
+int bsig_plan_run_host_async(bsig_plan *plan, int32_t *out_host);
 void bsig_plan_free(bsig_plan *plan);
 
 /* one-shot: columns already in HBM -> host result (upload ranges, run, download)               */
@@ -191,7 +194,9 @@ void bsig_bam_decode_timing(double *t6);
  * Ranges come as GRanges slots flattened by the shim (ref: parseRegions, src/bamsignals.cpp:
  * 92-135): seq_code[i] indexes seq_levels (the factor levels of seqnames, mapped to BAM ids BY
  * NAME), start is 1-based, strand is +1 / -1 / 0.  out/off as in bsig_layout().
- * device < 0: env BAMSIGNALS_DEVICE or 0.  maxgap is accepted for signature parity with the
+ * device < 0: the GPUs listed in env BAMSIGNALS_DEVICES ("0,1,...,7": the sorted ranges are dealt
+ * round-robin to them, one stream per GPU, results reassembled on the host), else env
+ * BAMSIGNALS_DEVICE, else GPU 0.  maxgap is accepted for signature parity with the
  * reference (ref: src/bamsignals.cpp:446,476) and does not influence the result.
  * ------------------------------------------------------------------------------------------ */
 /* replaces bamsignals_pileup_core (ref: src/RcppExports.cpp:33-52 -> src/bamsignals.cpp:444-461) */

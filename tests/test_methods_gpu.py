@@ -154,3 +154,27 @@ def test_file_level_on_synthetic_bam_with_gapped_cigars(tmp_path):
         else:
             os.environ["BAMSIGNALS_DECODE"] = old
         _lib.load().bsig_cache_clear()
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_single_process_multi_gpu_sharding(regions, expected_grid, devices, monkeypatch):
+    """BAMSIGNALS_DEVICES: one process deals the sorted ranges round-robin to several GPU contexts
+    and reassembles the shards.  This pool has one GPU per box, so the same GPU is listed several
+    times: separate contexts, streams and resident copies, same code path."""
+    from bamsignals_amd import _lib, bamCount, bamCoverage, bamProfile
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", devices)
+    _lib.load().bsig_cache_clear()
+    try:
+        for decode in ("all", "regions"):
+            monkeypatch.setenv("BAMSIGNALS_DECODE", decode)
+            _lib.load().bsig_cache_clear()
+            for rep in range(2):                      # second round: reads cached on every slot
+                sig = bamProfile(bampath, regions, ss=True, shift=100, paired_end="midpoint", tlenFilter=(50, 200), verbose=False)
+                got = np.concatenate([m.T.reshape(-1) for m in sig.as_list()])
+                assert np.array_equal(got, expected_grid["profile|shift=100,mapq=0,ss=1,pe=midpoint,tf=50_200"])
+                cnt = bamCount(bampath, regions, verbose=False)
+                assert np.array_equal(cnt, expected_grid["count|shift=0,mapq=0,ss=0,pe=ignore,tf=NULL"])
+                cov = bamCoverage(bampath, regions, paired_end="extend", verbose=False)
+                assert np.array_equal(np.concatenate(cov.as_list()), expected_grid["coverage|mapq=0,pe=extend,tf=NULL"])
+    finally:
+        _lib.load().bsig_cache_clear()
