@@ -51,20 +51,19 @@ def main():
         plans[0].run_device(outs[0].data_ptr())
         torch.cuda.synchronize()
         st = stamps.cpu().numpy().reshape(-1, 8)
-    t0 = st[:, 0].min()
-    rel = (st[:, :5] - t0).astype(np.float64)
-    clk = 100e6   # s_memtime ticks at the constant 100 MHz reference on gfx950? report raw ticks too
-    print("items", n_items, " kernel span (ticks):", rel[:, 4].max())
+    # s_memrealtime: 100 MHz reference clock shared by all XCDs -> microseconds
+    rel = (st[:, :5] - st[:, 0].min()).astype(np.float64) / 100.0
+    print("items", n_items, " kernel span (us):", rel[:, 4].max())
     names = ["start->item+windows+zero", "loads+process", "LDS->global issue", "stores drain"]
     for k in range(4):
         d = rel[:, k + 1] - rel[:, k]
-        print(f"{names[k]:28s} median {np.median(d):9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f}  max {d.max():9.0f}")
+        print(f"{names[k]:28s} median {np.median(d):9.2f}  p10 {np.percentile(d,10):9.2f}  p90 {np.percentile(d,90):9.2f}  max {d.max():9.2f}")
     life = rel[:, 4] - rel[:, 0]
-    print(f"{'lifetime':28s} median {np.median(life):9.0f}  p10 {np.percentile(life,10):9.0f}  p90 {np.percentile(life,90):9.0f}")
+    print(f"{'lifetime':28s} median {np.median(life):9.2f}  p10 {np.percentile(life,10):9.2f}  p90 {np.percentile(life,90):9.2f}")
     starts = np.sort(rel[:, 0])
-    print("start time deciles:", [int(x) for x in np.percentile(starts, np.arange(0, 101, 10))])
+    print("start time deciles:", [round(float(x), 2) for x in np.percentile(starts, np.arange(0, 101, 10))])
     ends = np.sort(rel[:, 4])
-    print("end   time deciles:", [int(x) for x in np.percentile(ends, np.arange(0, 101, 10))])
+    print("end   time deciles:", [round(float(x), 2) for x in np.percentile(ends, np.arange(0, 101, 10))])
     xcc = (st[:, 5] >> 32) & 0xF
     print("workgroups per XCC:", np.bincount(xcc.astype(np.int64), minlength=8))
     # concurrency: how many workgroups alive over time
@@ -72,6 +71,14 @@ def main():
     ev = ev[np.argsort(ev[:, 0])]
     alive = np.cumsum(ev[:, 1])
     print("max workgroups alive:", int(alive.max()), " mean alive:", float(np.sum(alive[:-1] * np.diff(ev[:, 0])) / ev[-1, 0]))
+    # timeline in 20 slices of the kernel span: workgroups alive, and how many are in each phase
+    span = rel[:, 4].max()
+    print("slice  alive  in:setup  in:reads  in:store-issue  in:drain   started  finished")
+    for k in range(20):
+        t = (k + 0.5) * span / 20
+        al = (rel[:, 0] <= t) & (rel[:, 4] > t)
+        ph = [int(np.sum((rel[:, j] <= t) & (rel[:, j + 1] > t))) for j in range(4)]
+        print(f"{k:5d} {int(al.sum()):6d} {ph[0]:9d} {ph[1]:9d} {ph[2]:15d} {ph[3]:9d} {int((rel[:, 0] <= t).sum()):9d} {int((rel[:, 4] <= t).sum()):9d}")
 
 
 if __name__ == "__main__":
