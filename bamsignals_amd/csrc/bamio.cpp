@@ -282,14 +282,7 @@ struct MappedFile {
     }
 };
 
-// one BGZF block (SAM spec 4.1)
-struct Block {
-    uint64_t coff;       // file offset of the block
-    uint32_t csize;      // whole block
-    uint32_t doff;       // offset of the deflate data inside the block
-    uint32_t dlen;       // deflate bytes
-    uint32_t isize;      // uncompressed bytes
-};
+using Block = BgzfBlock;
 
 // parses the block header at file offset `off`; false on a malformed block
 bool parse_block(const MappedFile &f, uint64_t off, Block &b)
@@ -538,6 +531,60 @@ static int inflate_batch(const MappedFile &f, const std::vector<Block> &blocks, 
     });
     if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
     return 0;
+}
+
+// ---- the BGZF layer on its own (device-side record decode) ------------------------------------
+struct BgzfFile::Impl {
+    MappedFile f;
+    std::vector<Block> blocks;
+};
+BgzfFile::BgzfFile() : p_(new Impl) {}
+BgzfFile::~BgzfFile() { delete p_; }
+int BgzfFile::open(const std::string &path)
+{
+    if (p_->f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    p_->blocks.clear();
+    return scan_blocks(p_->f, path, p_->blocks);
+}
+const std::vector<BgzfBlock> &BgzfFile::blocks() const { return p_->blocks; }
+const uint8_t *BgzfFile::data() const { return p_->f.data; }
+size_t BgzfFile::size() const { return p_->f.size; }
+int BgzfFile::inflate(size_t b0, size_t b1, uint8_t *dst, int threads) const
+{
+    if (b0 >= b1) return 0;
+    std::vector<uint64_t> uoff(b1 - b0 + 1, 0);
+    for (size_t k = b0; k < b1; ++k) uoff[k - b0 + 1] = uoff[k - b0] + p_->blocks[k].isize;
+    std::atomic<int> bad(0);
+    const MappedFile &f = p_->f;
+    const std::vector<Block> &blocks = p_->blocks;
+    parallel_for((int64_t)(b1 - b0), n_threads(threads), [&](int64_t i, int) {
+        static thread_local Inflater inf;
+        const Block &b = blocks[b0 + (size_t)i];
+        if (!inf.run(f.data + b.coff + b.doff, b.dlen, dst + uoff[(size_t)i], b.isize)) bad = 1;
+    });
+    if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+    return 0;
+}
+
+int64_t bam_header_bytes(const uint8_t *p, size_t n)
+{
+    if (n < 12) return -1;
+    if (memcmp(p, "BAM\1", 4) != 0) return -2;
+    const int32_t l_text = rdi32(p + 4);
+    if (l_text < 0) return -2;
+    uint64_t o = 8 + (uint64_t)l_text;
+    if (o + 4 > n) return -1;
+    const int32_t n_ref = rdi32(p + o);
+    if (n_ref < 0) return -2;
+    o += 4;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (o + 4 > n) return -1;
+        const int32_t l_name = rdi32(p + o);
+        if (l_name < 0) return -2;
+        o += 4 + (uint64_t)l_name + 4;
+        if (o > n) return -1;
+    }
+    return (int64_t)o;
 }
 
 namespace {

@@ -73,6 +73,36 @@ struct BaiIndex {
 
 struct Region { int32_t rid; int64_t beg, end; };   // 0-based half-open
 
+// one BGZF block (SAM spec 4.1)
+struct BgzfBlock {
+    uint64_t coff;       // file offset of the block
+    uint32_t csize;      // whole block
+    uint32_t doff;       // offset of the deflate data inside the block
+    uint32_t dlen;       // deflate bytes
+    uint32_t isize;      // uncompressed bytes
+};
+
+// The BGZF layer of a file on its own, for the device-side record decode (devdecode.hip): the
+// memory-mapped file, its block table, and the thread-pool inflate of a run of blocks.
+class BgzfFile {
+public:
+    BgzfFile();
+    ~BgzfFile();
+    int open(const std::string &path);                        // maps the file and scans every block header
+    const std::vector<BgzfBlock> &blocks() const;
+    const uint8_t *data() const;                              // the mapped (compressed) file
+    size_t size() const;
+    // inflates blocks [b0, b1) back to back into dst (sum of their isize bytes); threads <= 0: default
+    int inflate(size_t b0, size_t b1, uint8_t *dst, int threads) const;
+private:
+    struct Impl;
+    Impl *p_;
+};
+
+// bytes in front of the first record of an uncompressed BAM stream (magic, text, reference
+// table), or -1 if `n` bytes do not hold the whole header yet, -2 if it is not a BAM stream
+int64_t bam_header_bytes(const uint8_t *p, size_t n);
+
 // Whole file -> columns.  threads <= 0: hardware concurrency.
 int bam_decode_all(const std::string &path, int threads, BamHeader &hdr, HostColumns &cols);
 // Only the BGZF blocks the index lists for `regions` (a superset of the overlapping records,

@@ -1,0 +1,399 @@
+// Device-side BAM record decode ("BAM record -> columns at scale").
+//
+// The CPU keeps only what is inherently serial or I/O: scanning the BGZF block headers and
+// inflating the blocks (thread pool, straight into page-locked buffers that travel to HBM while
+// the next batch inflates).  Everything behind the uncompressed stream runs on the GPU:
+//
+//   k_bam_walk     one lane per BGZF block follows the block_size links of the records that START
+//                  in its block (what bam_itr_next does one record at a time, ref:
+//                  src/bamsignals.cpp:271), validates them and notes their offsets;
+//   k_bam_extract  one thread per record: core fields -> pos / flag / mapq / tlen columns,
+//                  bam_endpos - 1 from the CIGAR (ref: src/bamsignals.cpp:16-18), first read of
+//                  every reference;
+//   then the same HBM layout as bsig_reads_upload (runtime.hip: layout_from_device).
+//
+// A lane can only start where a record starts.  Files written by htslib/samtools and by this
+// library's BamWriter never split a record over two BGZF blocks unless it is larger than a block,
+// so every block start is a record start (or lies inside an oversized record, which the host
+// check below recognises).  Files that break this (htsjdk writes records across block borders),
+// CG-tag CIGARs, unsorted or damaged files are NOT handled here: the call returns
+// kNeedsCpuPath and the caller takes the CPU decode (bamio.cpp), which also owns every error
+// message.  Results are identical by construction and by tests/test_methods_gpu.py.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bamio.h"
+#include "runtime_internal.h"
+
+using bsig::fail;
+
+namespace {
+
+constexpr int kMaxRecPerSeg = 1824;          // a record is >= 36 bytes, a block <= 65536
+constexpr uint32_t kFlagBad = 1u;            // malformed / truncated / too many records
+constexpr uint32_t kFlagUnsorted = 2u;
+constexpr uint32_t kFlagCg = 4u;             // CG-tag placeholder CIGAR (SAM spec 4.2.2)
+
+struct SegSummary {
+    uint64_t end;                            // stream offset behind the last record walked
+    uint32_t n_placed, n_unplaced;
+    int32_t first_rid, first_pos, last_rid, last_pos;
+    uint32_t flags, pad;
+};
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);              // records are byte-aligned
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ stream, uint64_t total,
+                                                 const uint64_t *__restrict__ seg_start, int64_t n_seg,
+                                                 int32_t n_ref, uint16_t *__restrict__ off16,
+                                                 SegSummary *__restrict__ sum)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    uint64_t o = seg_start[s];
+    const uint64_t base = o, limit = seg_start[s + 1];
+    uint16_t *mine = off16 + s * kMaxRecPerSeg;
+    uint32_t np = 0, nu = 0, flags = 0;
+    int32_t frid = -1, fpos = -1, prid = -1, ppos = -1;
+    while (o < limit) {
+        if (o + 36 > total) { flags |= kFlagBad; break; }
+        const int32_t bs = (int32_t)ld32(stream + o);
+        if (bs < 32) { flags |= kFlagBad; break; }
+        const uint64_t next = o + 4 + (uint64_t)bs;
+        if (next > total) { flags |= kFlagBad; break; }
+        const int32_t rid = (int32_t)ld32(stream + o + 4);
+        if (rid < 0) { ++nu; o = next; continue; }                   // unplaced: skipped
+        if (rid >= n_ref) { flags |= kFlagBad; break; }
+        const int32_t pos = (int32_t)ld32(stream + o + 8);
+        const uint32_t l_name = ld32(stream + o + 12) & 0xFFu;
+        const uint32_t n_cig = ld32(stream + o + 16) & 0xFFFFu;
+        if (36 + (uint64_t)l_name + 4 * (uint64_t)n_cig > 4 + (uint64_t)bs) { flags |= kFlagBad; break; }
+        if (n_cig == 2 && 36 + (uint64_t)l_name + 8 <= 4 + (uint64_t)bs) {
+            const uint32_t c0 = ld32(stream + o + 36 + l_name), c1 = ld32(stream + o + 40 + l_name);
+            const int32_t l_seq = (int32_t)ld32(stream + o + 20);
+            if ((c0 & 0xFu) == 4u && (int32_t)(c0 >> 4) == l_seq && (c1 & 0xFu) == 3u) flags |= kFlagCg;
+        }
+        if (np == 0) { frid = rid; fpos = pos; }
+        else if (rid < prid || (rid == prid && pos < ppos)) flags |= kFlagUnsorted;
+        if (np >= (uint32_t)kMaxRecPerSeg) { flags |= kFlagBad; break; }
+        mine[np++] = (uint16_t)(o - base);
+        prid = rid; ppos = pos;
+        o = next;
+    }
+    SegSummary r;
+    r.end = o; r.n_placed = np; r.n_unplaced = nu;
+    r.first_rid = frid; r.first_pos = fpos; r.last_rid = prid; r.last_pos = ppos;
+    r.flags = flags; r.pad = 0;
+    sum[s] = r;
+}
+
+constexpr int kExtractThreads = 256;
+
+__global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
+    const uint8_t *__restrict__ stream, const uint64_t *__restrict__ seg_start,
+    const uint16_t *__restrict__ off16, const uint32_t *__restrict__ seg_n,
+    const int64_t *__restrict__ seg_base, const int32_t *__restrict__ seg_prev_rid,
+    int32_t *__restrict__ pos, uint16_t *__restrict__ flag, uint8_t *__restrict__ mapq,
+    int32_t *__restrict__ tlen, int32_t *__restrict__ end, long long *__restrict__ ref_first)
+{
+    const int64_t s = blockIdx.x;
+    const uint32_t n = seg_n[s];
+    if (n == 0) return;
+    const uint8_t *seg = stream + seg_start[s];
+    const uint16_t *offs = off16 + s * kMaxRecPerSeg;
+    const int64_t base = seg_base[s];
+    for (uint32_t k = threadIdx.x; k < n; k += kExtractThreads) {
+        const uint8_t *r = seg + offs[k];
+        const int32_t rid = (int32_t)ld32(r + 4);
+        const int32_t p = (int32_t)ld32(r + 8);
+        const uint32_t w12 = ld32(r + 12), w16 = ld32(r + 16);
+        const uint32_t l_name = w12 & 0xFFu, n_cig = w16 & 0xFFFFu, fl = w16 >> 16;
+        // bam_endpos - 1: M(0) D(2) N(3) =(7) X(8) consume the reference; 0x4 or nothing -> 1 base
+        int64_t rlen = 0;
+        if (!(fl & 0x4u)) {
+            const uint8_t *c = r + 36 + l_name;
+            for (uint32_t q = 0; q < n_cig; ++q) {
+                const uint32_t op = ld32(c + 4 * q);
+                if ((0x18Du >> (op & 0xFu)) & 1u) rlen += op >> 4;
+            }
+        }
+        if (rlen == 0) rlen = 1;
+        const int64_t i = base + k;
+        pos[i] = p;
+        flag[i] = (uint16_t)fl;
+        mapq[i] = (uint8_t)((w12 >> 8) & 0xFFu);
+        tlen[i] = (int32_t)ld32(r + 32);
+        end[i] = (int32_t)(p + rlen - 1);
+        const int32_t prev = k ? (int32_t)ld32(seg + offs[k - 1] + 4) : seg_prev_rid[s];
+        for (int32_t q = prev + 1; q <= rid; ++q) ref_first[q] = i;     // each q is written once
+    }
+}
+
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// page-locked staging for the uncompressed stream: allocated once per process (pinning memory is
+// slow), two halves so that one travels to HBM while the thread pool inflates into the other
+struct Staging {
+    std::mutex mu;
+    uint8_t *buf[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int ensure(size_t bytes)
+    {
+        if (cap >= bytes) return BSIG_OK;
+        for (int k = 0; k < 2; ++k) {
+            if (buf[k]) (void)hipHostFree(buf[k]);
+            buf[k] = nullptr;
+        }
+        cap = 0;
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipHostMalloc((void **)&buf[k], bytes, hipHostMallocDefault));
+            if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        cap = bytes;
+        return BSIG_OK;
+    }
+};
+Staging g_staging;
+
+thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
+
+}  // namespace
+
+namespace bsig {
+
+// > 0: the file (or this build's limits) needs the CPU decode path; nothing was allocated
+constexpr int kNeedsCpuPath = 1;
+
+// Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
+int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, bsig_reads **out)
+{
+    double *T = g_dev_decode_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
+    *out = nullptr;
+    BgzfFile f;
+    int rc = f.open(path);
+    if (rc) return rc;
+    const std::vector<BgzfBlock> &blocks = f.blocks();
+    if (blocks.empty()) return kNeedsCpuPath;
+    const size_t nb = blocks.size();
+    std::vector<uint64_t> uoff(nb + 1, 0);
+    for (size_t k = 0; k < nb; ++k) {
+        if (blocks[k].isize > 65536u) return kNeedsCpuPath;
+        uoff[k + 1] = uoff[k] + blocks[k].isize;
+    }
+    const uint64_t total = uoff[nb];
+    uint64_t max_stream = 64ull << 30;
+    if (const char *e = getenv("BAMSIGNALS_DEVICE_DECODE_MAX_GB")) max_stream = (uint64_t)atoll(e) << 30;
+    if (total < 12 || total > max_stream) return kNeedsCpuPath;
+    T[0] = now_s() - t_begin;
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevPool tmp;
+    uint8_t *d_stream = nullptr;
+    HIP_TRY(tmp.alloc(&d_stream, (size_t)total + 64));
+
+    // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ----------------
+    size_t batch_bytes = 128u << 20;
+    if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {          // testing: many small batches
+        const long v = atol(e);
+        if (v > 0) batch_bytes = (size_t)v * 65536u;
+    }
+    std::lock_guard<std::mutex> lock(g_staging.mu);
+    rc = g_staging.ensure(batch_bytes);
+    if (rc) return rc;
+    BamHeader hdr;
+    int64_t header_end = -1;
+    std::vector<uint8_t> head;                 // the first bytes of the stream, for the header
+    int half = 0;
+    bool used[2] = {false, false};
+    double t_inflate = 0, t_wait = 0;
+    for (size_t b0 = 0; b0 < nb;) {
+        size_t b1 = b0;
+        uint64_t bytes = 0;
+        while (b1 < nb && bytes + blocks[b1].isize <= batch_bytes) bytes += blocks[b1++].isize;
+        if (b1 == b0) return kNeedsCpuPath;    // cannot happen: a block is <= 64 KiB
+        double t0 = now_s();
+        if (used[half]) HIP_TRY(hipEventSynchronize(g_staging.ev[half]));
+        t_wait += now_s() - t0;
+        t0 = now_s();
+        rc = f.inflate(b0, b1, g_staging.buf[half], threads);
+        if (rc) { (void)hipStreamSynchronize(st); return kNeedsCpuPath; }   // the CPU path reports the error
+        t_inflate += now_s() - t0;
+        if (header_end < 0) {
+            // where the records start: read off the head of the stream (it spans several batches only
+            // in the small-batch test mode; only then is anything copied)
+            if (head.empty()) header_end = bam_header_bytes(g_staging.buf[half], bytes);
+            if (header_end == -1) {
+                head.insert(head.end(), g_staging.buf[half], g_staging.buf[half] + bytes);
+                header_end = bam_header_bytes(head.data(), head.size());
+            }
+            if (header_end == -2) { (void)hipStreamSynchronize(st); return kNeedsCpuPath; }
+            if (header_end >= 0) std::vector<uint8_t>().swap(head);
+        }
+        if (bytes) HIP_TRY(hipMemcpyAsync(d_stream + uoff[b0], g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(g_staging.ev[half], st));
+        used[half] = true;
+        half ^= 1;
+        b0 = b1;
+    }
+    T[1] = t_inflate;
+    T[2] = t_wait;
+    if (header_end < 0) { (void)hipStreamSynchronize(st); return kNeedsCpuPath; }
+    rc = bam_read_header(path, hdr);
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    const int32_t n_ref = (int32_t)hdr.names.size();
+
+    // ---- segments: the rest of the block the header ends in, then one per BGZF block -------------
+    const double t_gpu = now_s();
+    std::vector<uint64_t> seg_start;
+    seg_start.push_back((uint64_t)header_end);
+    for (size_t k = 1; k <= nb; ++k)
+        if (uoff[k] > (uint64_t)header_end) seg_start.push_back(uoff[k]);
+    if (seg_start.back() != total) seg_start.push_back(total);      // header ends exactly at the stream end
+    const int64_t n_seg = (int64_t)seg_start.size() - 1;
+    uint64_t *d_seg_start = nullptr;
+    uint16_t *d_off16 = nullptr;
+    SegSummary *d_sum = nullptr;
+    std::vector<SegSummary> sum((size_t)std::max<int64_t>(n_seg, 1));
+    if (n_seg > 0) {
+        HIP_TRY(tmp.alloc(&d_seg_start, seg_start.size()));
+        HIP_TRY(tmp.alloc(&d_off16, (size_t)n_seg * kMaxRecPerSeg));
+        HIP_TRY(tmp.alloc(&d_sum, (size_t)n_seg));
+        HIP_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_stream, total, d_seg_start,
+                           n_seg, n_ref, d_off16, d_sum);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // ---- host: every accepted segment must begin where its predecessor ended ---------------------
+    std::vector<uint32_t> seg_n((size_t)std::max<int64_t>(n_seg, 1), 0);
+    std::vector<int64_t> seg_base((size_t)std::max<int64_t>(n_seg, 1), 0);
+    std::vector<int32_t> seg_prev((size_t)std::max<int64_t>(n_seg, 1), -1);
+    uint64_t o = (uint64_t)header_end;
+    int64_t n_reads = 0;
+    int32_t last_rid = -1, last_pos = -1;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        if (seg_start[(size_t)s] < o) continue;                    // inside an oversized record
+        if (seg_start[(size_t)s] > o) return kNeedsCpuPath;        // a record crosses a block border
+        const SegSummary &g = sum[(size_t)s];
+        if (g.flags) return kNeedsCpuPath;                         // damaged, unsorted or CG-tag CIGARs
+        if (g.n_placed) {
+            if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return kNeedsCpuPath;
+            seg_n[(size_t)s] = g.n_placed;
+            seg_base[(size_t)s] = n_reads;
+            seg_prev[(size_t)s] = last_rid;
+            last_rid = g.last_rid; last_pos = g.last_pos;
+            n_reads += g.n_placed;
+        }
+        o = g.end;
+    }
+    if (o != total) return kNeedsCpuPath;                           // truncated last record
+
+    // ---- columns ---------------------------------------------------------------------------------
+    bsig_reads *R = new bsig_reads;
+    R->ctx = ctx;
+    std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
+    auto bail = [&](int code) { delete R; return code; };
+    if (n_reads == 0 || n_ref == 0) {
+        rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return bail(rc);
+        *out = R;
+        T[4] = now_s() - t_begin;
+        return BSIG_OK;
+    }
+    int32_t *d_pos = nullptr, *d_end = nullptr, *d_tlen = nullptr;
+    uint16_t *d_flag = nullptr;
+    uint8_t *d_mapq = nullptr;
+    uint32_t *d_seg_n = nullptr;
+    int64_t *d_seg_base = nullptr;
+    int32_t *d_seg_prev = nullptr;
+    long long *d_ref_first = nullptr;
+#define DD_TRY(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return bail(fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,         \
+                             "HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+    DD_TRY(tmp.alloc(&d_pos, (size_t)n_reads));
+    DD_TRY(tmp.alloc(&d_end, (size_t)n_reads));
+    DD_TRY(tmp.alloc(&d_tlen, (size_t)n_reads));
+    DD_TRY(tmp.alloc(&d_flag, (size_t)n_reads));
+    DD_TRY(tmp.alloc(&d_mapq, (size_t)n_reads));
+    DD_TRY(tmp.alloc(&d_seg_n, (size_t)n_seg));
+    DD_TRY(tmp.alloc(&d_seg_base, (size_t)n_seg));
+    DD_TRY(tmp.alloc(&d_seg_prev, (size_t)n_seg));
+    DD_TRY(tmp.alloc(&d_ref_first, (size_t)n_ref + 1));
+    DD_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    DD_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    DD_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    DD_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
+    hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)n_seg), dim3(kExtractThreads), 0, st, d_stream, d_seg_start, d_off16,
+                       d_seg_n, d_seg_base, d_seg_prev, d_pos, d_flag, d_mapq, d_tlen, d_end, d_ref_first);
+    DD_TRY(hipGetLastError());
+    std::vector<long long> ref_first((size_t)n_ref + 1, -1);
+    DD_TRY(hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
+    DD_TRY(hipStreamSynchronize(st));
+#undef DD_TRY
+    ref_off[(size_t)n_ref] = n_reads;
+    for (int32_t r = n_ref - 1; r >= 0; --r)
+        ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
+    ref_off[0] = 0;
+    T[3] = now_s() - t_gpu;
+
+    const double t_lay = now_s();
+    rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), d_pos, d_end, d_flag, d_mapq, d_tlen);
+    if (rc) return bail(rc);
+    T[5] = now_s() - t_lay;
+    T[4] = now_s() - t_begin;
+    *out = R;
+    return BSIG_OK;
+}
+
+}  // namespace bsig
+
+extern "C" {
+
+int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_reads **reads)
+{
+    if (!ctx || !bam || !reads) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_from_bam");
+    *reads = nullptr;
+    const char *path = bsig_bam_path(bam);
+    const char *mode = getenv("BAMSIGNALS_DEVICE_DECODE");        // "0": always the CPU decode
+    int rc = bsig::kNeedsCpuPath;
+    if (!(mode && !strcmp(mode, "0"))) rc = bsig::reads_from_bam_device(ctx, path, threads, reads);
+    if (rc != bsig::kNeedsCpuPath) return rc;
+    if (mode && !strcmp(mode, "require"))                          // testing: no silent change of path
+        return fail(BSIG_ERR_FORMAT, "%s needs the CPU decode path (BAMSIGNALS_DEVICE_DECODE=require)", path);
+    bsig_columns cols;
+    rc = bsig_bam_decode(bam, -1, nullptr, nullptr, nullptr, threads, &cols);
+    if (rc) return rc;
+    for (int k = 0; k < 6; ++k) g_dev_decode_timing[k] = 0;
+    return bsig_reads_upload(ctx, &cols, reads);
+}
+
+void bsig_device_decode_timing(double *t6)
+{
+    for (int k = 0; k < 6; ++k) t6[k] = g_dev_decode_timing[k];
+}
+
+}  // extern "C"

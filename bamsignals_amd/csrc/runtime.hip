@@ -38,59 +38,7 @@ int fail(int code, const char *fmt, ...)
 
 using bsig::fail;
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,          \
-                        "HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),     \
-                        __FILE__, __LINE__, #expr);                                            \
-    } while (0)
-
-namespace {
-
-// owns a set of device allocations
-struct DevPool {
-    std::vector<void *> ptrs;
-    int64_t bytes = 0;
-    template <typename T>
-    hipError_t alloc(T **p, size_t count)
-    {
-        void *q = nullptr;
-        const size_t nbytes = std::max<size_t>(count * sizeof(T), 16);
-        hipError_t e = hipMalloc(&q, nbytes);
-        if (e != hipSuccess) { *p = nullptr; return e; }
-        ptrs.push_back(q);
-        bytes += (int64_t)nbytes;
-        *p = (T *)q;
-        return hipSuccess;
-    }
-    void release()
-    {
-        for (void *p : ptrs) (void)hipFree(p);
-        ptrs.clear();
-        bytes = 0;
-    }
-    ~DevPool() { release(); }
-};
-
-}  // namespace
-
-struct bsig_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = false;
-};
-
-struct bsig_reads {
-    bsig_ctx *ctx = nullptr;
-    BsigReadsDev dev{};
-    DevPool pool;
-    bsig_reads_info info{};
-    int32_t n_ref = 0;
-    std::vector<uint32_t> ref_unit0, ref_units;
-    std::vector<int32_t> ref_len;
-};
+#include "runtime_internal.h"
 
 struct bsig_plan {
     bsig_ctx *ctx = nullptr;
@@ -202,10 +150,14 @@ void bsig_host_free(void *ptr)
 // ---------------------------------------------------------------------------------------------
 // reads -> HBM
 // ---------------------------------------------------------------------------------------------
-static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
+}  // extern "C"
+
+// The resident layout from device columns; shared by bsig_reads_upload (host columns) and the
+// device-side BAM decode (devdecode.hip).
+int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_ref, const int32_t *ref_len,
+                             const int64_t *ref_off, const int32_t *d_pos, const int32_t *d_end,
+                             const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tlen)
 {
-    const int64_t n = cols->n_reads;
-    const int32_t n_ref = cols->n_ref;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipSetDevice(ctx->device));
 
@@ -213,11 +165,11 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
     R->n_ref = n_ref;
     R->ref_unit0.resize(n_ref);
     R->ref_units.resize(n_ref);
-    R->ref_len.assign(cols->ref_len, cols->ref_len + n_ref);
+    R->ref_len.assign(ref_len, ref_len + n_ref);
     uint64_t total_units = 0;
     for (int r = 0; r < n_ref; ++r) {
-        if (cols->ref_len[r] < 0) return fail(BSIG_ERR_ARG, "negative length of reference %d", r);
-        const uint64_t u = ((uint64_t)cols->ref_len[r] >> BSIG_REF_UNIT_SHIFT) + 1;
+        if (ref_len[r] < 0) return fail(BSIG_ERR_ARG, "negative length of reference %d", r);
+        const uint64_t u = ((uint64_t)ref_len[r] >> BSIG_REF_UNIT_SHIFT) + 1;
         if (total_units + u >= (1ull << 31)) return fail(BSIG_ERR_ARG, "genome too large for the bucket index");
         R->ref_unit0[r] = (uint32_t)total_units;
         R->ref_units[r] = (uint32_t)u;
@@ -231,34 +183,7 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) R->dev.cls[c] = BsigClassCols{};
         return BSIG_OK;
     }
-
     DevPool tmp;
-    int32_t *d_pos, *d_end, *d_tlen;
-    uint16_t *d_flag;
-    uint8_t *d_mapq;
-    HIP_TRY(tmp.alloc(&d_pos, n));
-    HIP_TRY(tmp.alloc(&d_end, n));
-    HIP_TRY(tmp.alloc(&d_tlen, n));
-    HIP_TRY(tmp.alloc(&d_flag, n));
-    HIP_TRY(tmp.alloc(&d_mapq, n));
-    HIP_TRY(hipMemcpyAsync(d_pos, cols->pos, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_tlen, cols->tlen, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_flag, cols->flag, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_mapq, cols->mapq, n * sizeof(uint8_t), hipMemcpyHostToDevice, st));
-    if (cols->end) {
-        HIP_TRY(hipMemcpyAsync(d_end, cols->end, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    } else {
-        const int64_t n_ops = cols->cigar_off[n];
-        if (cols->cigar_off[0] != 0 || n_ops < 0) return fail(BSIG_ERR_ARG, "cigar_off must start at 0 and be non-decreasing");
-        int64_t *d_coff;
-        uint32_t *d_cig;
-        HIP_TRY(tmp.alloc(&d_coff, n + 1));
-        HIP_TRY(tmp.alloc(&d_cig, n_ops));
-        HIP_TRY(hipMemcpyAsync(d_coff, cols->cigar_off, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        if (n_ops) HIP_TRY(hipMemcpyAsync(d_cig, cols->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(bsig::launch_cigar_end(n, d_pos, d_flag, d_coff, d_cig, d_end, st));
-    }
-
     // span classes: per-chunk counts -> host exclusive scan
     const int64_t n_chunks = bsig::prep_chunks(n);
     uint32_t *d_counts;
@@ -268,7 +193,7 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
     HIP_TRY(hipMemsetAsync(d_maxspan, 0, (BSIG_MAX_CLASSES + 1) * sizeof(int32_t), st));
     int64_t *d_ref_off;
     HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
-    HIP_TRY(hipMemcpyAsync(d_ref_off, cols->ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ref_off, ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
     HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_pos, d_end, d_counts, d_maxspan, st));
     std::vector<uint32_t> counts(n_chunks * BSIG_MAX_CLASSES);
     int32_t maxspan[BSIG_MAX_CLASSES + 1];
@@ -342,6 +267,49 @@ static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
     HIP_TRY(hipStreamSynchronize(st));
     R->info.hbm_bytes = R->pool.bytes;
     return BSIG_OK;
+}
+
+extern "C" {
+
+static int upload_impl(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads *R)
+{
+    const int64_t n = cols->n_reads;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int r = 0; r < cols->n_ref; ++r)
+        if (cols->ref_len[r] < 0) return fail(BSIG_ERR_ARG, "negative length of reference %d", r);
+    if (n == 0 || cols->n_ref == 0)
+        return bsig::layout_from_device(ctx, R, n, cols->n_ref, cols->ref_len, cols->ref_off, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr);
+    DevPool tmp;
+    int32_t *d_pos, *d_end, *d_tlen;
+    uint16_t *d_flag;
+    uint8_t *d_mapq;
+    HIP_TRY(tmp.alloc(&d_pos, n));
+    HIP_TRY(tmp.alloc(&d_end, n));
+    HIP_TRY(tmp.alloc(&d_tlen, n));
+    HIP_TRY(tmp.alloc(&d_flag, n));
+    HIP_TRY(tmp.alloc(&d_mapq, n));
+    HIP_TRY(hipMemcpyAsync(d_pos, cols->pos, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_tlen, cols->tlen, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_flag, cols->flag, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_mapq, cols->mapq, n * sizeof(uint8_t), hipMemcpyHostToDevice, st));
+    if (cols->end) {
+        HIP_TRY(hipMemcpyAsync(d_end, cols->end, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    } else {
+        const int64_t n_ops = cols->cigar_off[n];
+        if (cols->cigar_off[0] != 0 || n_ops < 0) return fail(BSIG_ERR_ARG, "cigar_off must start at 0 and be non-decreasing");
+        int64_t *d_coff;
+        uint32_t *d_cig;
+        HIP_TRY(tmp.alloc(&d_coff, n + 1));
+        HIP_TRY(tmp.alloc(&d_cig, n_ops));
+        HIP_TRY(hipMemcpyAsync(d_coff, cols->cigar_off, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (n_ops) HIP_TRY(hipMemcpyAsync(d_cig, cols->cigar, n_ops * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(bsig::launch_cigar_end(n, d_pos, d_flag, d_coff, d_cig, d_end, st));
+    }
+    // layout_from_device synchronises the stream before it returns: tmp may be released then
+    return bsig::layout_from_device(ctx, R, n, cols->n_ref, cols->ref_len, cols->ref_off, d_pos, d_end, d_flag, d_mapq,
+                                    d_tlen);
 }
 
 int bsig_reads_upload(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads **out)

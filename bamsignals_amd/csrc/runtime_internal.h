@@ -1,0 +1,72 @@
+// Internals shared by the host runtime (runtime.hip) and the device-side BAM decode (devdecode.hip).
+#ifndef BSIG_RUNTIME_INTERNAL_H
+#define BSIG_RUNTIME_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/bamsignals_abi.h"
+#include "bsig_types.h"
+#include "host_util.h"
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,          \
+                        "HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__, #expr);                                            \
+    } while (0)
+
+// owns a set of device allocations
+struct DevPool {
+    std::vector<void *> ptrs;
+    int64_t bytes = 0;
+    template <typename T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        void *q = nullptr;
+        const size_t nbytes = std::max<size_t>(count * sizeof(T), 16);
+        hipError_t e = hipMalloc(&q, nbytes);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        ptrs.push_back(q);
+        bytes += (int64_t)nbytes;
+        *p = (T *)q;
+        return hipSuccess;
+    }
+    void release()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+        bytes = 0;
+    }
+    ~DevPool() { release(); }
+};
+
+struct bsig_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+};
+
+struct bsig_reads {
+    bsig_ctx *ctx = nullptr;
+    BsigReadsDev dev{};
+    DevPool pool;
+    bsig_reads_info info{};
+    int32_t n_ref = 0;
+    std::vector<uint32_t> ref_unit0, ref_units;
+    std::vector<int32_t> ref_len;
+};
+
+namespace bsig {
+// Builds the resident HBM layout of R (span classes + bucket indexes, bsig_types.h) from device
+// columns of n reads in BAM order; ref_off is a host array of n_ref + 1 entries.  The input
+// columns are only read.
+int layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_ref, const int32_t *ref_len,
+                       const int64_t *ref_off, const int32_t *d_pos, const int32_t *d_end,
+                       const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tlen);
+}  // namespace bsig
+#endif

@@ -120,6 +120,27 @@ class Reads:
         self.n_reads = n
         self.n_ref = len(ref_len)
 
+    @classmethod
+    def from_bam(cls, ctx, bam, threads=0):
+        """The whole of an open ``bamio.BamFile`` decoded to HBM: BGZF inflate on the CPU thread pool,
+        records -> columns on the GPU (csrc/devdecode.hip; CPU decode where the file needs it)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.ctx = ctx
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_reads_from_bam(ctx._h, bam._h, int(threads), C.byref(h)))
+        self._h = h
+        self.n_ref = len(bam.ref_len)
+        self.n_reads = self.info()["n_reads"]
+        return self
+
+    @staticmethod
+    def device_decode_timing():
+        """Stage seconds of this thread's last ``from_bam`` (all 0 when it took the CPU decode)."""
+        t = (C.c_double * 6)()
+        _lib.load().bsig_device_decode_timing(t)
+        return dict(zip(("block_scan", "inflate", "copy_wait", "gpu_parse", "total", "layout"), list(t)))
+
     def info(self):
         inf = _lib.ReadsInfo()
         _lib.check(self._lib.bsig_reads_get_info(self._h, C.byref(inf)))

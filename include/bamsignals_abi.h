@@ -175,6 +175,7 @@ typedef struct bsig_bam bsig_bam;
  * messages (ref: src/bamsignals.cpp:204,209)                                                  */
 int bsig_bam_open(const char *path, bsig_bam **bam);
 void bsig_bam_close(bsig_bam *bam);
+const char *bsig_bam_path(const bsig_bam *bam);
 int32_t bsig_bam_n_ref(const bsig_bam *bam);
 const char *bsig_bam_ref_name(const bsig_bam *bam, int32_t rid);
 int32_t bsig_bam_ref_len(const bsig_bam *bam, int32_t rid);
@@ -188,6 +189,19 @@ int bsig_bam_decode(bsig_bam *bam, int64_t n_regions, const int32_t *rid, const 
 /* stage timers (seconds) of the calling thread's last whole-file decode: BGZF block scan, waiting
  * for inflate, record-boundary scan, column extraction, total, inflate time on the producer side */
 void bsig_bam_decode_timing(double *t6);
+
+/* Whole BAM -> reads resident in HBM.  The BGZF blocks are inflated by the CPU thread pool straight
+ * into page-locked buffers that travel to HBM while the next batch inflates; record boundaries
+ * (the block_size links bam_itr_next follows, ref: src/bamsignals.cpp:271), the core fields and
+ * bam_endpos are then taken from the uncompressed stream by GPU kernels (csrc/devdecode.hip).
+ * Files whose records cross BGZF block borders, CG-tag CIGARs and damaged or unsorted files take
+ * the CPU decode (bsig_bam_decode + bsig_reads_upload) inside this call: same result, and the CPU
+ * path's error messages.  env BAMSIGNALS_DEVICE_DECODE=0 forces the CPU decode, =require fails
+ * instead of falling back (testing).                                                           */
+int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_reads **reads);
+/* stage seconds of the calling thread's last device-side decode: block scan, CPU inflate, waiting
+ * for the copies, record walk + extraction kernels, total, HBM layout (all 0 after a CPU decode) */
+void bsig_device_decode_timing(double *t6);
 
 /* ------------------------------------------------------------------------------------------
  * File-level drop-in entry points: what the R shim's .Call routines bind.

@@ -57,6 +57,17 @@ def main():
     reads = Reads(ctx, dec["ref_len"], dec["ref_off"], dec["pos"], dec["flag"], dec["mapq"], dec["tlen"],
                   cigar_off=dec["cigar_off"], cigar=dec["cigar"])
     res["upload_and_layout_s"] = time.time() - t
+    # --- the same BAM decoded on the device (CPU inflate -> pinned -> HBM, records -> columns on the GPU)
+    os.environ["BAMSIGNALS_DEVICE_DECODE"] = "require"
+    for rep in ("first", "again"):                   # the first call also pins the staging buffers
+        t = time.time(); rdev = Reads.from_bam(ctx, b); res[f"reads_from_bam_device_{rep}_s"] = time.time() - t
+        res[f"reads_from_bam_device_{rep}_stages_s"] = Reads.device_decode_timing()
+        assert rdev.info() == reads.info()
+        rdev.close()
+    os.environ["BAMSIGNALS_DEVICE_DECODE"] = "0"
+    t = time.time(); rcpu = Reads.from_bam(ctx, b); res["reads_from_bam_cpu_s"] = time.time() - t
+    rcpu.close()
+    os.environ.pop("BAMSIGNALS_DEVICE_DECODE")
     t = time.time()
     plan = Plan(ctx, reads, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=1))
     res["plan_s"] = time.time() - t
@@ -83,6 +94,8 @@ def main():
         os.environ["BAMSIGNALS_DECODE"] = mode
         _lib.load().bsig_cache_clear()
         t = time.time(); sig = bamProfile(bam, gr, verbose=False); res[f"bamProfile_cold_{mode}_s"] = time.time() - t
+        from bamsignals_amd.wrappers import last_call_timing
+        res[f"bamProfile_cold_{mode}_stages_s"] = last_call_timing()
         t = time.time(); sig = bamProfile(bam, gr, verbose=False); res[f"bamProfile_again_{mode}_s"] = time.time() - t
     got = np.concatenate(sig.as_list())
     assert np.array_equal(got, out)

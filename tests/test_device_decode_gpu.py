@@ -1,0 +1,269 @@
+"""GPU: the device-side BAM record decode (csrc/devdecode.hip) against the CPU decode stage and the
+C oracle.  The decode replaces what the reference gets record by record from htslib's
+bam_itr_next (ref: src/bamsignals.cpp:271); the only htslib-written bytes available are the
+reference's fixture BAM, everything else is written by this repo's writer or built by hand from
+the SAM/BAM specification (marked "spec-derived")."""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+BAM = os.path.join(GOLDEN, "randomBam.bam")
+EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from bamsignals_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _bgzf(data, sizes):
+    """BGZF-compress `data`, cutting it into blocks of the given sizes (cycled)."""
+    out, i, k = b"", 0, 0
+    while i < len(data):
+        n = sizes[k % len(sizes)]
+        chunk = data[i:i + n]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        dd = co.compress(chunk) + co.flush()
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(dd) + 25) + dd
+                + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        i += n
+        k += 1
+    return out + EOF_BLOCK
+
+
+def _empty_bai(path, n_ref):
+    with open(path, "wb") as f:
+        f.write(b"BAI\x01" + struct.pack("<i", n_ref) + struct.pack("<ii", 0, 0) * n_ref + struct.pack("<Q", 0))
+
+
+def _results(ctx, reads, ref_len, seed=3):
+    """profile / coverage / count over ranges covering every reference, as one tuple of arrays"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    from bamsignals_amd.synth import synth_ranges, tile_ranges
+    out = []
+    rg = synth_ranges(300, 900, ref_len, seed=seed, jitter=600)
+    tiles = tile_ranges(ref_len, 5000)
+    for mode, args, r in ((_lib.MODE_PROFILE, dict(binsize=1, ss=True, shift=15), rg),
+                          (_lib.MODE_PROFILE, dict(binsize=7, requiredF=66, tlen_filter=(40, 600), pe_mid=True), rg),
+                          (_lib.MODE_COVERAGE, dict(), tiles), (_lib.MODE_COUNT, dict(binsize=-1, ss=True), tiles)):
+        p = Plan(ctx, reads, r["rid"], r["loc"], r["len"], r["strand"], make_params(mode, **args))
+        out.append(p.run_host().copy())
+        p.close()
+    return out
+
+
+def _both_ways(ctx, path, monkeypatch, expect_device=True):
+    """decode `path` on the device and on the CPU; the resident reads must be indistinguishable"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    bam = BamFile(path)
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require" if expect_device else "1")
+    dev = Reads.from_bam(ctx, bam)
+    took_device = Reads.device_decode_timing()["total"] > 0
+    assert took_device == expect_device
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
+    cpu = Reads.from_bam(ctx, bam)
+    assert Reads.device_decode_timing()["total"] == 0
+    assert dev.info() == cpu.info()
+    for a, b in zip(_results(ctx, dev, bam.ref_len), _results(ctx, cpu, bam.ref_len)):
+        assert np.array_equal(a, b)
+    if not expect_device:
+        monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+        with pytest.raises(_lib.BsigError, match="CPU decode path"):
+            Reads.from_bam(ctx, bam)
+    cpu.close()
+    return bam, dev
+
+
+def test_fixture_bam(ctx, monkeypatch, fixture_reads):
+    """the reference's own (htslib-written) BAM: device decode == CPU decode == the fixture columns"""
+    from oracle import oracle_c
+    bam, dev = _both_ways(ctx, BAM, monkeypatch)
+    assert dev.n_reads == 99000
+    fx = fixture_reads
+    orc = oracle_c.OracleReads(fx["ref_off"], fx["bam_pos"], fx["bam_end"], fx["bam_flag"], fx["bam_mapq"], fx["bam_tlen"])
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    from bamsignals_amd.synth import tile_ranges
+    tiles = tile_ranges(bam.ref_len, 777, strand=-1)
+    p = Plan(ctx, dev, tiles["rid"], tiles["loc"], tiles["len"], tiles["strand"], make_params(_lib.MODE_PROFILE, binsize=1, ss=True))
+    want, _ = oracle_c.pileup_core(orc, tiles, binsize=1, ss=True)
+    assert np.array_equal(p.run_host(), want)
+    dev.close()
+
+
+@pytest.mark.parametrize("batch_blocks", ["", "1", "3"])
+def test_synthetic_bam_gapped_cigars_empty_references(ctx, tmp_path, monkeypatch, batch_blocks):
+    """our writer's BAM: D/N/S/I CIGARs, duplicates, references without reads in front of, between
+    and behind the populated ones; also with the stream cut into many tiny copy batches"""
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    from oracle import oracle_c
+    cols = synth_reads(200_000, [600_000, 90_000, 300_000], seed=11, paired=True)
+    # references 0, 2 and 5 are empty
+    ref_len = np.asarray([5000, 600_000, 1234, 90_000, 300_000, 77], dtype=np.int32)
+    ro = cols["ref_off"]
+    cols2 = dict(cols, ref_len=ref_len, ref_off=np.asarray([0, 0, ro[1], ro[1], ro[2], ro[3], ro[3]], dtype=np.int64))
+    path = str(tmp_path / "syn.bam")
+    write_columns_as_bam(path, ["e0", "a", "e2", "b", "c", "e5"], cols2)
+    if batch_blocks:
+        monkeypatch.setenv("BAMSIGNALS_BATCH_BLOCKS", batch_blocks)
+    bam, dev = _both_ways(ctx, path, monkeypatch)
+    assert dev.n_reads == 200_000
+    orc = oracle_c.OracleReads(cols2["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    from bamsignals_amd.synth import synth_ranges
+    rg = synth_ranges(500, 2000, ref_len, seed=9, jitter=1500)
+    a = dict(requiredF=66, tlen_filter=(0, 1000), tspan=True)
+    p = Plan(ctx, dev, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_COVERAGE, **a))
+    want, _ = oracle_c.coverage_core(orc, rg, **a)
+    assert np.array_equal(p.run_host(), want)
+    dev.close()
+
+
+def test_unplaced_and_unmapped_records(ctx, tmp_path, monkeypatch):
+    """spec-derived: records with refID -1 are skipped, 0x4 records placed at their mate count as
+    1-bp reads (bam_endpos), an empty CIGAR is a 1-bp read"""
+    from bamsignals_amd.bamio import writeSamAsBamAndIndex
+    sam = tmp_path / "u.sam"
+    lines = ["@HD\tVN:1.0\tSO:coordinate", "@SQ\tSN:c1\tLN:5000", "@SQ\tSN:c2\tLN:3000"]
+    lines += ["r%d\t0\tc1\t%d\t30\t50M\t*\t0\t0\t*\t*" % (i, 10 + 7 * i) for i in range(300)]
+    lines += ["m%d\t69\tc1\t%d\t0\t*\t=\t%d\t0\t*\t*" % (i, 2200 + i, 2200 + i) for i in range(40)]     # unmapped, placed
+    lines += ["s%d\t16\tc2\t%d\t11\t20M5D20M\t*\t0\t0\t*\t*" % (i, 5 + 3 * i) for i in range(500)]
+    lines += ["x%d\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*" % i for i in range(25)]                              # unplaced
+    sam.write_text("\n".join(lines) + "\n")
+    path = str(tmp_path / "u.bam")
+    writeSamAsBamAndIndex(str(sam), path)
+    bam, dev = _both_ways(ctx, path, monkeypatch)
+    assert dev.n_reads == 840
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    cov = Plan(ctx, dev, [0], [2150], [200], [1], make_params(_lib.MODE_COVERAGE)).run_host()
+    want = np.zeros(200, np.int32)
+    # the 50M reads starting at 10 + 7i - 1 (0-based) that reach into [2150, 2350)
+    for i in range(300):
+        s = 9 + 7 * i
+        want[max(s - 2150, 0):max(s + 50 - 2150, 0)] += 1
+    for i in range(40):
+        want[2200 + i - 1 - 2150] += 1                       # 1-bp reads
+    assert np.array_equal(cov, want)
+    dev.close()
+
+
+def test_files_that_need_the_cpu_path(ctx, tmp_path, monkeypatch, fixture_reads):
+    """records crossing BGZF block borders (htsjdk-style), a record larger than a block followed by
+    more records, and a CG-tag CIGAR: the call falls back to the CPU decode, same results"""
+    stream = gzip.decompress(open(BAM, "rb").read())
+    p = tmp_path / "straddle.bam"
+    p.write_bytes(_bgzf(stream, [4000, 9001, 517, 65000]))
+    _empty_bai(str(p) + ".bai", 3)
+    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=False)
+    assert dev.n_reads == 99000
+    dev.close()
+
+    # spec-derived: one 150-kB record (l_seq 100,000) between ordinary ones
+    text = b"@SQ\tSN:c\tLN:200000\n"
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\x00" + struct.pack("<i", 200000)
+
+    def rec(pos, lseq, cigar, aux=b""):
+        name = b"q\x00"
+        body = struct.pack("<iiBBHHHiiii", 0, pos, len(name), 40, 4681, len(cigar), 0, lseq, -1, -1, 0) + name
+        body += struct.pack("<%dI" % len(cigar), *cigar) + bytes((lseq + 1) // 2) + b"\xff" * lseq + aux
+        return struct.pack("<i", len(body)) + body
+    small = [rec(100 + 3 * i, 0, [(30 << 4) | 0]) for i in range(50)]
+    big = rec(400, 100_000, [(100_000 << 4) | 0])
+    tail = [rec(500 + i, 0, [(10 << 4) | 0, (5 << 4) | 2, (10 << 4) | 0]) for i in range(50)]
+    first = hdr + b"".join(small)
+    data = first + big + b"".join(tail)
+    p = tmp_path / "big.bam"
+    p.write_bytes(_bgzf(first, [len(first)])[:-len(EOF_BLOCK)] + _bgzf(big + b"".join(tail), [65000]))
+    assert gzip.decompress(p.read_bytes()) == data
+    _empty_bai(str(p) + ".bai", 1)
+    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=False)
+    assert dev.n_reads == 101
+    dev.close()
+
+    # the same oversized record as the LAST record of the file: every later block start lies
+    # inside it, which the device path recognises and accepts
+    p = tmp_path / "biglast.bam"
+    p.write_bytes(_bgzf(first, [len(first)])[:-len(EOF_BLOCK)] + _bgzf(big, [65000]))
+    _empty_bai(str(p) + ".bai", 1)
+    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=True)
+    assert dev.n_reads == 51
+    dev.close()
+
+    # CG-tag CIGAR (SAM spec 4.2.2)
+    ops = [(1 << 4) | 0, (1 << 4) | 2] * 40000
+    lseq = 40000
+    aux = b"CGBI" + struct.pack("<I", len(ops)) + struct.pack("<%dI" % len(ops), *ops)
+    cg = rec(1000, lseq, [lseq << 4 | 4, 80000 << 4 | 3], aux)
+    p = tmp_path / "cg.bam"
+    p.write_bytes(_bgzf(first, [len(first)])[:-len(EOF_BLOCK)] + _bgzf(cg, [60000]))
+    _empty_bai(str(p) + ".bai", 1)
+    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=False)
+    assert dev.info()["class_maxspan"][3] == 80000
+    dev.close()
+
+
+def test_damaged_files_report_the_cpu_paths_errors(ctx, tmp_path, monkeypatch):
+    """a truncated last record and an unsorted file: the device path declines, the CPU path names
+    the problem"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    stream = gzip.decompress(open(BAM, "rb").read())
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "1")
+    p = tmp_path / "trunc.bam"
+    p.write_bytes(_bgzf(stream[:-7], [60000]))
+    _empty_bai(str(p) + ".bai", 3)
+    with pytest.raises(_lib.BsigError, match="truncated"):
+        Reads.from_bam(ctx, BamFile(str(p)))
+    # swap two records: no longer sorted
+    hb = 4 + 4 + struct.unpack_from("<i", stream, 4)[0]
+    n_ref = struct.unpack_from("<i", stream, hb)[0]
+    o = hb + 4
+    for _ in range(n_ref):
+        o += 8 + struct.unpack_from("<i", stream, o)[0]
+    l0 = 4 + struct.unpack_from("<i", stream, o)[0]
+    l1 = 4 + struct.unpack_from("<i", stream, o + l0)[0]
+    l2 = 4 + struct.unpack_from("<i", stream, o + l0 + l1)[0]
+    r0, r1, r2 = stream[o:o + l0], stream[o + l0:o + l0 + l1], stream[o + l0 + l1:o + l0 + l1 + l2]
+    assert struct.unpack_from("<i", r2, 8)[0] > struct.unpack_from("<i", r0, 8)[0]
+    bad = stream[:o] + r2 + r1 + r0 + stream[o + l0 + l1 + l2:]
+    p = tmp_path / "unsorted.bam"
+    p.write_bytes(_bgzf(bad, [len(bad[:o + l0 + l1 + l2]), 50000]))
+    _empty_bai(str(p) + ".bai", 3)
+    with pytest.raises(_lib.BsigError, match="sorted"):
+        Reads.from_bam(ctx, BamFile(str(p)))
+
+
+def test_file_level_calls_take_the_device_decode(monkeypatch, fixture_regions, expected_grid):
+    """bamProfile(bampath, gr) with the whole-file decode goes through bsig_reads_from_bam"""
+    from bamsignals_amd import GRanges, _lib, bamProfile
+    from bamsignals_amd.device import Reads
+    reg, _ = fixture_regions
+    gr = GRanges(reg["chrom"], reg["start"], width=reg["width"], strand=reg["strand"])
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+    _lib.load().bsig_cache_clear()
+    try:
+        sig = bamProfile(BAM, gr, ss=True, shift=100, paired_end="midpoint", tlenFilter=(50, 200), verbose=False)
+        got = np.concatenate([m.T.reshape(-1) for m in sig.as_list()])
+        assert np.array_equal(got, expected_grid["profile|shift=100,mapq=0,ss=1,pe=midpoint,tf=50_200"])
+        assert Reads.device_decode_timing()["total"] > 0
+    finally:
+        _lib.load().bsig_cache_clear()
