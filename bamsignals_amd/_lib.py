@@ -86,6 +86,7 @@ def load():
     lib.bsig_host_free.restype = None
     lib.bsig_reads_upload.argtypes = [C.c_void_p, C.POINTER(Columns), C.POINTER(C.c_void_p)]
     lib.bsig_reads_get_info.argtypes = [C.c_void_p, C.POINTER(ReadsInfo)]
+    lib.bsig_reads_clone.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.bsig_reads_free.argtypes = [C.c_void_p]
     lib.bsig_reads_free.restype = None
     lib.bsig_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

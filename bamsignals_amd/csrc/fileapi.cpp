@@ -212,26 +212,33 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         const double t_dec = now_s();
         bsig_columns cols;
         bool on_device = false;
-        if (whole && nd == 1) {
-            // one GPU: the records are taken from the uncompressed stream on the GPU itself
-            // (devdecode.hip; falls back to the CPU decode inside the call where it must)
+        if (whole) {
+            // the records are taken from the uncompressed stream on the first GPU itself
+            // (devdecode.hip; falls back to the CPU decode inside the call where it must); further
+            // GPUs get device-to-device copies of the resident layout
             rc = bsig_reads_from_bam(g_cache.slots[0].ctx, bam, 0, &reads[0]);
             if (rc) return rc;
             on_device = true;
+            owned[0] = 1;
             double t6[6];
             bsig_device_decode_timing(t6);
             T[2] = t6[5];
             T[1] = now_s() - t_dec - T[2];
-            DevSlot &d = g_cache.slots[0];
-            if (!key.empty()) {
-                d.drop_reads();
-                d.reads = reads[0];
-                d.key = key;
-            } else {
-                owned[0] = 1;
+            const double t_rep = now_s();
+            for (size_t k = 1; k < nd; ++k) {
+                rc = bsig_reads_clone(reads[0], g_cache.slots[k].ctx, &reads[k]);
+                if (rc) { release(); return rc; }
+                owned[k] = 1;
             }
-        } else if (whole) {
-            rc = bsig_bam_decode(bam, -1, nullptr, nullptr, nullptr, 0, &cols);
+            T[2] += now_s() - t_rep;
+            if (!key.empty())
+                for (size_t k = 0; k < nd; ++k) {
+                    DevSlot &d = g_cache.slots[k];
+                    d.drop_reads();
+                    d.reads = reads[k];
+                    d.key = key;
+                    owned[k] = 0;
+                }
         } else {
             std::vector<int64_t> beg((size_t)n), end((size_t)n);
             for (int64_t i = 0; i < n; ++i) {

@@ -236,6 +236,8 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         HIP_TRY(tmp.alloc(&gb, cap));
         n_buckets[c] = total_bp >> k;
         HIP_TRY(R->pool.alloc(&idx, n_buckets[c] + 2));
+        R->col_cap[c] = cap;
+        R->idx_entries[c] = n_buckets[c] + 2;
         // the tail padding is read by the 16-B loads: keep it defined
         HIP_TRY(hipMemsetAsync(p + cap - 8, 0, 8 * sizeof(int32_t), st));
         if (e) HIP_TRY(hipMemsetAsync(e + cap - 8, 0, 8 * sizeof(int32_t), st));
@@ -346,6 +348,63 @@ int bsig_reads_get_info(const bsig_reads *reads, bsig_reads_info *info)
 }
 
 void bsig_reads_free(bsig_reads *reads) { delete reads; }
+
+int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **out)
+{
+    if (!src || !dst_ctx || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_clone");
+    *out = nullptr;
+    const int sdev = src->ctx->device, ddev = dst_ctx->device;
+    HIP_TRY(hipSetDevice(ddev));
+    if (sdev != ddev) {
+        // direct copies over xGMI where the link allows it; without peer access the runtime stages
+        // the copy through the host, which is still correct
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ddev, sdev) == hipSuccess && can) {
+            (void)hipDeviceEnablePeerAccess(sdev, 0);     // "already enabled" is fine
+            (void)hipGetLastError();
+        }
+    }
+    bsig_reads *R = new bsig_reads;
+    R->ctx = dst_ctx;
+    R->info = src->info;
+    R->n_ref = src->n_ref;
+    R->ref_unit0 = src->ref_unit0;
+    R->ref_units = src->ref_units;
+    R->ref_len = src->ref_len;
+    hipStream_t st = dst_ctx->stream;
+    hipError_t e = hipSuccess;
+    auto copy = [&](const void *from, size_t bytes, void **to) {
+        if (e != hipSuccess || !from) { *to = nullptr; return; }
+        uint8_t *q = nullptr;
+        e = R->pool.alloc(&q, bytes);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(q, ddev, from, sdev, bytes, st);
+        *to = q;
+    };
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &S = src->dev.cls[c];
+        BsigClassCols &D = R->dev.cls[c];
+        D = S;
+        if (S.n == 0) continue;
+        R->col_cap[c] = src->col_cap[c];
+        R->idx_entries[c] = src->idx_entries[c];
+        const size_t cb = (size_t)src->col_cap[c] * sizeof(int32_t);
+        void *p;
+        copy(S.pos, cb, &p); D.pos = (const int32_t *)p;
+        copy(S.end, cb, &p); D.end = (const int32_t *)p;
+        copy(S.fm, cb, &p); D.fm = (const uint32_t *)p;
+        copy(S.tlen, cb, &p); D.tlen = (const int32_t *)p;
+        copy(S.idx, (size_t)src->idx_entries[c] * sizeof(uint32_t), &p); D.idx = (const uint32_t *)p;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        delete R;
+        return fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "copying the reads to GPU %d failed: %s", ddev,
+                    hipGetErrorString(e));
+    }
+    R->info.hbm_bytes = R->pool.bytes;
+    *out = R;
+    return BSIG_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // plans

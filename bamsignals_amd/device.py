@@ -134,6 +134,17 @@ class Reads:
         self.n_reads = self.info()["n_reads"]
         return self
 
+    def clone(self, ctx):
+        """A copy of these resident reads on ``ctx``'s GPU (device-to-device)."""
+        other = type(self).__new__(type(self))
+        other._lib = self._lib
+        other.ctx = ctx
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_reads_clone(self._h, ctx._h, C.byref(h)))
+        other._h = h
+        other.n_ref, other.n_reads = self.n_ref, self.n_reads
+        return other
+
     @staticmethod
     def device_decode_timing():
         """Stage seconds of this thread's last ``from_bam`` (all 0 when it took the CPU decode)."""

@@ -104,6 +104,9 @@ typedef struct {
 int bsig_reads_upload(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads **reads);
 int bsig_reads_get_info(const bsig_reads *reads, bsig_reads_info *info);
 void bsig_reads_free(bsig_reads *reads);
+/* a copy of resident reads on another GPU (device-to-device over xGMI where peer access exists):
+ * how the single-process multi-GPU path replicates a BAM that was decoded once                 */
+int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **reads);
 
 /* ------------------------------------------------------------------------------------------
  * A plan = ranges + call parameters resident in HBM, ready to run any number of times.

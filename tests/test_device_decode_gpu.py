@@ -93,6 +93,14 @@ def test_fixture_bam(ctx, monkeypatch, fixture_reads):
     from oracle import oracle_c
     bam, dev = _both_ways(ctx, BAM, monkeypatch)
     assert dev.n_reads == 99000
+    from bamsignals_amd.device import Context
+    ctx2 = Context(0)                                  # a second context: the multi-GPU replication path
+    twin = dev.clone(ctx2)
+    assert twin.info() == dev.info()
+    for a, b in zip(_results(ctx2, twin, bam.ref_len), _results(ctx, dev, bam.ref_len)):
+        assert np.array_equal(a, b)
+    twin.close()
+    ctx2.close()
     fx = fixture_reads
     orc = oracle_c.OracleReads(fx["ref_off"], fx["bam_pos"], fx["bam_end"], fx["bam_flag"], fx["bam_mapq"], fx["bam_tlen"])
     from bamsignals_amd import _lib
