@@ -10,7 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -675,6 +678,99 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     return BSIG_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Result download into PAGEABLE host memory (an R vector, a numpy array): the runtime's own
+// pageable path stages through one buffer and is first-touch bound on the destination pages
+// (80 MB in 8 ms).  Here the result crosses PCIe by DMA into two page-locked halves and a few
+// threads move each half on into the destination while the next one is in flight.
+struct DownloadStage {
+    std::mutex mu;
+    uint8_t *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr size_t kHalf = 32u << 20;
+    int ensure()
+    {
+        for (int k = 0; k < 2; ++k) {
+            if (!buf[k]) HIP_TRY(hipHostMalloc((void **)&buf[k], kHalf, hipHostMallocDefault));
+            if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        return BSIG_OK;
+    }
+};
+DownloadStage g_download;
+
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t *dst, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_download.mu);
+    HIP_TRY(hipSetDevice(device));
+    const int rc = g_download.ensure();
+    if (rc) return rc;
+    const size_t half = DownloadStage::kHalf;
+    const size_t n_chunks = (bytes + half - 1) / half;
+    int n_thr = 8;
+    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    std::atomic<int64_t> ready(-1);                 // chunks 0..ready are in their half
+    std::vector<std::atomic<int>> done(n_chunks);   // workers finished with chunk c
+    for (auto &d : done) d.store(0);
+    std::atomic<bool> abort(false);
+    auto worker = [&](int t) {
+        for (size_t c = 0; c < n_chunks; ++c) {
+            while (ready.load(std::memory_order_acquire) < (int64_t)c) {
+                if (abort.load()) return;
+                std::this_thread::yield();
+            }
+            const size_t len = std::min(half, bytes - c * half);
+            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * (size_t)(t + 1) / (size_t)n_thr;
+            if (b > a) memcpy(dst + c * half + a, g_download.buf[c & 1] + a, b - a);
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; ++t) th.emplace_back(worker, t);
+    hipError_t e = hipSuccess;
+    auto issue = [&](size_t c) {
+        const size_t len = std::min(half, bytes - c * half);
+        e = hipMemcpyAsync(g_download.buf[c & 1], src_dev + c * half, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(g_download.ev[c & 1], st);
+    };
+    for (size_t c = 0; c < std::min<size_t>(2, n_chunks) && e == hipSuccess; ++c) issue(c);
+    for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+        e = hipEventSynchronize(g_download.ev[c & 1]);
+        if (e != hipSuccess) break;
+        ready.store((int64_t)c, std::memory_order_release);
+        {   // the calling thread is worker 0 of this chunk
+            const size_t len = std::min(half, bytes - c * half);
+            const size_t b = len / (size_t)n_thr;
+            if (b) memcpy(dst + c * half, g_download.buf[c & 1], b);
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+        while (done[c].load(std::memory_order_acquire) < n_thr) std::this_thread::yield();
+        if (c + 2 < n_chunks) issue(c + 2);       // this half is free again
+    }
+    if (e != hipSuccess) abort.store(true);
+    ready.store((int64_t)n_chunks, std::memory_order_release);
+    for (auto &t : th) t.join();
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
+    }
+    return BSIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
 {
     if (!p) return fail(BSIG_ERR_ARG, "plan is NULL");
@@ -684,11 +780,13 @@ int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
     HIP_TRY(hipSetDevice(p->ctx->device));
     if (!p->d_out) HIP_TRY(p->pool.alloc(&p->d_out, (size_t)cells));
     int rc = bsig_plan_run(p, p->d_out);
-    if (rc == BSIG_OK) {
-        hipError_t e = hipMemcpyAsync(out_host, p->d_out, cells * sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
-        if (e != hipSuccess) rc = fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
-    }
+    if (rc != BSIG_OK) return rc;
+    const size_t bytes = (size_t)cells * sizeof(int32_t);
+    if (bytes >= (8u << 20) && !is_pinned_host(out_host))
+        return download_staged(p->ctx->device, p->ctx->stream, (const uint8_t *)p->d_out, (uint8_t *)out_host, bytes);
+    hipError_t e = hipMemcpyAsync(out_host, p->d_out, bytes, hipMemcpyDeviceToHost, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
+    if (e != hipSuccess) rc = fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
     return rc;
 }
 
