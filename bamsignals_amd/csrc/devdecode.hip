@@ -14,11 +14,15 @@
 //
 // A lane can only start where a record starts.  Files written by htslib/samtools and by this
 // library's BamWriter never split a record over two BGZF blocks unless it is larger than a block,
-// so every block start is a record start (or lies inside an oversized record, which the host
-// check below recognises).  Files that break this (htsjdk writes records across block borders),
-// CG-tag CIGARs, unsorted or damaged files are NOT handled here: the call returns
-// kNeedsCpuPath and the caller takes the CPU decode (bamio.cpp), which also owns every error
-// message.  Results are identical by construction and by tests/test_methods_gpu.py.
+// so there the block start is a record start.  htsjdk lets records run across block borders: the
+// lane then looks for the first offset in its block behind which a chain of plausible records
+// follows (field ranges, the NUL ending the read name, sizes that fit block_size, coordinate
+// order).  Such a start is only a proposal.  The host accepts the parse only if the chain of
+// records from the header arrives EXACTLY at every block's proposed start -- then the lanes'
+// walks, laid end to end, are the serial walk of the stream and the proposal is proven.
+// Anything else (a wrong proposal, CG-tag CIGARs, unsorted or damaged files) returns kNeedsCpuPath
+// and the caller takes the CPU decode (bamio.cpp), which also owns every error message.
+// Results are identical by construction and by tests/test_device_decode_gpu.py.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -41,6 +45,7 @@ constexpr uint32_t kFlagUnsorted = 2u;
 constexpr uint32_t kFlagCg = 4u;             // CG-tag placeholder CIGAR (SAM spec 4.2.2)
 
 struct SegSummary {
+    uint64_t first;                          // where the first record that starts in the block begins
     uint64_t end;                            // stream offset behind the last record walked
     uint32_t n_placed, n_unplaced;
     int32_t first_rid, first_pos, last_rid, last_pos;
@@ -54,15 +59,70 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p)
     return v;
 }
 
+// Could a record start at stream offset o?  Field ranges of the fixed part, the NUL that ends the
+// read name, and the variable parts fitting block_size (SAM spec 4.2).  Random bytes pass with
+// negligible probability; the host check after the walk is what proves a start right.
+__device__ __forceinline__ bool plausible_record(const uint8_t *__restrict__ stream, uint64_t total, uint64_t o,
+                                                 int32_t n_ref, const int32_t *__restrict__ ref_len,
+                                                 uint64_t *next, int32_t *rid_out, int32_t *pos_out)
+{
+    if (o + 36 > total) return false;
+    const int32_t bs = (int32_t)ld32(stream + o);
+    if (bs < 33 || bs > (1 << 28)) return false;
+    const uint64_t nx = o + 4 + (uint64_t)bs;
+    if (nx > total) return false;
+    const int32_t rid = (int32_t)ld32(stream + o + 4);
+    if (rid < -1 || rid >= n_ref) return false;
+    const int32_t pos = (int32_t)ld32(stream + o + 8);
+    if (pos < -1 || (rid >= 0 && pos > ref_len[rid])) return false;
+    const uint32_t l_name = ld32(stream + o + 12) & 0xFFu;
+    const uint32_t n_cig = ld32(stream + o + 16) & 0xFFFFu;
+    const int32_t l_seq = (int32_t)ld32(stream + o + 20);
+    const int32_t nrid = (int32_t)ld32(stream + o + 24), npos = (int32_t)ld32(stream + o + 28);
+    if (l_name < 1 || l_seq < 0 || nrid < -1 || nrid >= n_ref || npos < -1) return false;
+    const uint64_t need = 32 + (uint64_t)l_name + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (need > (uint64_t)bs) return false;
+    if (stream[o + 36 + l_name - 1] != 0) return false;
+    *next = nx; *rid_out = rid; *pos_out = pos;
+    return true;
+}
+
+// kChain plausible records in coordinate order behind each other (or fewer, ending exactly at the
+// end of the stream)
+__device__ __forceinline__ bool plausible_chain(const uint8_t *__restrict__ stream, uint64_t total, uint64_t o,
+                                                int32_t n_ref, const int32_t *__restrict__ ref_len)
+{
+    constexpr int kChain = 3;
+    int32_t prid = -1, ppos = -1;
+    for (int k = 0; k < kChain; ++k) {
+        uint64_t nx;
+        int32_t rid, pos;
+        if (!plausible_record(stream, total, o, n_ref, ref_len, &nx, &rid, &pos)) return false;
+        if (k) {
+            // coordinate order; unplaced records (-1) only at the end
+            if (prid < 0 ? rid >= 0 : (rid >= 0 && (rid < prid || (rid == prid && pos < ppos)))) return false;
+        }
+        prid = rid; ppos = pos;
+        o = nx;
+        if (o == total) return true;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ stream, uint64_t total,
                                                  const uint64_t *__restrict__ seg_start, int64_t n_seg,
-                                                 int32_t n_ref, uint16_t *__restrict__ off16,
-                                                 SegSummary *__restrict__ sum)
+                                                 int32_t n_ref, const int32_t *__restrict__ ref_len,
+                                                 uint16_t *__restrict__ off16, SegSummary *__restrict__ sum)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
-    uint64_t o = seg_start[s];
-    const uint64_t base = o, limit = seg_start[s + 1];
+    const uint64_t base = seg_start[s], limit = seg_start[s + 1];
+    // the first record that starts in this block: the block start itself in files that keep records
+    // inside blocks (htslib, BamWriter); otherwise (htsjdk lets records run across block borders)
+    // the first offset behind which a chain of plausible records follows
+    uint64_t o = base;
+    while (o < limit && !plausible_chain(stream, total, o, n_ref, ref_len)) ++o;
+    const uint64_t first = o;
     uint16_t *mine = off16 + s * kMaxRecPerSeg;
     uint32_t np = 0, nu = 0, flags = 0;
     int32_t frid = -1, fpos = -1, prid = -1, ppos = -1;
@@ -92,6 +152,7 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ str
         o = next;
     }
     SegSummary r;
+    r.first = first;
     r.end = o; r.n_placed = np; r.n_unplaced = nu;
     r.first_rid = frid; r.first_pos = fpos; r.last_rid = prid; r.last_pos = ppos;
     r.flags = flags; r.pad = 0;
@@ -277,14 +338,19 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         HIP_TRY(tmp.alloc(&d_off16, (size_t)n_seg * kMaxRecPerSeg));
         HIP_TRY(tmp.alloc(&d_sum, (size_t)n_seg));
         HIP_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        int32_t *d_ref_len = nullptr;
+        HIP_TRY(tmp.alloc(&d_ref_len, (size_t)std::max(n_ref, 1)));
+        if (n_ref) HIP_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_stream, total, d_seg_start,
-                           n_seg, n_ref, d_off16, d_sum);
+                           n_seg, n_ref, d_ref_len, d_off16, d_sum);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
 
-    // ---- host: every accepted segment must begin where its predecessor ended ---------------------
+    // ---- host: the chain of records from the header must run through every block's first record ----
+    // (this is what proves the starts the lanes chose: a walk from the first record that always
+    // arrives exactly at the next block's chosen start IS the serial walk of the whole stream)
     std::vector<uint32_t> seg_n((size_t)std::max<int64_t>(n_seg, 1), 0);
     std::vector<int64_t> seg_base((size_t)std::max<int64_t>(n_seg, 1), 0);
     std::vector<int32_t> seg_prev((size_t)std::max<int64_t>(n_seg, 1), -1);
@@ -292,9 +358,10 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     int64_t n_reads = 0;
     int32_t last_rid = -1, last_pos = -1;
     for (int64_t s = 0; s < n_seg; ++s) {
-        if (seg_start[(size_t)s] < o) continue;                    // inside an oversized record
-        if (seg_start[(size_t)s] > o) return kNeedsCpuPath;        // a record crosses a block border
+        const uint64_t a = seg_start[(size_t)s], b = seg_start[(size_t)s + 1];
+        if (a == b || o >= b) continue;         // empty block, or the current record runs through all of it
         const SegSummary &g = sum[(size_t)s];
+        if (g.first != o) return kNeedsCpuPath; // a <= o < b: the lane must have chosen exactly this start
         if (g.flags) return kNeedsCpuPath;                         // damaged, unsorted or CG-tag CIGARs
         if (g.n_placed) {
             if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return kNeedsCpuPath;

@@ -42,6 +42,24 @@ def _bgzf(data, sizes):
     return out + EOF_BLOCK
 
 
+def _first_record(stream):
+    """offset of the first record of an uncompressed BAM stream"""
+    o = 8 + struct.unpack_from("<i", stream, 4)[0]
+    n_ref = struct.unpack_from("<i", stream, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        o += 8 + struct.unpack_from("<i", stream, o)[0]
+    return o
+
+
+def _boundary_after(stream, target):
+    """first record boundary at or behind `target`"""
+    o = _first_record(stream)
+    while o < target:
+        o += 4 + struct.unpack_from("<i", stream, o)[0]
+    return o
+
+
 def _empty_bai(path, n_ref):
     with open(path, "wb") as f:
         f.write(b"BAI\x01" + struct.pack("<i", n_ref) + struct.pack("<ii", 0, 0) * n_ref + struct.pack("<Q", 0))
@@ -172,16 +190,19 @@ def test_unplaced_and_unmapped_records(ctx, tmp_path, monkeypatch):
     dev.close()
 
 
-def test_files_that_need_the_cpu_path(ctx, tmp_path, monkeypatch, fixture_reads):
-    """records crossing BGZF block borders (htsjdk-style), a record larger than a block followed by
-    more records, and a CG-tag CIGAR: the call falls back to the CPU decode, same results"""
+def test_records_crossing_block_borders_and_oversized_records(ctx, tmp_path, monkeypatch, fixture_reads):
+    """records crossing BGZF block borders (htsjdk-style): the lanes propose their starts and the
+    host proves them; a record larger than a block, followed by more records or last in the file;
+    a CG-tag CIGAR falls back to the CPU decode.  Same results every time."""
     stream = gzip.decompress(open(BAM, "rb").read())
-    p = tmp_path / "straddle.bam"
-    p.write_bytes(_bgzf(stream, [4000, 9001, 517, 65000]))
-    _empty_bai(str(p) + ".bai", 3)
-    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=False)
-    assert dev.n_reads == 99000
-    dev.close()
+    for k, sizes in enumerate(([4000, 9001, 517, 65000], [65536], [33, 70, 1000])):
+        p = tmp_path / ("straddle%d.bam" % k)
+        p.write_bytes(_bgzf(stream if k < 2 else stream[:_boundary_after(stream, 400_000)], sizes))
+        _empty_bai(str(p) + ".bai", 3)
+        _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=True)
+        if k < 2:
+            assert dev.n_reads == 99000
+        dev.close()
 
     # spec-derived: one 150-kB record (l_seq 100,000) between ordinary ones
     text = b"@SQ\tSN:c\tLN:200000\n"
@@ -201,7 +222,7 @@ def test_files_that_need_the_cpu_path(ctx, tmp_path, monkeypatch, fixture_reads)
     p.write_bytes(_bgzf(first, [len(first)])[:-len(EOF_BLOCK)] + _bgzf(big + b"".join(tail), [65000]))
     assert gzip.decompress(p.read_bytes()) == data
     _empty_bai(str(p) + ".bai", 1)
-    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=False)
+    _, dev = _both_ways(ctx, str(p), monkeypatch, expect_device=True)
     assert dev.n_reads == 101
     dev.close()
 
@@ -241,11 +262,7 @@ def test_damaged_files_report_the_cpu_paths_errors(ctx, tmp_path, monkeypatch):
     with pytest.raises(_lib.BsigError, match="truncated"):
         Reads.from_bam(ctx, BamFile(str(p)))
     # swap two records: no longer sorted
-    hb = 4 + 4 + struct.unpack_from("<i", stream, 4)[0]
-    n_ref = struct.unpack_from("<i", stream, hb)[0]
-    o = hb + 4
-    for _ in range(n_ref):
-        o += 8 + struct.unpack_from("<i", stream, o)[0]
+    o = _first_record(stream)
     l0 = 4 + struct.unpack_from("<i", stream, o)[0]
     l1 = 4 + struct.unpack_from("<i", stream, o + l0)[0]
     l2 = 4 + struct.unpack_from("<i", stream, o + l0 + l1)[0]
