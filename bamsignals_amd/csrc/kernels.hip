@@ -343,6 +343,12 @@ __device__ __forceinline__ void add_vec(int32_t *__restrict__ gbase, int v, int4
 // ------------------------------------------------------------------------------------------
 // bamProfile: per-bin counts of 5' ends
 // ------------------------------------------------------------------------------------------
+// The tile image holds 16-bit counters, two per LDS dword: a tile that is not split into slices has
+// at most 32,768 reads in its windows (kMaxTileReads; bsig_plan_create cuts anything above into
+// slices of a quarter of that), so no counter can reach 65,536 and an add of 1 << 16 into the upper
+// half never sees a carry from the lower one.  Half the LDS per workgroup: 24 instead of 18
+// single-wave workgroups per CU (LDS is allocated in 1,280-byte granules on gfx950), which puts
+// config 2's 10,000 tiles into two rounds of resident workgroups instead of two and a sparse third.
 template <int NT, bool SS>
 __global__ __launch_bounds__(NT) void k_profile(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
                                                 int32_t *__restrict__ out,
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigWorkItem *__restrict__
     load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     // clear the whole tile image: this needs nothing from the work item, so it overlaps its load
-    for (int v = tid; v < (P.tile_cells * S + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    for (int v = tid; v < (P.tile_cells * S + 8 + 7) / 8; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     const int nv = w.nc * S;
     const int sh = (int)(w.out_off & 3);
     const int nvec = (sh + nv + 3) >> 2;
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigWorkItem *__restrict__
     BSIG_STAMP(1);
 
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
 
     auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
         if (!valid || read_rejected(P, fm, tl)) return;
@@ -381,18 +388,24 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigWorkItem *__restrict__
         const int cell = P.binsize == 1 ? rel
                                         : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
         const int lc = cell - w.c0;
-        if ((unsigned)lc < (unsigned)w.nc)
-            atomicAdd(&lds[sh + lc * S + (SS ? anti : 0)], 1);         // :361-362
+        if ((unsigned)lc < (unsigned)w.nc) {
+            const int k = sh + lc * S + (SS ? anti : 0);               // :361-362
+            atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
+        }
     };
     if (!BSIG_ABLATE(1)) for_each_read<NT>(R, P, win, tid, one);
     block_sync<NT>();
     BSIG_STAMP(2);
 
     int32_t *gbase = out + (w.out_off - sh);
+    const uint2 *lds2 = reinterpret_cast<const uint2 *>(lds);
+    auto widen = [](uint2 d) {
+        return make_int4((int)(d.x & 0xFFFFu), (int)(d.x >> 16), (int)(d.y & 0xFFFFu), (int)(d.y >> 16));
+    };
     if (P.accumulate) {
-        for (int v = tid; v < nvec; v += NT) add_vec(gbase, v, lds4[v], sh, nv);
+        for (int v = tid; v < nvec; v += NT) add_vec(gbase, v, widen(lds2[v]), sh, nv);
     } else if (!BSIG_ABLATE(2)) {
-        for (int v = tid; v < nvec; v += NT) store_vec(gbase, v, lds4[v], sh, nv);
+        for (int v = tid; v < nvec; v += NT) store_vec(gbase, v, widen(lds2[v]), sh, nv);
     }
     BSIG_STAMP(3);
 #ifdef BSIG_STAMPS
@@ -829,7 +842,7 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
         if (ss) hipLaunchKernelGGL((k_profile_small<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
         else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (mode == BSIG_MODE_PROFILE) {
-        const size_t lds = (size_t)(tile_cells * (ss ? 2 : 1) + 8) * sizeof(int32_t);
+        const size_t lds = (size_t)((tile_cells * (ss ? 2 : 1) + 8 + 7) / 8) * 16;     // 16-bit counters
         if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
         else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (mode == BSIG_MODE_COVERAGE) {

@@ -590,7 +590,8 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     // millions and would keep the whole launch waiting.  Probe the window sizes once per plan and
     // cut the windows of heavy tiles into slices that separate workgroups add up with atomics.
     int64_t heavy_reads = 32768, slice_reads = 8192;
-    if (const char *v = getenv("BAMSIGNALS_HEAVY_READS")) { heavy_reads = std::max<long long>(4, atoll(v)); slice_reads = std::max<int64_t>(4, heavy_reads / 4); }
+    // (k_profile's 16-bit tile image relies on the 32,768 ceiling: the environment may only lower it)
+    if (const char *v = getenv("BAMSIGNALS_HEAVY_READS")) { heavy_reads = std::min<long long>(32768, std::max<long long>(4, atoll(v))); slice_reads = std::max<int64_t>(4, heavy_reads / 4); }
     if (e == hipSuccess && !items.empty()) {
         DevPool tmp;
         uint2 *d_win = nullptr;
