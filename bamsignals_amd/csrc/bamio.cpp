@@ -506,6 +506,21 @@ private:
 // ---------------------------------------------------------------------------------------------
 static int scan_blocks(const MappedFile &f, const std::string &path, std::vector<Block> &blocks)
 {
+    // The scan below touches one header per block, i.e. nearly every page of the mapping, one page
+    // fault after the other.  Map the pages in from several threads first (the inflate would fault
+    // them in anyway): 8-15 ms -> a few ms for a 300-MB file.
+    if (f.size >= (16u << 20)) {
+        const size_t slice = 4u << 20;
+        const int64_t n_slices = (int64_t)((f.size + slice - 1) / slice);
+        parallel_for(n_slices, std::min(n_threads(0), 16), [&](int64_t i, int) {
+            const size_t a = (size_t)i * slice, b = std::min(f.size, a + slice);
+#ifdef MADV_POPULATE_READ
+            if (madvise((void *)(f.data + a), b - a, MADV_POPULATE_READ) == 0) return;
+#endif
+            volatile uint8_t sink = 0;
+            for (size_t o = a; o < b; o += 4096) sink = sink + f.data[o];
+        });
+    }
     uint64_t off = 0;
     while (off < f.size) {
         Block b;
