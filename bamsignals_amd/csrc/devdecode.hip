@@ -28,6 +28,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ constexpr int kMaxRecPerSeg = 1824;          // a record is >= 36 bytes, a block
 constexpr uint32_t kFlagBad = 1u;            // malformed / truncated / too many records
 constexpr uint32_t kFlagUnsorted = 2u;
 constexpr uint32_t kFlagCg = 4u;             // CG-tag placeholder CIGAR (SAM spec 4.2.2)
+constexpr uint32_t kFlagIncomplete = 8u;     // the record at `end` runs past this chunk of the stream
 
 struct SegSummary {
     uint64_t first;                          // where the first record that starts in the block begins
@@ -62,46 +64,51 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p)
 // Could a record start at stream offset o?  Field ranges of the fixed part, the NUL that ends the
 // read name, and the variable parts fitting block_size (SAM spec 4.2).  Random bytes pass with
 // negligible probability; the host check after the walk is what proves a start right.
-__device__ __forceinline__ bool plausible_record(const uint8_t *__restrict__ stream, uint64_t total, uint64_t o,
-                                                 int32_t n_ref, const int32_t *__restrict__ ref_len,
-                                                 uint64_t *next, int32_t *rid_out, int32_t *pos_out)
+// Returns 0 (no), 1 (yes, and the record lies inside the view), 2 (could be, but it runs past the
+// end of the view -- only when the view is not the end of the stream).
+__device__ __forceinline__ int plausible_record(const uint8_t *__restrict__ stream, uint64_t total, bool is_last,
+                                                uint64_t o, int32_t n_ref, const int32_t *__restrict__ ref_len,
+                                                uint64_t *next, int32_t *rid_out, int32_t *pos_out)
 {
-    if (o + 36 > total) return false;
+    if (o + 36 > total) return (!is_last && o < total) ? 2 : 0;
     const int32_t bs = (int32_t)ld32(stream + o);
-    if (bs < 33 || bs > (1 << 28)) return false;
+    if (bs < 33 || bs > (1 << 28)) return 0;
     const uint64_t nx = o + 4 + (uint64_t)bs;
-    if (nx > total) return false;
+    if (nx > total && is_last) return 0;
     const int32_t rid = (int32_t)ld32(stream + o + 4);
-    if (rid < -1 || rid >= n_ref) return false;
+    if (rid < -1 || rid >= n_ref) return 0;
     const int32_t pos = (int32_t)ld32(stream + o + 8);
-    if (pos < -1 || (rid >= 0 && pos > ref_len[rid])) return false;
+    if (pos < -1 || (rid >= 0 && pos > ref_len[rid])) return 0;
     const uint32_t l_name = ld32(stream + o + 12) & 0xFFu;
     const uint32_t n_cig = ld32(stream + o + 16) & 0xFFFFu;
     const int32_t l_seq = (int32_t)ld32(stream + o + 20);
     const int32_t nrid = (int32_t)ld32(stream + o + 24), npos = (int32_t)ld32(stream + o + 28);
-    if (l_name < 1 || l_seq < 0 || nrid < -1 || nrid >= n_ref || npos < -1) return false;
+    if (l_name < 1 || l_seq < 0 || nrid < -1 || nrid >= n_ref || npos < -1) return 0;
     const uint64_t need = 32 + (uint64_t)l_name + 4 * (uint64_t)n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
-    if (need > (uint64_t)bs) return false;
-    if (stream[o + 36 + l_name - 1] != 0) return false;
+    if (need > (uint64_t)bs) return 0;
+    if (o + 36 + l_name <= total && stream[o + 36 + l_name - 1] != 0) return 0;
     *next = nx; *rid_out = rid; *pos_out = pos;
-    return true;
+    return nx > total ? 2 : 1;
 }
 
 // kChain plausible records in coordinate order behind each other (or fewer, ending exactly at the
-// end of the stream)
-__device__ __forceinline__ bool plausible_chain(const uint8_t *__restrict__ stream, uint64_t total, uint64_t o,
-                                                int32_t n_ref, const int32_t *__restrict__ ref_len)
+// end of the stream or running past the end of the view)
+__device__ __forceinline__ bool plausible_chain(const uint8_t *__restrict__ stream, uint64_t total, bool is_last,
+                                                uint64_t o, int32_t n_ref, const int32_t *__restrict__ ref_len)
 {
     constexpr int kChain = 3;
     int32_t prid = -1, ppos = -1;
     for (int k = 0; k < kChain; ++k) {
-        uint64_t nx;
-        int32_t rid, pos;
-        if (!plausible_record(stream, total, o, n_ref, ref_len, &nx, &rid, &pos)) return false;
+        uint64_t nx = 0;
+        int32_t rid = -1, pos = -1;
+        const int ok = plausible_record(stream, total, is_last, o, n_ref, ref_len, &nx, &rid, &pos);
+        if (!ok) return false;
+        if (ok == 2 && o + 36 > total) return true;        // nothing of it can be checked
         if (k) {
             // coordinate order; unplaced records (-1) only at the end
             if (prid < 0 ? rid >= 0 : (rid >= 0 && (rid < prid || (rid == prid && pos < ppos)))) return false;
         }
+        if (ok == 2) return true;
         prid = rid; ppos = pos;
         o = nx;
         if (o == total) return true;
@@ -111,7 +118,7 @@ __device__ __forceinline__ bool plausible_chain(const uint8_t *__restrict__ stre
 
 __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ stream, uint64_t total,
                                                  const uint64_t *__restrict__ seg_start, int64_t n_seg,
-                                                 int32_t n_ref, const int32_t *__restrict__ ref_len,
+                                                 int32_t n_ref, const int32_t *__restrict__ ref_len, int is_last,
                                                  uint16_t *__restrict__ off16, SegSummary *__restrict__ sum)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,17 +128,18 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ str
     // inside blocks (htslib, BamWriter); otherwise (htsjdk lets records run across block borders)
     // the first offset behind which a chain of plausible records follows
     uint64_t o = base;
-    while (o < limit && !plausible_chain(stream, total, o, n_ref, ref_len)) ++o;
+    while (o < limit && !plausible_chain(stream, total, is_last != 0, o, n_ref, ref_len)) ++o;
     const uint64_t first = o;
     uint16_t *mine = off16 + s * kMaxRecPerSeg;
     uint32_t np = 0, nu = 0, flags = 0;
     int32_t frid = -1, fpos = -1, prid = -1, ppos = -1;
     while (o < limit) {
-        if (o + 36 > total) { flags |= kFlagBad; break; }
+        const uint32_t cut = is_last ? kFlagBad : kFlagIncomplete;     // the record is cut off by the view
+        if (o + 36 > total) { flags |= cut; break; }
         const int32_t bs = (int32_t)ld32(stream + o);
         if (bs < 32) { flags |= kFlagBad; break; }
         const uint64_t next = o + 4 + (uint64_t)bs;
-        if (next > total) { flags |= kFlagBad; break; }
+        if (next > total) { flags |= cut; break; }
         const int32_t rid = (int32_t)ld32(stream + o + 4);
         if (rid < 0) { ++nu; o = next; continue; }                   // unplaced: skipped
         if (rid >= n_ref) { flags |= kFlagBad; break; }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
     const uint16_t *__restrict__ off16, const uint32_t *__restrict__ seg_n,
     const int64_t *__restrict__ seg_base, const int32_t *__restrict__ seg_prev_rid,
     int32_t *__restrict__ pos, uint16_t *__restrict__ flag, uint8_t *__restrict__ mapq,
-    int32_t *__restrict__ tlen, int32_t *__restrict__ end, long long *__restrict__ ref_first)
+    int32_t *__restrict__ tlen, int32_t *__restrict__ end, long long *__restrict__ ref_first, int64_t index0)
 {
     const int64_t s = blockIdx.x;
     const uint32_t n = seg_n[s];
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
         tlen[i] = (int32_t)ld32(r + 32);
         end[i] = (int32_t)(p + rlen - 1);
         const int32_t prev = k ? (int32_t)ld32(seg + offs[k - 1] + 4) : seg_prev_rid[s];
-        for (int32_t q = prev + 1; q <= rid; ++q) ref_first[q] = i;     // each q is written once
+        for (int32_t q = prev + 1; q <= rid; ++q) ref_first[q] = index0 + i;     // each q is written once
     }
 }
 
@@ -240,7 +248,41 @@ namespace bsig {
 // > 0: the file (or this build's limits) needs the CPU decode path; nothing was allocated
 constexpr int kNeedsCpuPath = 1;
 
+namespace {
+
+// the columns of one chunk of the stream
+struct Piece {
+    DevPool pool;
+    int32_t *pos = nullptr, *end = nullptr, *tlen = nullptr;
+    uint16_t *flag = nullptr;
+    uint8_t *mapq = nullptr;
+    int64_t n = 0;
+    hipError_t alloc(int64_t count)
+    {
+        n = count;
+        hipError_t e = pool.alloc(&pos, (size_t)count);
+        if (e == hipSuccess) e = pool.alloc(&end, (size_t)count);
+        if (e == hipSuccess) e = pool.alloc(&tlen, (size_t)count);
+        if (e == hipSuccess) e = pool.alloc(&flag, (size_t)count);
+        if (e == hipSuccess) e = pool.alloc(&mapq, (size_t)count);
+        return e;
+    }
+};
+
+uint64_t env_mb(const char *name, uint64_t dflt_mb)
+{
+    if (const char *e = getenv(name)) { const long long v = atoll(e); if (v > 0) return (uint64_t)v << 20; }
+    return dflt_mb << 20;
+}
+
+}  // namespace
+
 // Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
+//
+// The uncompressed stream passes through HBM in chunks (default 8 GiB; a 30x human BAM inflates to
+// hundreds of GB): [carried tail | chunk].  A chunk ends at a BGZF block border; the record that
+// runs past it is carried in front of the next chunk, where the chain of records continues at
+// offset 0.  Every chunk leaves a piece of the columns; the pieces are joined at the end.
 int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, bsig_reads **out)
 {
     double *T = g_dev_decode_timing;
@@ -259,127 +301,214 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         uoff[k + 1] = uoff[k] + blocks[k].isize;
     }
     const uint64_t total = uoff[nb];
-    uint64_t max_stream = 64ull << 30;
-    if (const char *e = getenv("BAMSIGNALS_DEVICE_DECODE_MAX_GB")) max_stream = (uint64_t)atoll(e) << 30;
-    if (total < 12 || total > max_stream) return kNeedsCpuPath;
+    if (total < 12) return kNeedsCpuPath;
+    BamHeader hdr;
+    rc = bam_read_header(path, hdr);
+    if (rc) return kNeedsCpuPath;                      // the CPU path reports what is wrong
+    const int32_t n_ref = (int32_t)hdr.names.size();
     T[0] = now_s() - t_begin;
 
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    DevPool tmp;
-    uint8_t *d_stream = nullptr;
-    HIP_TRY(tmp.alloc(&d_stream, (size_t)total + 64));
-
-    // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ----------------
+    const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
+    const uint64_t carry_cap = total <= chunk_cap ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
     size_t batch_bytes = 128u << 20;
     if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {          // testing: many small batches
         const long v = atol(e);
         if (v > 0) batch_bytes = (size_t)v * 65536u;
     }
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevPool tmp;
+    uint8_t *d_view = nullptr;
+    HIP_TRY(tmp.alloc(&d_view, (size_t)(carry_cap + std::min(total, chunk_cap)) + 64));
+    uint8_t *const d_data = d_view + carry_cap;        // where every chunk's own bytes begin
+    int32_t *d_ref_len = nullptr;
+    long long *d_ref_first = nullptr;
+    HIP_TRY(tmp.alloc(&d_ref_len, (size_t)std::max(n_ref, 1)));
+    HIP_TRY(tmp.alloc(&d_ref_first, (size_t)n_ref + 1));
+    if (n_ref) HIP_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
+
     std::lock_guard<std::mutex> lock(g_staging.mu);
     rc = g_staging.ensure(batch_bytes);
     if (rc) return rc;
-    BamHeader hdr;
-    int64_t header_end = -1;
-    std::vector<uint8_t> head;                 // the first bytes of the stream, for the header
+
+    // a failure from here on must drain the stream before the buffers go away
+    auto decline = [&]() { (void)hipStreamSynchronize(st); return kNeedsCpuPath; };
+#define DD_TRY(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipStreamSynchronize(st);                                                        \
+            return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,              \
+                        "HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                          \
+    } while (0)
+
+    std::vector<std::unique_ptr<Piece>> pieces;
+    int64_t n_reads = 0;
+    int32_t last_rid = -1, last_pos = -1;
+    uint64_t tail = 0;                         // bytes carried in front of d_data
     int half = 0;
     bool used[2] = {false, false};
-    double t_inflate = 0, t_wait = 0;
-    for (size_t b0 = 0; b0 < nb;) {
-        size_t b1 = b0;
-        uint64_t bytes = 0;
-        while (b1 < nb && bytes + blocks[b1].isize <= batch_bytes) bytes += blocks[b1++].isize;
-        if (b1 == b0) return kNeedsCpuPath;    // cannot happen: a block is <= 64 KiB
-        double t0 = now_s();
-        if (used[half]) HIP_TRY(hipEventSynchronize(g_staging.ev[half]));
-        t_wait += now_s() - t0;
-        t0 = now_s();
-        rc = f.inflate(b0, b1, g_staging.buf[half], threads);
-        if (rc) { (void)hipStreamSynchronize(st); return kNeedsCpuPath; }   // the CPU path reports the error
-        t_inflate += now_s() - t0;
-        if (header_end < 0) {
-            // where the records start: read off the head of the stream (it spans several batches only
-            // in the small-batch test mode; only then is anything copied)
-            if (head.empty()) header_end = bam_header_bytes(g_staging.buf[half], bytes);
-            if (header_end == -1) {
-                head.insert(head.end(), g_staging.buf[half], g_staging.buf[half] + bytes);
-                header_end = bam_header_bytes(head.data(), head.size());
-            }
-            if (header_end == -2) { (void)hipStreamSynchronize(st); return kNeedsCpuPath; }
-            if (header_end >= 0) std::vector<uint8_t>().swap(head);
+    double t_inflate = 0, t_wait = 0, t_gpu = 0;
+    bool first_chunk = true;
+    // per-chunk scratch, sized for the largest chunk
+    size_t max_seg = 0;
+    {
+        size_t b = 0;
+        while (b < nb) {
+            size_t e = b;
+            uint64_t bytes = 0;
+            while (e < nb && (e == b || bytes + blocks[e].isize <= chunk_cap)) bytes += blocks[e++].isize;
+            max_seg = std::max(max_seg, e - b + 2);
+            b = e;
         }
-        if (bytes) HIP_TRY(hipMemcpyAsync(d_stream + uoff[b0], g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipEventRecord(g_staging.ev[half], st));
-        used[half] = true;
-        half ^= 1;
-        b0 = b1;
     }
-    T[1] = t_inflate;
-    T[2] = t_wait;
-    if (header_end < 0) { (void)hipStreamSynchronize(st); return kNeedsCpuPath; }
-    rc = bam_read_header(path, hdr);
-    if (rc) { (void)hipStreamSynchronize(st); return rc; }
-    const int32_t n_ref = (int32_t)hdr.names.size();
-
-    // ---- segments: the rest of the block the header ends in, then one per BGZF block -------------
-    const double t_gpu = now_s();
-    std::vector<uint64_t> seg_start;
-    seg_start.push_back((uint64_t)header_end);
-    for (size_t k = 1; k <= nb; ++k)
-        if (uoff[k] > (uint64_t)header_end) seg_start.push_back(uoff[k]);
-    if (seg_start.back() != total) seg_start.push_back(total);      // header ends exactly at the stream end
-    const int64_t n_seg = (int64_t)seg_start.size() - 1;
     uint64_t *d_seg_start = nullptr;
     uint16_t *d_off16 = nullptr;
     SegSummary *d_sum = nullptr;
-    std::vector<SegSummary> sum((size_t)std::max<int64_t>(n_seg, 1));
-    if (n_seg > 0) {
-        HIP_TRY(tmp.alloc(&d_seg_start, seg_start.size()));
-        HIP_TRY(tmp.alloc(&d_off16, (size_t)n_seg * kMaxRecPerSeg));
-        HIP_TRY(tmp.alloc(&d_sum, (size_t)n_seg));
-        HIP_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        int32_t *d_ref_len = nullptr;
-        HIP_TRY(tmp.alloc(&d_ref_len, (size_t)std::max(n_ref, 1)));
-        if (n_ref) HIP_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_stream, total, d_seg_start,
-                           n_seg, n_ref, d_ref_len, d_off16, d_sum);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
+    uint32_t *d_seg_n = nullptr;
+    int64_t *d_seg_base = nullptr;
+    int32_t *d_seg_prev = nullptr;
+    HIP_TRY(tmp.alloc(&d_seg_start, max_seg + 1));
+    HIP_TRY(tmp.alloc(&d_off16, max_seg * kMaxRecPerSeg));
+    HIP_TRY(tmp.alloc(&d_sum, max_seg));
+    HIP_TRY(tmp.alloc(&d_seg_n, max_seg));
+    HIP_TRY(tmp.alloc(&d_seg_base, max_seg));
+    HIP_TRY(tmp.alloc(&d_seg_prev, max_seg));
+    std::vector<uint64_t> seg_start;
+    std::vector<SegSummary> sum;
+    std::vector<uint32_t> seg_n;
+    std::vector<int64_t> seg_base;
+    std::vector<int32_t> seg_prev;
 
-    // ---- host: the chain of records from the header must run through every block's first record ----
-    // (this is what proves the starts the lanes chose: a walk from the first record that always
-    // arrives exactly at the next block's chosen start IS the serial walk of the whole stream)
-    std::vector<uint32_t> seg_n((size_t)std::max<int64_t>(n_seg, 1), 0);
-    std::vector<int64_t> seg_base((size_t)std::max<int64_t>(n_seg, 1), 0);
-    std::vector<int32_t> seg_prev((size_t)std::max<int64_t>(n_seg, 1), -1);
-    uint64_t o = (uint64_t)header_end;
-    int64_t n_reads = 0;
-    int32_t last_rid = -1, last_pos = -1;
-    for (int64_t s = 0; s < n_seg; ++s) {
-        const uint64_t a = seg_start[(size_t)s], b = seg_start[(size_t)s + 1];
-        if (a == b || o >= b) continue;         // empty block, or the current record runs through all of it
-        const SegSummary &g = sum[(size_t)s];
-        if (g.first != o) return kNeedsCpuPath; // a <= o < b: the lane must have chosen exactly this start
-        if (g.flags) return kNeedsCpuPath;                         // damaged, unsorted or CG-tag CIGARs
-        if (g.n_placed) {
-            if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return kNeedsCpuPath;
-            seg_n[(size_t)s] = g.n_placed;
-            seg_base[(size_t)s] = n_reads;
-            seg_prev[(size_t)s] = last_rid;
-            last_rid = g.last_rid; last_pos = g.last_pos;
-            n_reads += g.n_placed;
+    for (size_t B0 = 0; B0 < nb;) {
+        size_t B1 = B0;
+        uint64_t chunk_bytes = 0;
+        while (B1 < nb && (B1 == B0 || chunk_bytes + blocks[B1].isize <= chunk_cap)) chunk_bytes += blocks[B1++].isize;
+        const bool is_last = B1 == nb;
+
+        // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
+        int64_t header_end = -1;
+        std::vector<uint8_t> head;             // the head of the stream, only if the header spans batches
+        for (size_t b0 = B0; b0 < B1;) {
+            size_t b1 = b0;
+            uint64_t bytes = 0;
+            while (b1 < B1 && bytes + blocks[b1].isize <= batch_bytes) bytes += blocks[b1++].isize;
+            if (b1 == b0) return decline();    // cannot happen: a block is <= 64 KiB
+            double t0 = now_s();
+            if (used[half]) DD_TRY(hipEventSynchronize(g_staging.ev[half]));
+            t_wait += now_s() - t0;
+            t0 = now_s();
+            rc = f.inflate(b0, b1, g_staging.buf[half], threads);
+            if (rc) return decline();          // the CPU path reports the error
+            t_inflate += now_s() - t0;
+            if (first_chunk && header_end < 0) {
+                // where the records start: read off the head of the stream (it spans several batches
+                // only in the small-batch test mode; only then is anything copied)
+                if (head.empty()) header_end = bam_header_bytes(g_staging.buf[half], bytes);
+                if (header_end == -1) {
+                    head.insert(head.end(), g_staging.buf[half], g_staging.buf[half] + bytes);
+                    header_end = bam_header_bytes(head.data(), head.size());
+                }
+                if (header_end == -2) return decline();
+                if (header_end >= 0) std::vector<uint8_t>().swap(head);
+            }
+            if (bytes) DD_TRY(hipMemcpyAsync(d_data + (uoff[b0] - uoff[B0]), g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
+            DD_TRY(hipEventRecord(g_staging.ev[half], st));
+            used[half] = true;
+            half ^= 1;
+            b0 = b1;
         }
-        o = g.end;
-    }
-    if (o != total) return kNeedsCpuPath;                           // truncated last record
+        if (first_chunk && header_end < 0) return decline();      // header larger than a chunk
 
-    // ---- columns ---------------------------------------------------------------------------------
+        // ---- segments of the view [tail | chunk]: from where the chain stands, then one per block --
+        const double t0 = now_s();
+        const uint8_t *d_stream = d_data - tail;
+        const uint64_t view = tail + chunk_bytes;
+        const uint64_t o0 = first_chunk ? (uint64_t)header_end : 0;
+        seg_start.clear();
+        seg_start.push_back(o0);
+        for (size_t k = B0; k <= B1; ++k) {
+            const uint64_t a = tail + (uoff[k] - uoff[B0]);
+            if (a > o0) seg_start.push_back(a);
+        }
+        if (seg_start.back() != view) seg_start.push_back(view);
+        const int64_t n_seg = (int64_t)seg_start.size() - 1;
+        if ((size_t)n_seg > max_seg) return decline();
+        sum.assign((size_t)std::max<int64_t>(n_seg, 1), SegSummary{});
+        if (n_seg > 0) {
+            DD_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_stream, view, d_seg_start,
+                               n_seg, n_ref, d_ref_len, is_last ? 1 : 0, d_off16, d_sum);
+            DD_TRY(hipGetLastError());
+            DD_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
+        }
+        DD_TRY(hipStreamSynchronize(st));
+
+        // ---- host: the chain of records must run through every block's proposed first record ------
+        // (this is what proves the starts the lanes chose: a walk that always arrives exactly at the
+        // next block's chosen start IS the serial walk of the whole stream)
+        seg_n.assign((size_t)std::max<int64_t>(n_seg, 1), 0);
+        seg_base.assign((size_t)std::max<int64_t>(n_seg, 1), 0);
+        seg_prev.assign((size_t)std::max<int64_t>(n_seg, 1), -1);
+        uint64_t o = o0;
+        int64_t n_chunk = 0;
+        bool cut = false;
+        for (int64_t s = 0; s < n_seg; ++s) {
+            const uint64_t a = seg_start[(size_t)s], b = seg_start[(size_t)s + 1];
+            if (a == b || o >= b) continue;         // empty block, or the current record runs through all of it
+            const SegSummary &g = sum[(size_t)s];
+            if (g.first != o) return decline();     // a <= o < b: the lane must have chosen exactly this start
+            if (g.flags & ~kFlagIncomplete) return decline();          // damaged, unsorted or CG-tag CIGARs
+            if (g.n_placed) {
+                if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return decline();
+                seg_n[(size_t)s] = g.n_placed;
+                seg_base[(size_t)s] = n_chunk;
+                seg_prev[(size_t)s] = last_rid;
+                last_rid = g.last_rid; last_pos = g.last_pos;
+                n_chunk += g.n_placed;
+            }
+            o = g.end;
+            if (g.flags & kFlagIncomplete) { cut = true; break; }      // the rest of the view is that record's
+        }
+        if (is_last ? (cut || o != view) : (!cut && o < view)) return decline();   // truncated / chain lost
+        const uint64_t new_tail = view - std::min(o, view);
+        if (new_tail > carry_cap || (new_tail && o < tail)) return decline();     // a record larger than the carry
+
+        // ---- this chunk's columns -------------------------------------------------------------------
+        if (n_chunk > 0) {
+            pieces.emplace_back(new Piece);
+            Piece &pc = *pieces.back();
+            DD_TRY(pc.alloc(n_chunk));
+            DD_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            DD_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            DD_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)n_seg), dim3(kExtractThreads), 0, st, d_stream, d_seg_start, d_off16,
+                               d_seg_n, d_seg_base, d_seg_prev, pc.pos, pc.flag, pc.mapq, pc.tlen, pc.end, d_ref_first, n_reads);
+            DD_TRY(hipGetLastError());
+            n_reads += n_chunk;
+        }
+        // the cut-off record moves in front of the next chunk (source and destination do not overlap:
+        // it starts inside this chunk's own bytes)
+        if (new_tail) DD_TRY(hipMemcpyAsync(d_data - new_tail, d_stream + o, (size_t)new_tail, hipMemcpyDeviceToDevice, st));
+        // the host arrays of this chunk are reused: the copies above must have left them
+        DD_TRY(hipStreamSynchronize(st));
+        tail = new_tail;
+        first_chunk = false;
+        t_gpu += now_s() - t0;
+        B0 = B1;
+    }
+    T[1] = t_inflate;
+    T[2] = t_wait;
+
+    // ---- join the pieces, first read of every reference ----------------------------------------------
+    const double t_join = now_s();
     bsig_reads *R = new bsig_reads;
     R->ctx = ctx;
     std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
-    auto bail = [&](int code) { delete R; return code; };
+    auto bail = [&](int code) { (void)hipStreamSynchronize(st); delete R; return code; };
     if (n_reads == 0 || n_ref == 0) {
         rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
         if (rc) return bail(rc);
@@ -387,48 +516,38 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         T[4] = now_s() - t_begin;
         return BSIG_OK;
     }
-    int32_t *d_pos = nullptr, *d_end = nullptr, *d_tlen = nullptr;
-    uint16_t *d_flag = nullptr;
-    uint8_t *d_mapq = nullptr;
-    uint32_t *d_seg_n = nullptr;
-    int64_t *d_seg_base = nullptr;
-    int32_t *d_seg_prev = nullptr;
-    long long *d_ref_first = nullptr;
-#define DD_TRY(expr)                                                                               \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return bail(fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,         \
-                             "HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__)); \
-    } while (0)
-    DD_TRY(tmp.alloc(&d_pos, (size_t)n_reads));
-    DD_TRY(tmp.alloc(&d_end, (size_t)n_reads));
-    DD_TRY(tmp.alloc(&d_tlen, (size_t)n_reads));
-    DD_TRY(tmp.alloc(&d_flag, (size_t)n_reads));
-    DD_TRY(tmp.alloc(&d_mapq, (size_t)n_reads));
-    DD_TRY(tmp.alloc(&d_seg_n, (size_t)n_seg));
-    DD_TRY(tmp.alloc(&d_seg_base, (size_t)n_seg));
-    DD_TRY(tmp.alloc(&d_seg_prev, (size_t)n_seg));
-    DD_TRY(tmp.alloc(&d_ref_first, (size_t)n_ref + 1));
-    DD_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    DD_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    DD_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    DD_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
-    hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)n_seg), dim3(kExtractThreads), 0, st, d_stream, d_seg_start, d_off16,
-                       d_seg_n, d_seg_base, d_seg_prev, d_pos, d_flag, d_mapq, d_tlen, d_end, d_ref_first);
-    DD_TRY(hipGetLastError());
+    Piece whole;
+    Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
+    hipError_t e = hipSuccess;
+    if (pieces.size() > 1) {
+        e = whole.alloc(n_reads);
+        int64_t at = 0;
+        for (auto &pp : pieces) {
+            Piece &pc = *pp;
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st);
+            at += pc.n;
+        }
+    }
     std::vector<long long> ref_first((size_t)n_ref + 1, -1);
-    DD_TRY(hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
-    DD_TRY(hipStreamSynchronize(st));
-#undef DD_TRY
+    if (e == hipSuccess) e = hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+        return bail(fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "joining the decoded columns failed: %s", hipGetErrorString(e)));
+    if (pieces.size() > 1) pieces.clear();
     ref_off[(size_t)n_ref] = n_reads;
     for (int32_t r = n_ref - 1; r >= 0; --r)
         ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
     ref_off[0] = 0;
-    T[3] = now_s() - t_gpu;
+    T[3] = t_gpu + (now_s() - t_join);
+#undef DD_TRY
 
     const double t_lay = now_s();
-    rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), d_pos, d_end, d_flag, d_mapq, d_tlen);
+    rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), cols->pos, cols->end, cols->flag, cols->mapq,
+                            cols->tlen);
     if (rc) return bail(rc);
     T[5] = now_s() - t_lay;
     T[4] = now_s() - t_begin;

@@ -248,6 +248,50 @@ def test_records_crossing_block_borders_and_oversized_records(ctx, tmp_path, mon
     dev.close()
 
 
+def test_stream_in_chunks(ctx, tmp_path, monkeypatch):
+    """the uncompressed stream passes through HBM in chunks (8 GiB by default; 1 MiB here): the record
+    cut off by a chunk border is carried in front of the next chunk"""
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", "1")
+    stream = gzip.decompress(open(BAM, "rb").read())
+    assert len(stream) > (4 << 20)
+    _, dev = _both_ways(ctx, BAM, monkeypatch)                          # htslib's blocks: borders are record starts
+    assert dev.n_reads == 99000
+    dev.close()
+    for k, sizes in enumerate(([4000, 9001, 517, 65000], [65536])):    # records across block AND chunk borders
+        p = tmp_path / ("straddle%d.bam" % k)
+        p.write_bytes(_bgzf(stream, sizes))
+        _empty_bai(str(p) + ".bai", 3)
+        _, dev = _both_ways(ctx, str(p), monkeypatch)
+        assert dev.n_reads == 99000
+        dev.close()
+    # 300,000 reads, 16 MB of stream, three references
+    cols = synth_reads(300_000, [900_000, 70_000, 400_000], seed=4, paired=True)
+    path = str(tmp_path / "syn.bam")
+    write_columns_as_bam(path, ["a", "b", "c"], cols)
+    _, dev = _both_ways(ctx, path, monkeypatch)
+    assert dev.n_reads == 300_000
+    dev.close()
+    # a 150-kB record carried over a chunk border (spec-derived)
+    text = b"@SQ\tSN:c\tLN:3000000\n"
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\x00" + struct.pack("<i", 3000000)
+
+    def rec(pos, lseq):
+        name = b"q\x00"
+        body = struct.pack("<iiBBHHHiiii", 0, pos, len(name), 40, 4681, 1, 0, lseq, -1, -1, 0) + name
+        body += struct.pack("<I", (max(lseq, 30) << 4) | 0) + bytes((lseq + 1) // 2) + b"\xff" * lseq
+        return struct.pack("<i", len(body)) + body
+    recs = [rec(10 + i, 20_000 if i % 7 else 100_000) for i in range(120)]        # 30 kB and 150 kB records
+    data = hdr + b"".join(recs)
+    p = tmp_path / "bigs.bam"
+    p.write_bytes(_bgzf(data, [65536]))
+    _empty_bai(str(p) + ".bai", 1)
+    _, dev = _both_ways(ctx, str(p), monkeypatch)
+    assert dev.n_reads == 120
+    dev.close()
+
+
 def test_damaged_files_report_the_cpu_paths_errors(ctx, tmp_path, monkeypatch):
     """a truncated last record and an unsorted file: the device path declines, the CPU path names
     the problem"""
