@@ -920,9 +920,16 @@ int bam_read_header(const std::string &path, BamHeader &hdr)
 // ---------------------------------------------------------------------------------------------
 int bai_load(const std::string &bai_path, BaiIndex &idx)
 {
-    std::ifstream in(bai_path, std::ios::binary);
+    FILE *in = fopen(bai_path.c_str(), "rb");
     if (!in) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", bai_path.c_str());
-    std::vector<uint8_t> d((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> d;
+    {
+        struct stat stt;
+        if (fstat(fileno(in), &stt) == 0 && stt.st_size > 0) d.resize((size_t)stt.st_size);
+        const size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), in);
+        d.resize(got);
+        fclose(in);
+    }
     size_t o = 0;
     auto need = [&](size_t n) { return o + n <= d.size(); };
     if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) return fail(BSIG_ERR_FORMAT, "%s is not a BAI index", bai_path.c_str());
