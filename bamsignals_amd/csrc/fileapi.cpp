@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bamsignals_abi.h"
@@ -474,8 +475,31 @@ int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off,
         const int64_t i = which[k];
         if (len < 0 || i < 0) return fail(BSIG_ERR_ARG, "bad segment %lld", (long long)k);
         if (len != dst_off[i + 1] - dst_off[i]) return fail(BSIG_ERR_ARG, "segment %lld does not fit its destination", (long long)k);
-        if (len) memcpy(dst + dst_off[i], src + src_off[k], (size_t)len * sizeof(int32_t));
     }
+    if (n <= 0) return BSIG_OK;
+    auto copy_range = [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const int64_t len = src_off[k + 1] - src_off[k];
+            if (len) memcpy(dst + dst_off[which[k]], src + src_off[k], (size_t)len * sizeof(int32_t));
+        }
+    };
+    // the destinations are disjoint (each range owns its cells): big results are moved by a few
+    // threads, each taking a contiguous share of the source
+    const int64_t cells = src_off[n] - src_off[0];
+    int n_thr = cells * (int64_t)sizeof(int32_t) >= (16 << 20) ? 8 : 1;
+    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    n_thr = (int)std::min<int64_t>(n_thr, n);
+    if (n_thr <= 1) { copy_range(0, n); return BSIG_OK; }
+    std::vector<int64_t> cut((size_t)n_thr + 1, n);
+    cut[0] = 0;
+    for (int t = 1; t < n_thr; ++t) {
+        const int64_t target = src_off[0] + cells * t / n_thr;
+        cut[(size_t)t] = std::lower_bound(src_off, src_off + n, target) - src_off;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; ++t) th.emplace_back(copy_range, cut[(size_t)t], cut[(size_t)t + 1]);
+    copy_range(cut[0], cut[1]);
+    for (auto &x : th) x.join();
     return BSIG_OK;
 }
 
