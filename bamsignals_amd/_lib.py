@@ -99,6 +99,11 @@ def load():
     lib.bsig_plan_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.bsig_plan_run_host.argtypes = [C.c_void_p, C.c_void_p]
     lib.bsig_plan_run_host_async.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bsig_graph_begin.argtypes = [C.c_void_p]
+    lib.bsig_graph_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.bsig_graph_launch.argtypes = [C.c_void_p]
+    lib.bsig_graph_free.argtypes = [C.c_void_p]
+    lib.bsig_graph_free.restype = None
     lib.bsig_plan_free.argtypes = [C.c_void_p]
     lib.bsig_plan_free.restype = None
     lib.bsig_pileup_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -805,6 +805,58 @@ int bsig_plan_run_host_async(bsig_plan *p, int32_t *out_host)
     return BSIG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// launch trains as HIP graphs: a fixed sequence of bsig_plan_run() calls on one context is
+// captured once and replayed with one host call per replay (a step of config 2 is 23 us of GPU
+// time: a host thread that issues every launch itself must never be late by more than that)
+// ---------------------------------------------------------------------------------------------
+struct bsig_graph {
+    bsig_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int bsig_graph_begin(bsig_ctx *ctx)
+{
+    if (!ctx) return fail(BSIG_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return BSIG_OK;
+}
+
+int bsig_graph_end(bsig_ctx *ctx, bsig_graph **out)
+{
+    if (!ctx || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_graph_end");
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamEndCapture(ctx->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail(BSIG_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    bsig_graph *G = new bsig_graph;
+    G->ctx = ctx; G->graph = g; G->exec = ex;
+    *out = G;
+    return BSIG_OK;
+}
+
+int bsig_graph_launch(bsig_graph *g)
+{
+    if (!g) return fail(BSIG_ERR_ARG, "graph is NULL");
+    HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
+    return BSIG_OK;
+}
+
+void bsig_graph_free(bsig_graph *g)
+{
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
 int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
 {
     if (!p || !s) return fail(BSIG_ERR_ARG, "NULL argument");

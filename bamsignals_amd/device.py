@@ -239,6 +239,44 @@ class Plan:
         self.close()
 
 
+class LaunchGraph:
+    """A train of ``Plan.run_device`` calls on one context captured as a HIP graph::
+
+        with LaunchGraph(ctx) as g:
+            for plan, out in zip(plans, outs):
+                plan.run_device(out.data_ptr())      # recorded, not executed
+        g.launch()                                   # one host call replays the whole train
+    """
+
+    def __init__(self, ctx):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        self._h = None
+
+    def __enter__(self):
+        _lib.check(self._lib.bsig_graph_begin(self.ctx._h))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        h = C.c_void_p()
+        rc = self._lib.bsig_graph_end(self.ctx._h, C.byref(h))
+        if exc_type is None:
+            _lib.check(rc)
+        self._h = h if rc == 0 else None
+        return False
+
+    def launch(self):
+        _lib.check(self._lib.bsig_graph_launch(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bsig_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 def layout(length, binsize, ss):
     """Flat offsets of the result (allocateList's shapes, ref: src/bamsignals.cpp:139-192)."""
     lib = _lib.load()

@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even with one rank (exercises RCCL "
                          "on a 1-GPU box)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the round of --batches launches as a HIP graph instead of issuing every launch "
+                         "from Python (same kernels; measured 0.4-0.6 us per step SLOWER on MI355X, so off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0xBA51)
     a = ap.parse_args()
@@ -112,7 +115,7 @@ def main():
             dist.init_process_group("gloo")
 
     from bamsignals_amd import _lib
-    from bamsignals_amd.device import Context, Plan, Reads, make_params
+    from bamsignals_amd.device import Context, LaunchGraph, Plan, Reads, make_params
     from bamsignals_amd.synth import synth_ranges, synth_reads
 
     cfg = CONFIGS[a.config]
@@ -159,8 +162,27 @@ def main():
 
         for b in range(nb):                      # every result buffer is produced at least once
             plans[b].run_device(outs[b].data_ptr())
-        for s in range(a.warmup):
-            plans[s % nb].run_device(outs[s % nb].data_ptr())
+        # One round over the batches = nb launches of the pileup kernel.  With --graph the round is
+        # captured as a HIP graph and replayed (one host call per nb steps).  The default is the plain
+        # loop: the host keeps ahead of the 23-us steps (ms_per_step == kernel_ms) and the graph's
+        # kernel-to-kernel boundaries are 0.4-0.6 us longer than the stream's.
+        graph = None
+        if a.graph:
+            graph = LaunchGraph(ctx)
+            with graph:
+                for b in range(nb):
+                    plans[b].run_device(outs[b].data_ptr())
+
+        def run_steps(k):
+            s = 0
+            if graph is not None:
+                for _ in range(k // nb):
+                    graph.launch()
+                s = k - k % nb
+            for q in range(s, k):
+                plans[q % nb].run_device(outs[q % nb].data_ptr())
+
+        run_steps(a.warmup)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -170,8 +192,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t_start = time.perf_counter()
         e0.record(stream)
-        for s in range(a.steps):
-            plans[s % nb].run_device(outs[s % nb].data_ptr())
+        run_steps(a.steps)
         e1.record(stream)
         torch.cuda.synchronize()
         # this rank's K steps are done: stop its clock here.  The closing barrier only lines the ranks
@@ -310,6 +331,7 @@ def main():
             "config": {"workload": a.config + ": " + cfg["desc"], "reads": n_reads,
                        "ranges_per_gpu": len(rg["rid"]), "range_width": width, "batches": nb,
                        "parallelism": f"ranges round-robin over {world} GPU(s), reads replicated",
+                       "launch": f"HIP graph of {nb} launches, replayed" if a.graph else "one launch per step from the host loop",
                        "threads": params.threads or 64,
                        "tile_cells": params.tile_cells or "auto (widest range, at most 2048)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -162,6 +162,15 @@ int bsig_plan_run_host(bsig_plan *plan, int32_t *out_host);
 int bsig_plan_run_host_async(bsig_plan *plan, int32_t *out_host);
 void bsig_plan_free(bsig_plan *plan);
 
+/* A fixed train of bsig_plan_run() calls on one context, captured once as a HIP graph and replayed
+ * with one host call per replay: between bsig_graph_begin and bsig_graph_end the bsig_plan_run
+ * calls on that context are recorded instead of executed.                                      */
+typedef struct bsig_graph bsig_graph;
+int bsig_graph_begin(bsig_ctx *ctx);
+int bsig_graph_end(bsig_ctx *ctx, bsig_graph **graph);
+int bsig_graph_launch(bsig_graph *graph);
+void bsig_graph_free(bsig_graph *graph);
+
 /* one-shot: columns already in HBM -> host result (upload ranges, run, download)               */
 int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,
                         const int32_t *rid, const int32_t *loc, const int32_t *len,
