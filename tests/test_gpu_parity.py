@@ -389,3 +389,39 @@ def test_heavy_tile_slices(ctx, synth, monkeypatch):
         got, _ = _gpu(ctx, hot, hr, kind, **dict(a))
         assert np.array_equal(got, want), (kind, a)
     hot.close()
+
+
+def test_launch_graph_replays_the_same_launches(synth):
+    """bsig_graph_*: a train of plan runs (profile, count with its zero fill, coverage) captured as a
+    HIP graph gives, on every replay, what the direct launches give."""
+    import torch
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Context, LaunchGraph, Plan, make_params
+    gpu, orc, cols, _ = synth["se"]
+    rng = np.random.default_rng(12)
+    rg = _rand_ranges(rng, cols["ref_len"], 300, 5000)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        c2 = Context(0, stream=stream.cuda_stream)
+        twin = gpu.clone(c2)
+        plans = [Plan(c2, twin, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(m, **a))
+                 for m, a in ((_lib.MODE_PROFILE, dict(binsize=1, ss=True, shift=11)), (_lib.MODE_COUNT, dict(binsize=-1)),
+                              (_lib.MODE_COVERAGE, dict()))]
+        want = [p.run_host().copy() for p in plans]
+        outs = [torch.full((max(p.cells, 4),), -7, dtype=torch.int32, device="cuda") for p in plans]
+        g = LaunchGraph(c2)
+        with g:
+            for p, o in zip(plans, outs):
+                p.run_device(o.data_ptr())
+        for _ in range(3):
+            for o in outs:
+                o.fill_(-7)
+            g.launch()
+            c2.sync()
+            for p, o, w in zip(plans, outs, want):
+                assert np.array_equal(o[:p.cells].cpu().numpy(), w)
+        g.close()
+        for p in plans:
+            p.close()
+        twin.close()
+        c2.close()
