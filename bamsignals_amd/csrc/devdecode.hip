@@ -310,7 +310,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
 
     const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
     const uint64_t carry_cap = total <= chunk_cap ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
-    size_t batch_bytes = 128u << 20;
+    size_t batch_bytes = 32u << 20;        // 512 blocks per copy: pinning 2 x 32 MiB is quick, the copies stay hidden
     if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {          // testing: many small batches
         const long v = atol(e);
         if (v > 0) batch_bytes = (size_t)v * 65536u;
