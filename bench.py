@@ -51,6 +51,64 @@ CONFIGS = {
 }
 
 
+def end_to_end(cfg, n_reads, seed, rg, want_flat, device):
+    """Informational (NOT `value`): the file-level call bamProfile(bampath, gr) on a synthetic BAM written
+    to local disk -- BGZF inflate, records -> columns, HBM layout, kernels, result in host memory -- cold
+    and again with the BAM resident in HBM, next to the CPU path that includes the BAM decode (one
+    thread: this repo's BGZF/BAM reader, htslib being absent, + the oracle), as the reference's own
+    call does (ref: src/bamsignals.cpp:271 bam_itr_next inside the pileup loop)."""
+    import shutil
+    import tempfile
+
+    from bamsignals_amd import GRanges, _lib
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    from bamsignals_amd.wrappers import last_call_timing, pileup_core
+    from oracle import oracle_c
+    args = cfg["args"]
+    d = tempfile.mkdtemp(prefix="bsig_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        cols = synth_reads(n_reads, cfg["ref_len"], seed=seed, paired=cfg["paired"], with_cigar=True)
+        names = ["ref%d" % (i + 1) for i in range(len(cfg["ref_len"]))]
+        bam = os.path.join(d, "synth.bam")
+        t0 = time.perf_counter(); write_columns_as_bam(bam, names, cols, level=1); t_write = time.perf_counter() - t0
+        gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"],
+                     strand=[{1: "+", -1: "-", 0: "*"}[int(x)] for x in rg["strand"]])
+        call = dict(tlen_filter=args.get("tlen_filter", ()), mapqual=args.get("mapqual", 0), binsize=args.get("binsize", 1),
+                    shift=args.get("shift", 0), ss=args.get("ss", False), requiredF=args.get("requiredF", 0),
+                    filteredF=args.get("filteredF", -1), pe_mid=args.get("pe_mid", False), device=device)
+        _lib.load().bsig_cache_clear()
+        t0 = time.perf_counter(); sig = pileup_core(bam, gr, **call); t_cold = time.perf_counter() - t0
+        stages = last_call_timing()
+        t0 = time.perf_counter(); sig2 = pileup_core(bam, gr, **call); t_warm = time.perf_counter() - t0
+        flat = np.concatenate([np.asarray(m).T.reshape(-1) if call["ss"] else np.asarray(m) for m in sig2])
+        if not np.array_equal(flat, want_flat):
+            raise SystemExit("file-level result differs from the resident-column result")
+        del sig, sig2, flat
+        _lib.load().bsig_cache_clear()
+        b = BamFile(bam)
+        dec = b.decode(threads=1)
+        t_dec1 = b.decode_timing()["total"]
+        t0 = time.perf_counter()
+        end = oracle_c.cigar_end(dec["pos"], dec["flag"], dec["cigar_off"], dec["cigar"])
+        orc = oracle_c.OracleReads(dec["ref_off"], dec["pos"], end, dec["flag"], dec["mapq"], dec["tlen"])
+        want, _ = oracle_c.pileup_core(orc, rg, **args)
+        t_orc = time.perf_counter() - t0
+        if not np.array_equal(want, want_flat):
+            raise SystemExit("CPU path on the decoded BAM differs from the GPU result")
+        bases = int(rg["len"].astype(np.int64).sum())
+        return dict(bam_bytes=os.path.getsize(bam), write_bam_s=t_write,
+                    cold_call_s=t_cold, cold_call_stages_s=stages, warm_call_s=t_warm,
+                    cold_Mbases_s=bases / t_cold / 1e6, warm_Mbases_s=bases / t_warm / 1e6,
+                    cpu_path_s=t_dec1 + t_orc, cpu_decode_1thread_s=t_dec1, cpu_pileup_s=t_orc,
+                    cpu_path_Mbases_s=bases / (t_dec1 + t_orc) / 1e6,
+                    speedup_cold=(t_dec1 + t_orc) / t_cold, speedup_warm=(t_dec1 + t_orc) / t_warm,
+                    note="pileup_core(bampath, GRanges) -> per-range arrays in host memory; the CPU path = single-thread "
+                         "BAM decode (this repo's reader) + oracle, parity-checked against the GPU result")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +137,9 @@ def main():
                     help="replay the round of --batches launches as a HIP graph instead of issuing every launch "
                          "from Python (same kernels; measured 0.4-0.6 us per step SLOWER on MI355X, so off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the informational end-to-end section (synthetic BAM on disk -> host result, next to "
+                         "the single-thread CPU path incl. BAM decode); it runs at N=1 for <= 1e8 reads")
     ap.add_argument("--seed", type=int, default=0xBA51)
     a = ap.parse_args()
 
@@ -282,6 +343,10 @@ def main():
                                         sample=f"{reps_m} x the same workload, ranges split into {len(shards)} contiguous "
                                                f"blocks, one thread per block")
 
+        e2e = None
+        if rank == 0 and world == 1 and not use_dist and not a.no_cpu_baseline and not a.no_e2e and n_reads <= 100_000_000:
+            e2e = end_to_end(cfg, n_reads, a.seed, batches[0], got[:plan.cells], local)
+
         # ---- final reassembly on rank 0 over RCCL (outside the timed region) -------------------
         gather = None
         if use_dist:
@@ -348,6 +413,7 @@ def main():
                          "bytes_per_visit_long": stats["bytes_per_visit_long"],
                          "items": stats["n_items"], "cells": stats["cells"]},
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
             "parity_checked": parity,
             "pipelined_two_streams": pipelined,
             "gather": gather,
