@@ -336,3 +336,19 @@ def test_file_level_calls_take_the_device_decode(monkeypatch, fixture_regions, e
         assert Reads.device_decode_timing()["total"] > 0
     finally:
         _lib.load().bsig_cache_clear()
+
+
+def test_header_only_bam(ctx, tmp_path, monkeypatch):
+    """no records at all: empty resident reads, every call returns zeros"""
+    from bamsignals_amd import _lib, write_columns_as_bam
+    from bamsignals_amd.device import Plan, make_params
+    cols = dict(ref_len=np.asarray([1000, 2000], np.int32), ref_off=np.zeros(3, np.int64), pos=np.zeros(0, np.int32),
+                flag=np.zeros(0, np.uint16), mapq=np.zeros(0, np.uint8), tlen=np.zeros(0, np.int32),
+                cigar_off=np.zeros(1, np.int64), cigar=np.zeros(0, np.uint32))
+    path = str(tmp_path / "empty.bam")
+    write_columns_as_bam(path, ["a", "b"], cols)
+    bam, dev = _both_ways(ctx, path, monkeypatch)
+    assert dev.n_reads == 0
+    p = Plan(ctx, dev, [0, 1], [10, 0], [100, 2000], [1, -1], make_params(_lib.MODE_COVERAGE))
+    assert not p.run_host().any()
+    dev.close()
