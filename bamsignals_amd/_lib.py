@@ -114,6 +114,8 @@ def load():
     lib.bsig_bam_path.argtypes = [C.c_void_p]
     lib.bsig_bam_path.restype = C.c_char_p
     lib.bsig_reads_from_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bsig_reads_from_bam_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.POINTER(C.c_void_p)]
     lib.bsig_device_decode_timing.argtypes = [C.POINTER(C.c_double)]
     lib.bsig_device_decode_timing.restype = None
     lib.bsig_bam_n_ref.argtypes = [C.c_void_p]

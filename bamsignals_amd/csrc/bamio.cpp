@@ -504,23 +504,40 @@ private:
 // whole-file decode: blocks are inflated by a thread pool in batches while the previous batch
 // is parsed
 // ---------------------------------------------------------------------------------------------
+// Map the pages of the given byte spans of the file in from several threads, in slices of 4 MiB.
+// Dozens of threads that each fault single pages of one mapping queue up in the kernel (an index-
+// driven decode of 38,000 chunks spent 60 ms that way); populating whole slices first costs a few ms.
+static void populate_spans(const MappedFile &f, std::vector<std::pair<uint64_t, uint64_t>> spans)
+{
+    if (spans.empty() || !f.data) return;
+    std::sort(spans.begin(), spans.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (const auto &sp : spans) {
+        const uint64_t a = std::min<uint64_t>(sp.first, f.size) & ~4095ull, b = std::min<uint64_t>(sp.second, f.size);
+        if (a >= b) continue;
+        if (!merged.empty() && a <= merged.back().second + (256u << 10)) merged.back().second = std::max(merged.back().second, b);
+        else merged.emplace_back(a, b);
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> slices;
+    const uint64_t slice = 4u << 20;
+    for (const auto &m : merged)
+        for (uint64_t a = m.first; a < m.second; a += slice) slices.emplace_back(a, std::min(m.second, a + slice));
+    parallel_for((int64_t)slices.size(), std::min(n_threads(0), 16), [&](int64_t i, int) {
+        const uint64_t a = slices[(size_t)i].first, b = slices[(size_t)i].second;
+#ifdef MADV_POPULATE_READ
+        if (madvise((void *)(f.data + a), b - a, MADV_POPULATE_READ) == 0) return;
+#endif
+        volatile uint8_t sink = 0;
+        for (uint64_t o = a; o < b; o += 4096) sink = sink + f.data[o];
+    });
+}
+
 static int scan_blocks(const MappedFile &f, const std::string &path, std::vector<Block> &blocks)
 {
     // The scan below touches one header per block, i.e. nearly every page of the mapping, one page
-    // fault after the other.  Map the pages in from several threads first (the inflate would fault
-    // them in anyway): 8-15 ms -> a few ms for a 300-MB file.
-    if (f.size >= (16u << 20)) {
-        const size_t slice = 4u << 20;
-        const int64_t n_slices = (int64_t)((f.size + slice - 1) / slice);
-        parallel_for(n_slices, std::min(n_threads(0), 16), [&](int64_t i, int) {
-            const size_t a = (size_t)i * slice, b = std::min(f.size, a + slice);
-#ifdef MADV_POPULATE_READ
-            if (madvise((void *)(f.data + a), b - a, MADV_POPULATE_READ) == 0) return;
-#endif
-            volatile uint8_t sink = 0;
-            for (size_t o = a; o < b; o += 4096) sink = sink + f.data[o];
-        });
-    }
+    // fault after the other: map the pages in from several threads first (8-15 ms -> a few ms for a
+    // 300-MB file; the inflate would fault them in anyway).
+    if (f.size >= (16u << 20)) populate_spans(f, {{0, f.size}});
     uint64_t off = 0;
     while (off < f.size) {
         Block b;
@@ -560,6 +577,33 @@ int BgzfFile::open(const std::string &path)
     if (p_->f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
     p_->blocks.clear();
     return scan_blocks(p_->f, path, p_->blocks);
+}
+int BgzfFile::map(const std::string &path)
+{
+    if (p_->f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    p_->blocks.clear();
+    return 0;
+}
+bool BgzfFile::block_at(uint64_t off, BgzfBlock &b) const { return parse_block(p_->f, off, b); }
+void BgzfFile::populate(const std::vector<std::pair<uint64_t, uint64_t>> &spans) const { populate_spans(p_->f, spans); }
+int BgzfFile::inflate_list(const BgzfBlock *list, size_t n, uint8_t *dst, int threads) const
+{
+    if (n == 0) return 0;
+    std::vector<uint64_t> uoff(n + 1, 0);
+    for (size_t k = 0; k < n; ++k) uoff[k + 1] = uoff[k] + list[k].isize;
+    std::atomic<int> bad(0);
+    const MappedFile &f = p_->f;
+    parallel_for((int64_t)n, n_threads(threads), [&](int64_t i, int) {
+        static thread_local Inflater inf;
+        const Block &b = list[(size_t)i];
+        if (!inf.run(f.data + b.coff + b.doff, b.dlen, dst + uoff[(size_t)i], b.isize)) bad = 1;
+    });
+    if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+    return 0;
+}
+void pool_for(int64_t n, int threads, const std::function<void(int64_t)> &body)
+{
+    parallel_for(n, n_threads(threads), [&](int64_t i, int) { body(i); });
 }
 const std::vector<BgzfBlock> &BgzfFile::blocks() const { return p_->blocks; }
 const uint8_t *BgzfFile::data() const { return p_->f.data; }
@@ -990,16 +1034,8 @@ uint32_t reg2bin(int64_t beg, int64_t end)
 
 }  // namespace
 
-int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::vector<Region> &regions,
-                       int threads, BamHeader &hdr, HostColumns &cols)
+std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<Region> &regions)
 {
-    MappedFile f;
-    if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
-    threads = n_threads(threads);
-    int rc = bam_read_header(path, hdr);
-    if (rc) return rc;
-    cols = HostColumns();
-
     // candidate chunks of every region (htslib's iterator: bins + linear-index lower bound)
     std::vector<BaiChunk> chunks;
     std::vector<uint32_t> bins;
@@ -1013,12 +1049,30 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
             const size_t w = (size_t)(beg >> 14);
             min_off = w < R.linear.size() ? R.linear[w] : R.linear.back();
         }
+        // Upper bound.  htslib's iterator stops at the first record with pos >= end; the chunk lists of
+        // the coarse bins (reads that straddle a finer bin's border) run on to the end of their bin,
+        // far behind the region.  The first read of a LEAF bin behind the region's last 16-kbp window
+        // has pos >= end, and the file is sorted by pos: every read with pos < end lies in front of
+        // that read's virtual offset, which is a record boundary.
+        uint64_t max_off = ~0ull;
+        {
+            const int64_t w_end = (end - 1) >> 14;
+            for (int64_t w = w_end + 1; w <= w_end + 64 && w < (1 << 15); ++w) {
+                const uint32_t leaf = 4681u + (uint32_t)w;
+                auto it = std::lower_bound(R.bins.begin(), R.bins.end(), leaf, [](const auto &x, uint32_t v) { return x.first < v; });
+                if (it == R.bins.end() || it->first != leaf || it->second.empty()) continue;
+                uint64_t first = ~0ull;
+                for (const BaiChunk &c : it->second) first = std::min(first, c.beg);
+                max_off = first;
+                break;
+            }
+        }
         reg2bins(beg, end, bins);
         for (uint32_t b : bins) {
             auto it = std::lower_bound(R.bins.begin(), R.bins.end(), b, [](const auto &x, uint32_t v) { return x.first < v; });
             if (it == R.bins.end() || it->first != b) continue;
             for (const BaiChunk &c : it->second)
-                if (c.end > min_off) chunks.push_back(c);
+                if (c.end > min_off && c.beg < max_off) chunks.push_back(BaiChunk{c.beg, std::min(c.end, max_off)});
         }
     }
     std::sort(chunks.begin(), chunks.end(), [](const BaiChunk &a, const BaiChunk &b) { return a.beg < b.beg; });
@@ -1026,6 +1080,26 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
     for (const BaiChunk &c : chunks) {
         if (!merged.empty() && c.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, c.end);
         else merged.push_back(c);
+    }
+
+    return merged;
+}
+
+int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::vector<Region> &regions,
+                       int threads, BamHeader &hdr, HostColumns &cols)
+{
+    MappedFile f;
+    if (f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    threads = n_threads(threads);
+    int rc = bam_read_header(path, hdr);
+    if (rc) return rc;
+    cols = HostColumns();
+
+    const std::vector<BaiChunk> merged = bai_region_chunks(idx, regions);
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> spans;
+        for (const BaiChunk &c : merged) spans.emplace_back(c.beg >> 16, (c.end >> 16) + 0x10000);
+        populate_spans(f, spans);
     }
 
     // Every merged chunk is an independent job (it starts at a record boundary the index vouches

@@ -8,6 +8,7 @@
 #define BSIG_BAMIO_H
 #include <stdint.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <utility>
@@ -89,15 +90,29 @@ public:
     BgzfFile();
     ~BgzfFile();
     int open(const std::string &path);                        // maps the file and scans every block header
+    int map(const std::string &path);                         // maps the file only (index-driven access)
     const std::vector<BgzfBlock> &blocks() const;
     const uint8_t *data() const;                              // the mapped (compressed) file
     size_t size() const;
     // inflates blocks [b0, b1) back to back into dst (sum of their isize bytes); threads <= 0: default
     int inflate(size_t b0, size_t b1, uint8_t *dst, int threads) const;
+    // maps the pages of these byte spans of the file in (several threads) before they are read
+    void populate(const std::vector<std::pair<uint64_t, uint64_t>> &spans) const;
+    // the block whose header sits at file offset `off`; false if there is none / it is malformed
+    bool block_at(uint64_t off, BgzfBlock &b) const;
+    // inflates the listed blocks back to back into dst
+    int inflate_list(const BgzfBlock *list, size_t n, uint8_t *dst, int threads) const;
 private:
     struct Impl;
     Impl *p_;
 };
+
+// The file chunks htslib's iterator would visit for `regions` (bins of reg2bins + the linear
+// index's lower bound, SAM spec 5.3), sorted by file offset and merged: every chunk starts and
+// ends at a record boundary, no two overlap.
+std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<Region> &regions);
+// runs body(i) for i in [0, n) on the decode thread pool
+void pool_for(int64_t n, int threads, const std::function<void(int64_t)> &body);
 
 // bytes in front of the first record of an uncompressed BAM stream (magic, text, reference
 // table), or -1 if `n` bytes do not hold the whole header yet, -2 if it is not a BAM stream

@@ -38,6 +38,9 @@
 
 using bsig::fail;
 
+// the parsed BAI of an open BAM (fileapi.cpp owns bsig_bam); internal, not part of the C ABI
+const bsig::BaiIndex *bsig_bam_index(const bsig_bam *bam);
+
 namespace {
 
 constexpr int kMaxRecPerSeg = 1824;          // a record is >= 36 bytes, a block <= 65536
@@ -119,11 +122,19 @@ __device__ __forceinline__ bool plausible_chain(const uint8_t *__restrict__ stre
 __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ stream, uint64_t total,
                                                  const uint64_t *__restrict__ seg_start, int64_t n_seg,
                                                  int32_t n_ref, const int32_t *__restrict__ ref_len, int is_last,
+                                                 const uint64_t *__restrict__ seg_hard_end,
                                                  uint16_t *__restrict__ off16, SegSummary *__restrict__ sum)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
-    const uint64_t base = seg_start[s], limit = seg_start[s + 1];
+    const uint64_t base = seg_start[s];
+    uint64_t limit = seg_start[s + 1];
+    // index-driven decode: the view is a row of islands (runs of blocks the BAI lists); records of an
+    // island end at its own end, what lies behind is the gap to the next island
+    if (seg_hard_end) {
+        total = seg_hard_end[s];
+        if (limit > total) limit = total;
+    }
     // the first record that starts in this block: the block start itself in files that keep records
     // inside blocks (htslib, BamWriter); otherwise (htsjdk lets records run across block borders)
     // the first offset behind which a chain of plausible records follows
@@ -441,7 +452,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         if (n_seg > 0) {
             DD_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_stream, view, d_seg_start,
-                               n_seg, n_ref, d_ref_len, is_last ? 1 : 0, d_off16, d_sum);
+                               n_seg, n_ref, d_ref_len, is_last ? 1 : 0, nullptr, d_off16, d_sum);
             DD_TRY(hipGetLastError());
             DD_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
         }
@@ -555,6 +566,329 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     return BSIG_OK;
 }
 
+
+// The records the index lists for `regions` -> bsig_reads on ctx's device (what the reference gets
+// from one bam_itr_queryi per chunk of ranges, ref: src/bamsignals.cpp:252-271).  The merged BAI
+// chunks are independent islands of the file: each starts at a record boundary the index vouches
+// for.  Their blocks are inflated into one view, island behind island, and walked / extracted by
+// the same kernels as the whole file; the host check runs per island.  A superset of the
+// overlapping records, each at most once, in file order -- exactly what the CPU region decode
+// (bamio.cpp: bam_decode_regions) returns.
+int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiIndex &idx,
+                              const std::vector<Region> &regions, int threads, bsig_reads **out)
+{
+    double *T = g_dev_decode_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
+    *out = nullptr;
+    BamHeader hdr;
+    int rc = bam_read_header(path, hdr);
+    if (rc) return kNeedsCpuPath;
+    const int32_t n_ref = (int32_t)hdr.names.size();
+    const std::vector<BaiChunk> chunks = bai_region_chunks(idx, regions);
+    BgzfFile f;
+    rc = f.map(path);
+    if (rc) return rc;
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> spans;
+        for (const BaiChunk &c : chunks) spans.emplace_back(c.beg >> 16, (c.end >> 16) + 0x10000);
+        f.populate(spans);
+    }
+
+    // ---- the blocks of every island (a serial header walk per island, islands in parallel) -------
+    struct Island {
+        std::vector<BgzfBlock> blocks;
+        uint64_t bytes = 0;            // uncompressed bytes of its blocks
+        uint32_t ub = 0;               // the chain starts at this offset of the first block
+        uint64_t end = 0;              // ... and ends at this offset from the start of the first block
+        bool bad = false;
+    };
+    std::vector<Island> isl(chunks.size());
+    pool_for((int64_t)chunks.size(), threads, [&](int64_t i) {
+        Island &I = isl[(size_t)i];
+        const BaiChunk &c = chunks[(size_t)i];
+        const uint64_t cb = c.beg >> 16, ce = c.end >> 16;
+        const uint32_t ue = (uint32_t)(c.end & 0xFFFF);
+        I.ub = (uint32_t)(c.beg & 0xFFFF);
+        uint64_t off = cb;
+        bool closed = false;
+        while (off < f.size() && off <= ce) {
+            if (off == ce && ue == 0) { I.end = I.bytes; closed = true; break; }
+            BgzfBlock b;
+            if (!f.block_at(off, b) || b.isize > 65536u) { I.bad = true; return; }
+            if (off == ce) {
+                if (ue > b.isize) { I.bad = true; return; }
+                I.end = I.bytes + ue;
+                closed = true;
+            }
+            I.blocks.push_back(b);
+            I.bytes += b.isize;
+            off += b.csize;
+            if (closed) break;
+        }
+        if (!closed) I.end = I.bytes;                          // the chunk runs to the end of the file
+        if (I.blocks.empty()) { I.end = 0; I.ub = 0; return; }
+        if (I.ub > I.blocks[0].isize || I.ub > I.end) I.bad = true;
+    });
+    uint64_t total = 0;
+    for (const Island &I : isl) {
+        if (I.bad) return kNeedsCpuPath;                        // the CPU path names the problem
+        total += I.bytes;
+    }
+    T[0] = now_s() - t_begin;
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    bsig_reads *R = new bsig_reads;
+    R->ctx = ctx;
+    auto bail = [&](int code) { (void)hipStreamSynchronize(st); delete R; return code; };
+    std::vector<int64_t> ref_off((size_t)n_ref + 1, 0);
+    if (total == 0 || n_ref == 0) {
+        rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return bail(rc);
+        *out = R;
+        T[4] = now_s() - t_begin;
+        return BSIG_OK;
+    }
+
+    const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
+    size_t batch_bytes = 32u << 20;
+    if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {
+        const long v = atol(e);
+        if (v > 0) batch_bytes = (size_t)v * 65536u;
+    }
+    // groups of whole islands that pass through HBM together
+    std::vector<std::pair<size_t, size_t>> groups;
+    uint64_t max_group = 0;
+    size_t max_seg = 0;
+    for (size_t i = 0; i < isl.size();) {
+        size_t j = i;
+        uint64_t bytes = 0;
+        size_t segs = 0;
+        while (j < isl.size() && (j == i || bytes + isl[j].bytes <= chunk_cap)) { bytes += isl[j].bytes; segs += isl[j].blocks.size() + 2; ++j; }
+        if (bytes > (64ull << 30)) { delete R; return kNeedsCpuPath; }      // one island beyond any sensible chunk
+        groups.emplace_back(i, j);
+        max_group = std::max(max_group, bytes);
+        max_seg = std::max(max_seg, segs);
+        i = j;
+    }
+
+    DevPool tmp;
+    uint8_t *d_view = nullptr;
+    int32_t *d_ref_len = nullptr;
+    long long *d_ref_first = nullptr;
+    uint64_t *d_seg_start = nullptr, *d_seg_hard = nullptr;
+    uint16_t *d_off16 = nullptr;
+    SegSummary *d_sum = nullptr;
+    uint32_t *d_seg_n = nullptr;
+    int64_t *d_seg_base = nullptr;
+    int32_t *d_seg_prev = nullptr;
+#define DR_TRY(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return bail(fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,         \
+                             "HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+    DR_TRY(tmp.alloc(&d_view, (size_t)max_group + 64));
+    DR_TRY(tmp.alloc(&d_ref_len, (size_t)std::max(n_ref, 1)));
+    DR_TRY(tmp.alloc(&d_ref_first, (size_t)n_ref + 1));
+    DR_TRY(tmp.alloc(&d_seg_start, max_seg + 1));
+    DR_TRY(tmp.alloc(&d_seg_hard, max_seg + 1));
+    DR_TRY(tmp.alloc(&d_off16, max_seg * kMaxRecPerSeg));
+    DR_TRY(tmp.alloc(&d_sum, max_seg));
+    DR_TRY(tmp.alloc(&d_seg_n, max_seg));
+    DR_TRY(tmp.alloc(&d_seg_base, max_seg));
+    DR_TRY(tmp.alloc(&d_seg_prev, max_seg));
+    if (n_ref) DR_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    DR_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
+
+    std::lock_guard<std::mutex> lock(g_staging.mu);
+    rc = g_staging.ensure(batch_bytes);
+    if (rc) return bail(rc);
+    auto decline = [&]() { return bail(kNeedsCpuPath); };
+
+    std::vector<std::unique_ptr<Piece>> pieces;
+    int64_t n_reads = 0;
+    int32_t last_rid = -1, last_pos = -1;
+    int half = 0;
+    bool used[2] = {false, false};
+    double t_inflate = 0, t_wait = 0, t_gpu = 0;
+    std::vector<BgzfBlock> list;
+    std::vector<uint64_t> seg_start, seg_hard, isl_first_seg, isl_a, isl_b, isl_v0;
+    std::vector<SegSummary> sum;
+    std::vector<uint32_t> seg_n;
+    std::vector<int64_t> seg_base;
+    std::vector<int32_t> seg_prev;
+    for (const auto &gr : groups) {
+        // ---- the group's distinct blocks in file order (neighbouring islands often end and begin in
+        // the same block: it is inflated once); every island is an interval of that view ------------
+        list.clear();
+        isl_a.clear(); isl_b.clear(); isl_v0.clear();
+        uint64_t view = 0;
+        for (size_t i = gr.first; i < gr.second; ++i) {
+            const Island &I = isl[i];
+            uint64_t v0 = view;
+            for (size_t k = 0; k < I.blocks.size(); ++k) {
+                const BgzfBlock &b = I.blocks[k];
+                if (k == 0 && !list.empty() && list.back().coff == b.coff) { v0 = view - b.isize; continue; }
+                if (k == 0) v0 = view;
+                list.push_back(b);
+                view += b.isize;
+            }
+            isl_v0.push_back(v0);
+            isl_a.push_back(v0 + I.ub);
+            isl_b.push_back(v0 + I.end);
+        }
+        uint64_t copied = 0;
+        for (size_t b0 = 0; b0 < list.size();) {
+            size_t b1 = b0;
+            uint64_t bytes = 0;
+            while (b1 < list.size() && bytes + list[b1].isize <= batch_bytes) bytes += list[b1++].isize;
+            if (b1 == b0) return decline();
+            double t0 = now_s();
+            if (used[half]) DR_TRY(hipEventSynchronize(g_staging.ev[half]));
+            t_wait += now_s() - t0;
+            t0 = now_s();
+            rc = f.inflate_list(list.data() + b0, b1 - b0, g_staging.buf[half], threads);
+            if (rc) return decline();
+            t_inflate += now_s() - t0;
+            if (bytes) DR_TRY(hipMemcpyAsync(d_view + copied, g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
+            DR_TRY(hipEventRecord(g_staging.ev[half], st));
+            used[half] = true;
+            half ^= 1;
+            copied += bytes;
+            b0 = b1;
+        }
+
+        // ---- segments: per island its chain start, its inner block borders, its end; what lies
+        // between two islands is a gap segment nobody walks ----------------------------------------------
+        const double t0 = now_s();
+        seg_start.clear(); seg_hard.clear(); isl_first_seg.clear();
+        for (size_t q = 0; q < isl_a.size(); ++q) {
+            const Island &I = isl[gr.first + q];
+            isl_first_seg.push_back(seg_start.size());
+            if (I.blocks.empty()) continue;
+            const uint64_t a0 = isl_a[q], lim = isl_b[q];
+            if (!seg_start.empty() && a0 < seg_start.back()) return decline();      // islands must not overlap
+            seg_start.push_back(a0); seg_hard.push_back(lim);
+            uint64_t a = isl_v0[q];
+            for (size_t k = 0; k + 1 < I.blocks.size(); ++k) {
+                a += I.blocks[k].isize;
+                if (a > a0 && a < lim) { seg_start.push_back(a); seg_hard.push_back(lim); }
+            }
+            const uint64_t next = q + 1 < isl_a.size() ? isl_a[q + 1] : view;
+            if (lim < next || q + 1 == isl_a.size()) { seg_start.push_back(lim); seg_hard.push_back(lim); }   // gap
+        }
+        isl_first_seg.push_back(seg_start.size());
+        seg_start.push_back(view);
+        seg_hard.push_back(view);
+        const int64_t n_seg = (int64_t)seg_start.size() - 1;
+        if ((size_t)n_seg > max_seg) return decline();
+        sum.assign((size_t)std::max<int64_t>(n_seg, 1), SegSummary{});
+        if (n_seg > 0) {
+            DR_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            DR_TRY(hipMemcpyAsync(d_seg_hard, seg_hard.data(), seg_hard.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_view, view, d_seg_start, n_seg,
+                               n_ref, d_ref_len, 1, d_seg_hard, d_off16, d_sum);
+            DR_TRY(hipGetLastError());
+            DR_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
+        }
+        DR_TRY(hipStreamSynchronize(st));
+
+        // ---- host: per island, the chain from its vouched start must run through every block's
+        // proposed first record and end exactly at the island's end ---------------------------------
+        seg_n.assign((size_t)std::max<int64_t>(n_seg, 1), 0);
+        seg_base.assign((size_t)std::max<int64_t>(n_seg, 1), 0);
+        seg_prev.assign((size_t)std::max<int64_t>(n_seg, 1), -1);
+        int64_t n_chunk = 0;
+        for (size_t ii = 0; ii + 1 < isl_first_seg.size(); ++ii) {
+            const size_t s0 = (size_t)isl_first_seg[ii], s1 = (size_t)isl_first_seg[ii + 1];
+            if (s0 == s1) continue;
+            uint64_t o = seg_start[s0];
+            const uint64_t lim = seg_hard[s0];
+            for (size_t s = s0; s < s1; ++s) {
+                const uint64_t a = seg_start[s], b = std::min(seg_start[s + 1], lim);
+                if (a >= lim) break;                        // the gap segment
+                if (a == b || o >= b) continue;
+                const SegSummary &g = sum[s];
+                if (g.first != o || g.flags) return decline();
+                if (g.n_placed) {
+                    if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return decline();
+                    seg_n[s] = g.n_placed;
+                    seg_base[s] = n_chunk;
+                    seg_prev[s] = last_rid;
+                    last_rid = g.last_rid; last_pos = g.last_pos;
+                    n_chunk += g.n_placed;
+                }
+                o = g.end;
+            }
+            if (o != lim) return decline();
+        }
+
+        if (n_chunk > 0) {
+            pieces.emplace_back(new Piece);
+            Piece &pc = *pieces.back();
+            DR_TRY(pc.alloc(n_chunk));
+            DR_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            DR_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            DR_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)n_seg), dim3(kExtractThreads), 0, st, d_view, d_seg_start, d_off16,
+                               d_seg_n, d_seg_base, d_seg_prev, pc.pos, pc.flag, pc.mapq, pc.tlen, pc.end, d_ref_first, n_reads);
+            DR_TRY(hipGetLastError());
+            n_reads += n_chunk;
+        }
+        DR_TRY(hipStreamSynchronize(st));
+        t_gpu += now_s() - t0;
+    }
+    T[1] = t_inflate;
+    T[2] = t_wait;
+
+    // ---- join the pieces, first read of every reference ----------------------------------------------
+    const double t_join = now_s();
+    ref_off.assign((size_t)n_ref + 1, n_reads);
+    if (n_reads == 0) {
+        rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return bail(rc);
+        *out = R;
+        T[4] = now_s() - t_begin;
+        return BSIG_OK;
+    }
+    Piece whole;
+    Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
+    if (pieces.size() > 1) {
+        DR_TRY(whole.alloc(n_reads));
+        int64_t at = 0;
+        for (auto &pp : pieces) {
+            Piece &pc = *pp;
+            DR_TRY(hipMemcpyAsync(whole.pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+            DR_TRY(hipMemcpyAsync(whole.end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+            DR_TRY(hipMemcpyAsync(whole.tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+            DR_TRY(hipMemcpyAsync(whole.flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st));
+            DR_TRY(hipMemcpyAsync(whole.mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st));
+            at += pc.n;
+        }
+    }
+    std::vector<long long> ref_first((size_t)n_ref + 1, -1);
+    DR_TRY(hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
+    DR_TRY(hipStreamSynchronize(st));
+#undef DR_TRY
+    if (pieces.size() > 1) pieces.clear();
+    ref_off[(size_t)n_ref] = n_reads;
+    for (int32_t r = n_ref - 1; r >= 0; --r)
+        ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
+    ref_off[0] = 0;
+    T[3] = t_gpu + (now_s() - t_join);
+    const double t_lay = now_s();
+    rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), cols->pos, cols->end, cols->flag, cols->mapq,
+                            cols->tlen);
+    if (rc) return bail(rc);
+    T[5] = now_s() - t_lay;
+    T[4] = now_s() - t_begin;
+    *out = R;
+    return BSIG_OK;
+}
+
 }  // namespace bsig
 
 extern "C" {
@@ -572,6 +906,29 @@ int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_read
         return fail(BSIG_ERR_FORMAT, "%s needs the CPU decode path (BAMSIGNALS_DEVICE_DECODE=require)", path);
     bsig_columns cols;
     rc = bsig_bam_decode(bam, -1, nullptr, nullptr, nullptr, threads, &cols);
+    if (rc) return rc;
+    for (int k = 0; k < 6; ++k) g_dev_decode_timing[k] = 0;
+    return bsig_reads_upload(ctx, &cols, reads);
+}
+
+int bsig_reads_from_bam_regions(bsig_ctx *ctx, bsig_bam *bam, int64_t n_regions, const int32_t *rid,
+                                const int64_t *beg, const int64_t *end, int32_t threads, bsig_reads **reads)
+{
+    if (!ctx || !bam || !reads) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_from_bam_regions");
+    if (n_regions < 0 || (n_regions > 0 && (!rid || !beg || !end))) return fail(BSIG_ERR_ARG, "region arrays missing");
+    *reads = nullptr;
+    const char *mode = getenv("BAMSIGNALS_DEVICE_DECODE");
+    int rc = bsig::kNeedsCpuPath;
+    if (!(mode && !strcmp(mode, "0"))) {
+        std::vector<bsig::Region> rg((size_t)n_regions);
+        for (int64_t i = 0; i < n_regions; ++i) rg[(size_t)i] = bsig::Region{rid[i], beg[i], end[i]};
+        rc = bsig::reads_from_regions_device(ctx, bsig_bam_path(bam), *bsig_bam_index(bam), rg, threads, reads);
+    }
+    if (rc != bsig::kNeedsCpuPath) return rc;
+    if (mode && !strcmp(mode, "require"))
+        return fail(BSIG_ERR_FORMAT, "%s needs the CPU decode path (BAMSIGNALS_DEVICE_DECODE=require)", bsig_bam_path(bam));
+    bsig_columns cols;
+    rc = bsig_bam_decode(bam, n_regions, rid, beg, end, threads, &cols);
     if (rc) return rc;
     for (int k = 0; k < 6; ++k) g_dev_decode_timing[k] = 0;
     return bsig_reads_upload(ctx, &cols, reads);

@@ -211,15 +211,12 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         T[5] = 1;
     } else {
         const double t_dec = now_s();
-        bsig_columns cols;
-        bool on_device = false;
         if (whole) {
             // the records are taken from the uncompressed stream on the first GPU itself
             // (devdecode.hip; falls back to the CPU decode inside the call where it must); further
             // GPUs get device-to-device copies of the resident layout
             rc = bsig_reads_from_bam(g_cache.slots[0].ctx, bam, 0, &reads[0]);
             if (rc) return rc;
-            on_device = true;
             owned[0] = 1;
             double t6[6];
             bsig_device_decode_timing(t6);
@@ -241,30 +238,28 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                     owned[k] = 0;
                 }
         } else {
+            // index-driven: only the blocks the BAI lists for the ranges (ref: one bam_itr_queryi per
+            // chunk of ranges, :252-267), parsed on the first GPU like the whole file; not cached
             std::vector<int64_t> beg((size_t)n), end((size_t)n);
             for (int64_t i = 0; i < n; ++i) {
                 beg[(size_t)i] = (int64_t)loc[(size_t)i] - ext;
                 end[(size_t)i] = (int64_t)loc[(size_t)i] + width[i] + ext;
             }
-            rc = bsig_bam_decode(bam, n, rid.data(), beg.data(), end.data(), 0, &cols);
-        }
-        if (rc) return rc;
-        if (!on_device) T[1] = now_s() - t_dec;
-        const double t_up = now_s();
-        for (size_t k = 0; k < nd && !on_device; ++k) {
-            DevSlot &d = g_cache.slots[k];
-            if (whole && !key.empty() && d.reads && d.key == key) { reads[k] = d.reads; continue; }
-            rc = bsig_reads_upload(d.ctx, &cols, &reads[k]);
-            if (rc) { release(); return rc; }
-            if (whole && !key.empty()) {
-                d.drop_reads();
-                d.reads = reads[k];
-                d.key = key;
-            } else {
+            rc = bsig_reads_from_bam_regions(g_cache.slots[0].ctx, bam, n, rid.data(), beg.data(), end.data(), 0, &reads[0]);
+            if (rc) return rc;
+            owned[0] = 1;
+            double t6[6];
+            bsig_device_decode_timing(t6);
+            T[2] = t6[5];
+            T[1] = now_s() - t_dec - T[2];
+            const double t_rep = now_s();
+            for (size_t k = 1; k < nd; ++k) {
+                rc = bsig_reads_clone(reads[0], g_cache.slots[k].ctx, &reads[k]);
+                if (rc) { release(); return rc; }
                 owned[k] = 1;
             }
+            T[2] += now_s() - t_rep;
         }
-        if (!on_device) T[2] = now_s() - t_up;
     }
 
     const double t_run = now_s();
@@ -355,6 +350,9 @@ int bsig_bam_open(const char *path, bsig_bam **out)
 void bsig_bam_close(bsig_bam *b) { delete b; }
 
 const char *bsig_bam_path(const bsig_bam *b) { return b ? b->path.c_str() : nullptr; }
+}  // extern "C"
+const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b) { return &b->idx; }
+extern "C" {
 
 int32_t bsig_bam_n_ref(const bsig_bam *b) { return b ? (int32_t)b->hdr.names.size() : 0; }
 

@@ -134,6 +134,27 @@ class Reads:
         self.n_reads = self.info()["n_reads"]
         return self
 
+    @classmethod
+    def from_bam_regions(cls, ctx, bam, rid, beg, end, threads=0):
+        """The records the BAI lists for the regions [beg, end) (0-based) decoded to HBM -- a superset
+        of the overlapping records, each once, in file order (what ``BamFile.decode(rid, beg, end)``
+        returns on the host)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.ctx = ctx
+        rid = np.ascontiguousarray(rid, dtype=np.int32)
+        beg = np.ascontiguousarray(beg, dtype=np.int64)
+        end = np.ascontiguousarray(end, dtype=np.int64)
+        if not (len(rid) == len(beg) == len(end)):
+            raise ValueError("region arrays differ in length")
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_reads_from_bam_regions(ctx._h, bam._h, len(rid), _ptr(rid), _ptr(beg), _ptr(end),
+                                                         int(threads), C.byref(h)))
+        self._h = h
+        self.n_ref = len(bam.ref_len)
+        self.n_reads = self.info()["n_reads"]
+        return self
+
     def clone(self, ctx):
         """A copy of these resident reads on ``ctx``'s GPU (device-to-device)."""
         other = type(self).__new__(type(self))

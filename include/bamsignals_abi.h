@@ -211,6 +211,12 @@ void bsig_bam_decode_timing(double *t6);
  * path's error messages.  env BAMSIGNALS_DEVICE_DECODE=0 forces the CPU decode, =require fails
  * instead of falling back (testing).                                                           */
 int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_reads **reads);
+/* The same for an index-driven query: the records the BAI lists for the regions [beg, end) (what
+ * one bam_itr_queryi per chunk of ranges returns, ref: src/bamsignals.cpp:252-271): a superset of
+ * the overlapping records, each at most once, in file order.  Falls back like bsig_reads_from_bam. */
+int bsig_reads_from_bam_regions(bsig_ctx *ctx, bsig_bam *bam, int64_t n_regions, const int32_t *rid,
+                                const int64_t *beg, const int64_t *end, int32_t threads,
+                                bsig_reads **reads);
 /* stage seconds of the calling thread's last device-side decode: block scan, CPU inflate, waiting
  * for the copies, record walk + extraction kernels, total, HBM layout (all 0 after a CPU decode) */
 void bsig_device_decode_timing(double *t6);

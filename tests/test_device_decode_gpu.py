@@ -352,3 +352,72 @@ def test_header_only_bam(ctx, tmp_path, monkeypatch):
     p = Plan(ctx, dev, [0, 1], [10, 0], [100, 2000], [1, -1], make_params(_lib.MODE_COVERAGE))
     assert not p.run_host().any()
     dev.close()
+
+
+def _regions_both_ways(ctx, bam, rg, monkeypatch, expect_device=True):
+    """index-driven decode of the regions `rg` on the device and on the CPU: same resident reads"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, Reads, make_params
+    beg = rg["loc"].astype(np.int64)
+    end = beg + rg["len"]
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require" if expect_device else "1")
+    dev = Reads.from_bam_regions(ctx, bam, rg["rid"], beg, end)
+    assert (Reads.device_decode_timing()["total"] > 0) == expect_device
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
+    cpu = Reads.from_bam_regions(ctx, bam, rg["rid"], beg, end)
+    assert dev.info() == cpu.info()
+    host = bam.decode(rg["rid"], beg, end)
+    assert dev.n_reads == len(host["pos"])
+    out = []
+    for mode, a in ((_lib.MODE_PROFILE, dict(binsize=1, ss=True, shift=9)), (_lib.MODE_COVERAGE, dict()),
+                    (_lib.MODE_COUNT, dict(binsize=-1))):
+        res = []
+        for r in (dev, cpu):
+            p = Plan(ctx, r, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(mode, **a))
+            res.append(p.run_host().copy())
+            p.close()
+        assert np.array_equal(res[0], res[1])
+        out.append(res[0])
+    cpu.close()
+    return dev, out
+
+
+def test_index_driven_regions(ctx, tmp_path, monkeypatch, fixture_regions):
+    """the BAI's chunks as independent islands: fixture BAM (one leaf bin per reference), a
+    multi-bin synthetic BAM, regions that list nothing, one region, many overlapping regions; also in
+    several passes through HBM"""
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from oracle import oracle_c
+    _, rg = fixture_regions
+    dev, _ = _regions_both_ways(ctx, BamFile(BAM), rg, monkeypatch)
+    dev.close()
+
+    cols = synth_reads(400_000, [3_000_000, 200_000, 1_500_000], seed=31, paired=True)
+    path = str(tmp_path / "syn.bam")
+    write_columns_as_bam(path, ["a", "b", "c"], cols)
+    bam = BamFile(path)
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    for n, width, seed in ((1, 500, 1), (40, 3000, 2), (600, 1500, 3)):
+        rg = synth_ranges(n, width, cols["ref_len"], seed=seed, jitter=width // 2)
+        for chunk_mb in ("", "1"):
+            if chunk_mb:
+                monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", chunk_mb)
+            dev, out = _regions_both_ways(ctx, bam, rg, monkeypatch)
+            # the decoded subset answers the query like the whole file does
+            want, _ = oracle_c.pileup_core(orc, rg, binsize=1, ss=True, shift=9)
+            assert np.array_equal(out[0], want)
+            want, _ = oracle_c.coverage_core(orc, rg)
+            assert np.array_equal(out[1], want)
+            dev.close()
+            monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", raising=False)
+    # a region on a reference without reads nearby, and no regions at all
+    empty = dict(rid=np.asarray([1], np.int32), loc=np.asarray([199_990], np.int32), len=np.asarray([5], np.int32),
+                 strand=np.asarray([1], np.int32))
+    dev, _ = _regions_both_ways(ctx, bam, empty, monkeypatch)
+    dev.close()
+    none = dict(rid=np.zeros(0, np.int32), loc=np.zeros(0, np.int32), len=np.zeros(0, np.int32), strand=np.zeros(0, np.int32))
+    dev, _ = _regions_both_ways(ctx, bam, none, monkeypatch)
+    assert dev.n_reads == 0
+    dev.close()
