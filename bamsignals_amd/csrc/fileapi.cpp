@@ -194,9 +194,9 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     for (int32_t l : bam->hdr.lens) genome += l;
     for (int64_t i = 0; i < n; ++i) wanted += (int64_t)width[i] + 2 * ext + 16384;
     const char *force = getenv("BAMSIGNALS_DECODE");   // "all" | "regions" (testing / tuning)
-    // (region decode runs at ~0.6 s per decoded genome fraction of a 300-MB BAM, the whole-file
-    // device decode at 0.07 s flat: the break-even is near one eighth of the genome)
-    bool whole = wanted * 8 > genome;
+    // (5e7-read BAM: the whole-file decode costs 0.06-0.08 s flat and leaves the BAM resident for the
+    // next call; the index-driven decode 0.02 s for 7 % of the genome, 0.09 s for 74 %)
+    bool whole = wanted * 3 > genome;
     if (force && !strcmp(force, "all")) whole = true;
     if (force && !strcmp(force, "regions")) whole = false;
 
