@@ -421,3 +421,66 @@ def test_index_driven_regions(ctx, tmp_path, monkeypatch, fixture_regions):
     dev, _ = _regions_both_ways(ctx, bam, none, monkeypatch)
     assert dev.n_reads == 0
     dev.close()
+
+
+def test_fuzz_streams(ctx, tmp_path, monkeypatch):
+    """seeded random BAM streams (spec-derived records: random names, CIGARs, sequence lengths, tags,
+    references without reads, unplaced tail) cut into BGZF blocks at random sizes and chunked at
+    random sizes: device decode == CPU decode, whole file and index-free region lists alike"""
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    rng = np.random.default_rng(int(os.environ.get("BSIG_FUZZ_SEED", "99")))
+    ops_ref = [0, 2, 3, 7, 8]
+    for case in range(int(os.environ.get("BSIG_DECODE_FUZZ_CASES", "25"))):
+        n_ref = int(rng.integers(1, 5))
+        ref_len = rng.integers(500, 200_000, n_ref).astype(np.int64)
+        text = b"".join(b"@SQ\tSN:r%d\tLN:%d\n" % (i, ref_len[i]) for i in range(n_ref))
+        hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", n_ref)
+        for i in range(n_ref):
+            nm = b"r%d\x00" % i
+            hdr += struct.pack("<i", len(nm)) + nm + struct.pack("<i", int(ref_len[i]))
+        recs = []
+        n_placed = 0
+        for r in range(n_ref):
+            if rng.random() < 0.2:
+                continue                                            # a reference without reads
+            m = int(rng.integers(1, 400))
+            pos = np.sort(rng.integers(0, ref_len[r], m))
+            for p in pos:
+                name = bytes(rng.integers(33, 127, int(rng.integers(1, 40))).astype(np.uint8)) + b"\x00"
+                ncig = int(rng.integers(0, 6))
+                cig = [(int(rng.integers(1, 300)) << 4) | int(rng.choice([0, 1, 2, 3, 4, 5, 7, 8])) for _ in range(ncig)]
+                lseq = int(rng.choice([0, 0, 5, 36, 151, 3000]))
+                flag = int(rng.choice([0, 16, 4, 99, 147, 1024 + 16]))
+                aux = b"" if rng.random() < 0.5 else b"NMC\x03" + b"XZZ" + bytes(rng.integers(65, 90, int(rng.integers(0, 50))).astype(np.uint8)) + b"\x00"
+                body = struct.pack("<iiBBHHHiiii", r, int(p), len(name), int(rng.integers(0, 61)), 4681, ncig, flag, lseq,
+                                   r if rng.random() < 0.5 else -1, int(rng.integers(-1, 1000)), int(rng.integers(-600, 600)))
+                body += name + struct.pack("<%dI" % ncig, *cig) + bytes(rng.integers(0, 256, (lseq + 1) // 2).astype(np.uint8))
+                body += bytes(rng.integers(0, 60, lseq).astype(np.uint8)) + aux
+                recs.append(struct.pack("<i", len(body)) + body)
+                n_placed += 1
+        for _ in range(int(rng.integers(0, 5))):                     # unplaced tail
+            name = b"u\x00"
+            body = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, 0, -1, -1, 0) + name
+            recs.append(struct.pack("<i", len(body)) + body)
+        stream = hdr + b"".join(recs)
+        sizes = [int(x) for x in rng.integers(40, 65536, 7)] if rng.random() < 0.7 else [65536]
+        path = str(tmp_path / ("f%d.bam" % case))
+        with open(path, "wb") as fh:
+            fh.write(_bgzf(stream, sizes))
+        _empty_bai(path + ".bai", n_ref)
+        if rng.random() < 0.5:
+            monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", "1")
+            monkeypatch.setenv("BAMSIGNALS_BATCH_BLOCKS", str(int(rng.integers(1, 9))))
+        bam = BamFile(path)
+        monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+        dev = Reads.from_bam(ctx, bam)
+        monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
+        cpu = Reads.from_bam(ctx, bam)
+        assert dev.n_reads == n_placed and dev.info() == cpu.info(), case
+        for a, b in zip(_results(ctx, dev, bam.ref_len.astype(np.int64), seed=case), _results(ctx, cpu, bam.ref_len.astype(np.int64), seed=case)):
+            assert np.array_equal(a, b), case
+        dev.close(); cpu.close(); bam.close()
+        monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", raising=False)
+        monkeypatch.delenv("BAMSIGNALS_BATCH_BLOCKS", raising=False)
+        os.remove(path); os.remove(path + ".bai")
