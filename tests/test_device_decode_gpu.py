@@ -451,6 +451,9 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
                 ncig = int(rng.integers(0, 6))
                 cig = [(int(rng.integers(1, 300)) << 4) | int(rng.choice([0, 1, 2, 3, 4, 5, 7, 8])) for _ in range(ncig)]
                 lseq = int(rng.choice([0, 0, 5, 36, 151, 3000]))
+                if ncig == 2 and (cig[0] & 15) == 4 and (cig[0] >> 4) == lseq and (cig[1] & 15) == 3:
+                    cig[1] = (cig[1] & ~15) | 2      # "<l_seq>S<n>N" is the CG-tag placeholder: the device path
+                                                     # declines it unseen (covered by its own test), keep it out here
                 flag = int(rng.choice([0, 16, 4, 99, 147, 1024 + 16]))
                 aux = b"" if rng.random() < 0.5 else b"NMC\x03" + b"XZZ" + bytes(rng.integers(65, 90, int(rng.integers(0, 50))).astype(np.uint8)) + b"\x00"
                 body = struct.pack("<iiBBHHHiiii", r, int(p), len(name), int(rng.integers(0, 61)), 4681, ncig, flag, lseq,
