@@ -16,4 +16,7 @@ ARGS="--steps 64 --warmup 16 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $R/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1
+# the device-side decode kernels (whole file + index-driven) on the same 5e7-read BAM
+rm -rf $OUT/${TAG}_decode_trace
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_decode_trace -- python3 $R/scripts/decode_device_time.py > $OUT/${TAG}_decode_trace.log 2>&1
 ls $OUT | grep $TAG

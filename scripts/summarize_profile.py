@@ -77,4 +77,16 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
         f.write(f"| {k} | {v['hbm_read_bytes']:.3e} | {v['hbm_write_bytes']:.3e} |\n")
     f.write(f"\nstep HBM traffic = {out['step_hbm_bytes']:.4e} B vs algorithmic {out['algorithmic_bytes']:.4e} B "
             f"(ratio {out['step_hbm_bytes'] / out['algorithmic_bytes']:.3f})\n")
+# optional: the decode kernels' trace (scripts/decode_device_time.py under rocprofv3)
+dec = glob.glob(os.path.join(G, f"{tag}_decode_trace/*/*_kernel_stats.csv"))
+if dec:
+    dec = max(dec, key=os.path.getmtime)
+    shutil.copyfile(dec, os.path.join(P, f"{tag}_decode_kernel_stats.csv"))
+    with open(os.path.join(P, f"{tag}_summary.md"), "a") as f:
+        f.write("\n## Device-side decode (`rocprofv3 --kernel-trace --stats -- python3 scripts/decode_device_time.py`: "
+                "5e7-read BAM, 3 whole-file decodes + index-driven decodes of 100 / 1,000 / 10,000 regions)\n\n")
+        f.write("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
+        for r in csv.DictReader(open(dec)):
+            if any(s in r["Name"] for s in ("k_bam_walk", "k_bam_extract", "k_scatter", "k_span_hist", "k_build_idx")):
+                f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
 print(open(os.path.join(P, f"{tag}_summary.md")).read())
