@@ -20,7 +20,7 @@
 // order).  Such a start is only a proposal.  The host accepts the parse only if the chain of
 // records from the header arrives EXACTLY at every block's proposed start -- then the lanes'
 // walks, laid end to end, are the serial walk of the stream and the proposal is proven.
-// Anything else (a wrong proposal, CG-tag CIGARs, unsorted or damaged files) returns kNeedsCpuPath
+// Anything else (a wrong proposal, unsorted or damaged files) returns kNeedsCpuPath
 // and the caller takes the CPU decode (bamio.cpp), which also owns every error message.
 // Results are identical by construction and by tests/test_device_decode_gpu.py.
 #include <hip/hip_runtime.h>
@@ -46,7 +46,6 @@ namespace {
 constexpr int kMaxRecPerSeg = 1824;          // a record is >= 36 bytes, a block <= 65536
 constexpr uint32_t kFlagBad = 1u;            // malformed / truncated / too many records
 constexpr uint32_t kFlagUnsorted = 2u;
-constexpr uint32_t kFlagCg = 4u;             // CG-tag placeholder CIGAR (SAM spec 4.2.2)
 constexpr uint32_t kFlagIncomplete = 8u;     // the record at `end` runs past this chunk of the stream
 
 struct SegSummary {
@@ -158,11 +157,6 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ str
         const uint32_t l_name = ld32(stream + o + 12) & 0xFFu;
         const uint32_t n_cig = ld32(stream + o + 16) & 0xFFFFu;
         if (36 + (uint64_t)l_name + 4 * (uint64_t)n_cig > 4 + (uint64_t)bs) { flags |= kFlagBad; break; }
-        if (n_cig == 2 && 36 + (uint64_t)l_name + 8 <= 4 + (uint64_t)bs) {
-            const uint32_t c0 = ld32(stream + o + 36 + l_name), c1 = ld32(stream + o + 40 + l_name);
-            const int32_t l_seq = (int32_t)ld32(stream + o + 20);
-            if ((c0 & 0xFu) == 4u && (int32_t)(c0 >> 4) == l_seq && (c1 & 0xFu) == 3u) flags |= kFlagCg;
-        }
         if (np == 0) { frid = rid; fpos = pos; }
         else if (rid < prid || (rid == prid && pos < ppos)) flags |= kFlagUnsorted;
         if (np >= (uint32_t)kMaxRecPerSeg) { flags |= kFlagBad; break; }
@@ -176,6 +170,33 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ str
     r.first_rid = frid; r.first_pos = fpos; r.last_rid = prid; r.last_pos = ppos;
     r.flags = flags; r.pad = 0;
     sum[s] = r;
+}
+
+// offset (from the record start) of the CG:B,I tag's operations and their number, or 0: a walk over
+// the record's optional fields behind the 2-operation placeholder CIGAR
+__device__ uint32_t find_cg_tag(const uint8_t *__restrict__ r, uint32_t rec_len, uint32_t l_name, uint32_t l_seq,
+                                uint32_t *n_ops)
+{
+    uint64_t a = 36ull + l_name + 8ull + ((uint64_t)l_seq + 1) / 2 + l_seq;
+    while (a + 3 <= rec_len) {
+        const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+        a += 3;
+        uint64_t sz = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+        else if (ty == 's' || ty == 'S') sz = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+        else if (ty == 'Z' || ty == 'H') { while (a + sz < rec_len && r[a + sz]) ++sz; ++sz; }
+        else if (ty == 'B') {
+            if (a + 5 > rec_len) return 0;
+            const uint8_t sub = r[a];
+            const uint32_t cnt = ld32(r + a + 1);
+            const uint64_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= rec_len) { *n_ops = cnt; return (uint32_t)(a + 5); }
+            sz = 5 + es * cnt;
+        } else return 0;
+        a += sz;
+    }
+    return 0;
 }
 
 constexpr int kExtractThreads = 256;
@@ -203,7 +224,19 @@ __global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
         int64_t rlen = 0;
         if (!(fl & 0x4u)) {
             const uint8_t *c = r + 36 + l_name;
-            for (uint32_t q = 0; q < n_cig; ++q) {
+            uint32_t n_ops = n_cig;
+            if (n_cig == 2) {
+                // "<l_seq>S<n>N" is the placeholder of an alignment with more than 65,535 operations:
+                // the real CIGAR is the CG:B,I tag (SAM spec 4.2.2)
+                const uint32_t c0 = ld32(c), c1 = ld32(c + 4);
+                const int32_t l_seq = (int32_t)ld32(r + 20);
+                if ((c0 & 0xFu) == 4u && (int32_t)(c0 >> 4) == l_seq && (c1 & 0xFu) == 3u) {
+                    uint32_t cnt = 0;
+                    const uint32_t at = find_cg_tag(r, 4u + ld32(r), l_name, (uint32_t)l_seq, &cnt);
+                    if (at) { c = r + at; n_ops = cnt; }
+                }
+            }
+            for (uint32_t q = 0; q < n_ops; ++q) {
                 const uint32_t op = ld32(c + 4 * q);
                 if ((0x18Du >> (op & 0xFu)) & 1u) rlen += op >> 4;
             }
@@ -472,7 +505,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             if (a == b || o >= b) continue;         // empty block, or the current record runs through all of it
             const SegSummary &g = sum[(size_t)s];
             if (g.first != o) return decline();     // a <= o < b: the lane must have chosen exactly this start
-            if (g.flags & ~kFlagIncomplete) return decline();          // damaged, unsorted or CG-tag CIGARs
+            if (g.flags & ~kFlagIncomplete) return decline();          // damaged or unsorted
             if (g.n_placed) {
                 if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return decline();
                 seg_n[(size_t)s] = g.n_placed;

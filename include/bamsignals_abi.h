@@ -206,10 +206,11 @@ void bsig_bam_decode_timing(double *t6);
  * into page-locked buffers that travel to HBM while the next batch inflates; record boundaries
  * (the block_size links bam_itr_next follows, ref: src/bamsignals.cpp:271), the core fields and
  * bam_endpos are then taken from the uncompressed stream by GPU kernels (csrc/devdecode.hip).
- * Files whose records cross BGZF block borders, CG-tag CIGARs and damaged or unsorted files take
- * the CPU decode (bsig_bam_decode + bsig_reads_upload) inside this call: same result, and the CPU
- * path's error messages.  env BAMSIGNALS_DEVICE_DECODE=0 forces the CPU decode, =require fails
- * instead of falling back (testing).                                                           */
+ * Records that cross BGZF block borders (htsjdk) and CG-tag CIGARs are handled there; damaged or
+ * unsorted files, and any parse the host check could not prove, take the CPU decode
+ * (bsig_bam_decode + bsig_reads_upload) inside this call: same result, and the CPU path's error
+ * messages.  env BAMSIGNALS_DEVICE_DECODE=0 forces the CPU decode, =require fails instead of
+ * falling back (testing).                                                                      */
 int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_reads **reads);
 /* The same for an index-driven query: the records the BAI lists for the regions [beg, end) (what
  * one bam_itr_queryi per chunk of ranges returns, ref: src/bamsignals.cpp:252-271): a superset of
