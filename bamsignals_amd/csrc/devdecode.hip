@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "bamio.h"
+#include "inflate_lane.h"
 #include "runtime_internal.h"
 
 using bsig::fail;
@@ -253,6 +254,55 @@ __global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
     }
 }
 
+// ---- DEFLATE on the GPU: every lane inflates its own BGZF block (inflate_lane.h) ----------------
+struct InflateJob {
+    uint64_t in_off;     // the block's deflate data in the device copy of the compressed bytes
+    uint64_t out_off;    // where its bytes go in the view
+    uint32_t in_len, isize;
+};
+// LaneTables padded to an odd number of dwords: the same field of neighbouring lanes then sits in
+// different LDS banks
+struct alignas(4) LaneSlot {
+    bsig_inflate::LaneTables t;
+    uint32_t pad[(sizeof(bsig_inflate::LaneTables) / 4) % 2 ? 2 : 1];
+};
+static_assert(sizeof(LaneSlot) % 8 == 4, "LaneSlot must be an odd number of dwords");
+
+// LANES blocks per wave: a file of 40,000 blocks is only 625 full waves for 1,024 SIMDs, and what
+// a lane does is a chain of dependent steps (bits -> table -> bits ...): fewer blocks per wave put
+// more waves on the chip, which hides that latency and wastes less on lanes that wait for the
+// longest code or match of their wave.
+template <int LANES>
+__global__ __launch_bounds__(LANES) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
+                                                   int64_t n, uint8_t *__restrict__ out, uint8_t *__restrict__ lens,
+                                                   int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    LaneSlot *slots = reinterpret_cast<LaneSlot *>(lds_raw);
+    const int64_t i = (int64_t)blockIdx.x * LANES + threadIdx.x;
+    if (i >= n) return;
+    const InflateJob j = jobs[i];
+    const int rc = bsig_inflate::inflate_block(comp + j.in_off, j.in_len, out + j.out_off, j.isize, slots[threadIdx.x].t,
+                                               lens + i * bsig_inflate::kLensBytes);
+    if (rc) atomicMax(status, rc);
+}
+
+hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n, uint8_t *out, uint8_t *lens, int *status,
+                          hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int lanes = n >= 400000 ? 64 : n >= 160000 ? 32 : n >= 60000 ? 16 : 8;
+    if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
+    switch (lanes) {
+    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
+    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3((unsigned)((n + 31) / 32)), dim3(32), 32 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
+    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3((unsigned)((n + 15) / 16)), dim3(16), 16 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
+    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(4), 4 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
+    default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(8), 8 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
+    }
+    return hipGetLastError();
+}
+
 inline double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -291,6 +341,8 @@ namespace bsig {
 
 // > 0: the file (or this build's limits) needs the CPU decode path; nothing was allocated
 constexpr int kNeedsCpuPath = 1;
+// BGZF inflate on the GPU (k_inflate) unless BAMSIGNALS_INFLATE=cpu
+constexpr bool kGpuInflateDefault = false;
 
 namespace {
 
@@ -373,6 +425,31 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     if (n_ref) HIP_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
 
+    // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
+    const char *eng = getenv("BAMSIGNALS_INFLATE");
+    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : kGpuInflateDefault;
+    uint8_t *d_comp = nullptr, *d_lens = nullptr;
+    InflateJob *d_jobs = nullptr;
+    int *d_status = nullptr;
+    std::vector<InflateJob> jobs;
+    if (gpu_inflate) {
+        uint64_t max_comp = 0;
+        size_t max_blk = 0;
+        for (size_t b = 0; b < nb;) {
+            size_t e = b;
+            uint64_t bytes = 0;
+            while (e < nb && (e == b || bytes + blocks[e].isize <= chunk_cap)) bytes += blocks[e++].isize;
+            max_comp = std::max<uint64_t>(max_comp, blocks[e - 1].coff + blocks[e - 1].csize - blocks[b].coff);
+            max_blk = std::max(max_blk, e - b);
+            b = e;
+        }
+        HIP_TRY(tmp.alloc(&d_comp, (size_t)max_comp + 64));
+        HIP_TRY(tmp.alloc(&d_lens, max_blk * (size_t)bsig_inflate::kLensBytes));
+        HIP_TRY(tmp.alloc(&d_jobs, max_blk));
+        HIP_TRY(tmp.alloc(&d_status, 4));
+        HIP_TRY(hipMemsetAsync(d_status, 0, 4 * sizeof(int), st));
+    }
+
     std::lock_guard<std::mutex> lock(g_staging.mu);
     rc = g_staging.ensure(batch_bytes);
     if (rc) return rc;
@@ -433,9 +510,61 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         while (B1 < nb && (B1 == B0 || chunk_bytes + blocks[B1].isize <= chunk_cap)) chunk_bytes += blocks[B1++].isize;
         const bool is_last = B1 == nb;
 
-        // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
         int64_t header_end = -1;
         std::vector<uint8_t> head;             // the head of the stream, only if the header spans batches
+        if (gpu_inflate) {
+            // ---- the compressed bytes travel to HBM as they are; k_inflate turns them into the view ----
+            if (first_chunk) {
+                // the header is read on the host: inflate leading blocks until it is complete
+                for (size_t k = B0; k < B1 && header_end == -1 && head.size() < (64u << 20); ++k) {
+                    const size_t at = head.size();
+                    head.resize(at + blocks[k].isize);
+                    if (f.inflate(k, k + 1, head.data() + at, 1)) return decline();
+                    header_end = bam_header_bytes(head.data(), head.size());
+                }
+                if (header_end < 0) return decline();
+                std::vector<uint8_t>().swap(head);
+            }
+            const uint64_t file0 = blocks[B0].coff;
+            for (size_t b0 = B0; b0 < B1;) {
+                size_t b1 = b0;
+                uint64_t bytes = 0;
+                while (b1 < B1 && bytes + blocks[b1].csize <= batch_bytes) bytes += blocks[b1++].csize;
+                if (b1 == b0) return decline();
+                double t0 = now_s();
+                if (used[half]) DD_TRY(hipEventSynchronize(g_staging.ev[half]));
+                t_wait += now_s() - t0;
+                t0 = now_s();
+                {
+                    const uint8_t *src = f.data() + blocks[b0].coff;
+                    uint8_t *dst = g_staging.buf[half];
+                    const uint64_t slice = 1u << 20;
+                    pool_for((int64_t)((bytes + slice - 1) / slice), threads, [&](int64_t q) {
+                        const uint64_t a = (uint64_t)q * slice;
+                        memcpy(dst + a, src + a, (size_t)std::min(slice, bytes - a));
+                    });
+                }
+                t_inflate += now_s() - t0;
+                DD_TRY(hipMemcpyAsync(d_comp + (blocks[b0].coff - file0), g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
+                DD_TRY(hipEventRecord(g_staging.ev[half], st));
+                used[half] = true;
+                half ^= 1;
+                b0 = b1;
+            }
+            jobs.resize(B1 - B0);
+            for (size_t k = B0; k < B1; ++k)
+                jobs[k - B0] = InflateJob{blocks[k].coff + blocks[k].doff - file0, uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize};
+            const double t0 = now_s();
+            DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
+            DD_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, st));
+            int status = 0;
+            DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+            DD_TRY(hipStreamSynchronize(st));
+            t_inflate += now_s() - t0;
+            if (getenv("BSIG_DIAG_INFLATE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d)\n", (now_s() - t0) * 1e3, jobs.size(), status);
+            if (status) return decline();      // a damaged block: the CPU path reports it
+        } else {
+        // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
         for (size_t b0 = B0; b0 < B1;) {
             size_t b1 = b0;
             uint64_t bytes = 0;
@@ -464,6 +593,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             used[half] = true;
             half ^= 1;
             b0 = b1;
+        }
         }
         if (first_chunk && header_end < 0) return decline();      // header larger than a chunk
 

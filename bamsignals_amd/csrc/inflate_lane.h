@@ -1,0 +1,399 @@
+// Raw DEFLATE (RFC 1951) decoder for ONE work-item: every active lane of a wave inflates its own
+// BGZF block (a BAM holds tens of thousands of independent blocks of <= 64 KiB: that, not the bits
+// inside a block, is where the parallelism is).  Written for lanes that march together:
+//
+//   * Huffman decoding: a 9-bit (literal/length) and a 6-bit (distance) first-level table answer
+//     nearly every symbol with one 16-bit lookup; longer codes fall back to the canonical walk over
+//     the code lengths (per length the NUMBER of codes, packed two per register, and the symbols
+//     sorted by (length, value): an unrolled compare chain, then one lookup).  1.8 KB per lane
+//     (LDS on the device), where zlib-style two-level tables need 5.7 KB;
+//   * one symbol OR a slice of a pending match per turn of the main loop: a lane that copies a
+//     258-byte match does not hold the other lanes of its wave for 258 turns;
+//   * the LZ77 window is the output itself (global memory): matches read back what the lane wrote.
+//
+// The same source compiles for the host (tests/test_inflate_lane.py runs it against zlib) and for
+// gfx950 (devdecode.hip: k_inflate).
+#ifndef BSIG_INFLATE_LANE_H
+#define BSIG_INFLATE_LANE_H
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define BSIG_HD __host__ __device__ __forceinline__
+#else
+#define BSIG_HD inline
+#endif
+
+namespace bsig_inflate {
+
+constexpr int kLFast = 8, kDFast = 0;   // first-level table bits (0: none, every symbol by the walk)
+constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
+
+// per-lane working storage (LDS on the device)
+struct LaneTables {
+    uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
+    uint16_t dfast[kDFast ? (1 << kDFast) : 2];   // distance, likewise
+    uint16_t lsym[288];            // literal/length symbols sorted by (code length, symbol)
+    uint16_t dsym[32];             // distance symbols sorted likewise (30 used)
+    uint16_t offs[16];             // scratch of the table construction
+    uint16_t next[16];             // scratch: next canonical code of every length
+};
+
+// number of codes of every length 1..15, two 16-bit counts per word (index len >> 1)
+struct Counts {
+    uint32_t w[8];
+};
+
+struct BitIn {
+    const uint8_t *p;      // next input byte that is not in buf yet
+    const uint8_t *end;    // end of this block's deflate data
+    uint64_t buf;          // bit buffer, next bit = bit 0
+    uint64_t ahead;        // the 8 bytes at p, loaded a turn before they are needed
+    int cnt;               // valid bits in buf
+};
+
+enum { OK = 0, ERR_INPUT = 1, ERR_CODE = 2, ERR_OUTPUT = 3, ERR_DIST = 4, ERR_STORED = 5, ERR_TABLE = 6 };
+
+BSIG_HD uint32_t load32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+BSIG_HD uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+BSIG_HD void store64(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }
+
+// the 8 input bytes at p; zeros behind the end of the input (a well-formed stream never consumes
+// them, a damaged one runs into ERR_INPUT)
+BSIG_HD uint64_t peek64(const uint8_t *p, const uint8_t *end)
+{
+    if (p + 8 <= end) return load64(p);
+    uint64_t v = 0;
+    for (int k = 0; k < 8; ++k)
+        if (p + k < end) v |= (uint64_t)p[k] << (8 * k);
+    return v;
+}
+
+// at least 56 valid bits afterwards.  The bytes come from `ahead`, which was loaded when the
+// previous refill finished: the load of the next 8 bytes is issued here and has a whole turn of
+// the main loop to arrive.
+BSIG_HD void refill(BitIn &in)
+{
+    const int nb = (64 - in.cnt) >> 3;           // whole bytes that fit
+    if (nb <= 0) return;
+    const uint64_t take_bits = nb >= 8 ? in.ahead : in.ahead & ((1ull << (8 * nb)) - 1);
+    in.buf |= take_bits << in.cnt;
+    in.cnt += 8 * nb;
+    in.p += nb;
+    in.ahead = peek64(in.p, in.end);
+}
+
+BSIG_HD uint32_t take(BitIn &in, int n)
+{
+    const uint32_t v = (uint32_t)(in.buf & ((1ull << n) - 1));
+    in.buf >>= n;
+    in.cnt -= n;
+    return v;
+}
+
+BSIG_HD int count_of(const Counts &c, int len) { return (int)((c.w[len >> 1] >> ((len & 1) * 16)) & 0xFFFFu); }
+
+// one symbol of a canonical code by the walk over the code lengths; needs 15 valid bits.  -1: no such code
+BSIG_HD int decode_walk(BitIn &in, const Counts &c, const uint16_t *sym)
+{
+    int code = 0, first = 0, index = 0;
+    uint64_t b = in.buf;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(b & 1);
+        b >>= 1;
+        const int count = count_of(c, len);
+        if (code - count < first) {
+            in.buf = b;
+            in.cnt -= len;
+            return sym[index + (code - first)];
+        }
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+template <int FAST>
+BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const uint16_t *sym)
+{
+    if (FAST == 0) return decode_walk(in, c, sym);
+    const uint32_t e = fast[in.buf & ((1u << FAST) - 1)];
+    if (e) {
+        const int len = (int)(e & 15u);
+        in.buf >>= len;
+        in.cnt -= len;
+        return (int)(e >> 4);
+    }
+    return decode_walk(in, c, sym);
+}
+
+BSIG_HD uint32_t bit_reverse(uint32_t v, int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - n);
+#else
+    uint32_t r = 0;
+    for (int k = 0; k < n; ++k) r |= ((v >> k) & 1u) << (n - 1 - k);
+    return r;
+#endif
+}
+
+// counts + sorted symbols + first-level table from n code lengths (0: symbol unused).  Returns
+// false for an over-subscribed set; incomplete sets are accepted (their unused codes decode to -1).
+template <int FAST, typename LenAt>
+BSIG_HD bool construct(Counts &c, uint16_t *fast, uint16_t *sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
+{
+    for (int k = 0; k < 16; ++k) offs[k] = 0;
+    for (int i = 0; i < n; ++i) offs[len_at(i)] = (uint16_t)(offs[len_at(i)] + 1);      // offs = counts for now
+    for (int k = 0; k < 8; ++k) c.w[k] = 0;
+    int left = 1;
+    uint32_t code = 0;
+    offs[0] = 0;
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= offs[len];
+        if (left < 0) return false;
+        c.w[len >> 1] |= (uint32_t)offs[len] << ((len & 1) * 16);
+        code = (code + offs[len - 1]) << 1;          // first canonical code of this length
+        next[len] = (uint16_t)code;
+    }
+    // offsets of every length in the sorted symbol array
+    int acc = 0;
+    for (int len = 1; len <= 15; ++len) {
+        const int cnt = offs[len];
+        offs[len] = (uint16_t)acc;
+        acc += cnt;
+    }
+    if (FAST == 0) fast = nullptr;
+    if (fast)
+        for (int k = 0; k < (1 << FAST); ++k) fast[k] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int l = len_at(i);
+        if (!l) continue;
+        sym[offs[l]++] = (uint16_t)i;
+        const uint32_t cd = next[l]++;
+        if (fast && l <= FAST) {
+            const uint16_t e = (uint16_t)((i << 4) | l);
+            for (uint32_t k = bit_reverse(cd, l); k < (1u << FAST); k += 1u << l) fast[k] = e;
+        }
+    }
+    return true;
+}
+
+// position k of the code-length code's lengths in the stream -> symbol (RFC 1951, 3.2.7:
+// 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15), 5 bits per entry
+BSIG_HD int cl_order(int k)
+{
+    const uint64_t lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                        10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    return (int)((k < 12 ? lo >> (5 * k) : hi >> (5 * (k - 12))) & 31);
+}
+
+constexpr int kLensBytes = 352;   // scratch of inflate_block: 32 for the code-length code + 316 lengths
+
+// true once more bits were consumed than the input holds
+BSIG_HD bool overrun(const BitIn &in) { return in.p - (in.cnt >> 3) > in.end; }
+
+BSIG_HD int len_base(int s)     // length symbols 257..285 -> s = 0..28
+{
+    return s < 8 ? 3 + s : s == 28 ? 258 : 3 + ((4 + (s & 3)) << ((s >> 2) - 1));
+}
+BSIG_HD int len_extra(int s) { return s < 8 || s == 28 ? 0 : (s >> 2) - 1; }
+BSIG_HD int dist_base(int s)    // distance symbols 0..29
+{
+    return s < 4 ? 1 + s : 1 + ((2 + (s & 1)) << ((s >> 1) - 1));
+}
+BSIG_HD int dist_extra(int s) { return s < 4 ? 0 : (s >> 1) - 1; }
+
+// Inflates one raw DEFLATE stream of in_len bytes into exactly out_len bytes (nothing behind
+// out + out_len is touched).  lens: kLensBytes of scratch (global memory on the device).
+// Returns OK or an ERR_ code.
+BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, uint32_t out_len, LaneTables &T,
+                          uint8_t *lens)
+{
+    BitIn in;
+    in.p = in_p; in.end = in_p + in_len; in.buf = 0; in.cnt = 0;
+    in.ahead = peek64(in.p, in.end);
+    uint32_t op = 0;
+    Counts lc, dc;
+    for (;;) {
+        refill(in);
+        const uint32_t last = take(in, 1);
+        const uint32_t type = take(in, 2);
+        if (type == 0) {
+            // stored: skip to the byte boundary, LEN / NLEN, raw bytes
+            take(in, in.cnt & 7);
+            refill(in);
+            const uint32_t len = take(in, 16), nlen = take(in, 16);
+            if ((len ^ 0xFFFFu) != nlen) return ERR_STORED;
+            // bytes still in the bit buffer belong to the raw data
+            const uint8_t *src = in.p - (in.cnt >> 3);
+            if (src + len > in.end) return ERR_INPUT;
+            if (op + len > out_len) return ERR_OUTPUT;
+            for (uint32_t k = 0; k < len; ++k) out[op + k] = src[k];
+            op += len;
+            in.p = src + len; in.buf = 0; in.cnt = 0;
+            in.ahead = peek64(in.p, in.end);
+        } else if (type == 3) {
+            return ERR_CODE;
+        } else {
+            if (type == 1) {
+                // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
+                auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
+                auto fd = [](int) { return 5; };
+                construct<kLFast>(lc, T.lfast, T.lsym, T.offs, T.next, 288, fl);
+                construct<kDFast>(dc, T.dfast, T.dsym, T.offs, T.next, 30, fd);
+            } else {
+                const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
+                if (nlen > 286 || ndist > 30) return ERR_TABLE;
+                // the code-length code: its 19 lengths in the order of RFC 1951, 3.2.7
+                for (int k = 0; k < 19; ++k) lens[k] = 0;
+                for (int k = 0; k < ncode; ++k) {
+                    refill(in);
+                    lens[cl_order(k)] = (uint8_t)take(in, 3);
+                }
+                Counts cc;
+                // the code-length symbols are sorted into dsym (free until the distance code is built)
+                if (!construct<kDFast>(cc, (uint16_t *)nullptr, T.dsym, T.offs, T.next, 19, [&](int i) { return (int)lens[i]; }))
+                    return ERR_TABLE;
+                // literal/length + distance code lengths, run-length coded
+                int idx = 0;
+                uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
+                while (idx < nlen + ndist) {
+                    refill(in);
+                    const int s = decode_walk(in, cc, T.dsym);
+                    if (s < 0) return ERR_CODE;
+                    if (s < 16) {
+                        ll[idx++] = (uint8_t)s;
+                    } else {
+                        int prev = 0, rep;
+                        if (s == 16) {
+                            if (idx == 0) return ERR_TABLE;
+                            prev = ll[idx - 1];
+                            rep = 3 + (int)take(in, 2);
+                        } else if (s == 17) {
+                            rep = 3 + (int)take(in, 3);
+                        } else {
+                            rep = 11 + (int)take(in, 7);
+                        }
+                        if (idx + rep > nlen + ndist) return ERR_TABLE;
+                        while (rep--) ll[idx++] = (uint8_t)prev;
+                    }
+                    if (overrun(in)) return ERR_INPUT;
+                }
+                if (ll[256] == 0) return ERR_TABLE;               // no end-of-block code
+                if (!construct<kLFast>(lc, T.lfast, T.lsym, T.offs, T.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
+                if (!construct<kDFast>(dc, T.dfast, T.dsym, T.offs, T.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
+                    return ERR_TABLE;
+            }
+            // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
+            // The bytes of a match are LOADED in the turn that meets it and STORED in the next one,
+            // behind that turn's symbol decode: the trip to memory runs beside the decode. ----
+            uint32_t pend = 0, pdist = 0;
+            uint32_t dn = 0, dpos = 0;          // deferred stores: dn bytes (in 8-byte moves) at out + dpos
+            uint64_t v[kTurn / 8];
+            for (uint32_t k = 0; k < kTurn / 8; ++k) v[k] = 0;
+            int err = OK;
+            for (;;) {
+                int lit = -1;
+                bool stop = false;
+                if (pend == 0) {
+                    refill(in);
+                    int s = decode<kLFast>(in, T.lfast, lc, T.lsym);
+                    if (s < 256) {
+                        if (s < 0) { err = ERR_CODE; stop = true; }
+                        else if (op >= out_len) { err = ERR_OUTPUT; stop = true; }
+                        else lit = s;
+                    } else if (s == 256) {
+                        stop = true;
+                    } else {
+                        s -= 257;
+                        if (s >= 29) { err = ERR_CODE; stop = true; }
+                        else {
+                            const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
+                            const int d = decode<kDFast>(in, T.dfast, dc, T.dsym);      // <= 20 + 28 of the 56 bits
+                            if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
+                            else {
+                                const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
+                                if (dist > op) { err = ERR_DIST; stop = true; }
+                                else if (op + len > out_len) { err = ERR_OUTPUT; stop = true; }
+                                else if (overrun(in)) { err = ERR_INPUT; stop = true; }
+                                else { pend = len; pdist = dist; }
+                            }
+                        }
+                    }
+                }
+                // the previous turn's match bytes
+                if (dn) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                    for (uint32_t k = 0; k < kTurn / 8; ++k)
+                        if (8 * k < dn) store64(out + dpos + 8 * k, v[k]);
+                    dn = 0;
+                }
+                if (stop) break;
+                if (lit >= 0) out[op++] = (uint8_t)lit;
+                if (pend) {
+                    // up to kTurn bytes of the match per turn, in 8-byte moves.  A move may write up to 7
+                    // bytes past the match (inside this block's own area: the next symbols overwrite
+                    // them); only the last bytes of a block are moved one by one.
+                    uint32_t n = pend < kTurn ? pend : kTurn;
+                    if (op + ((n + 7u) & ~7u) <= out_len) {
+                        if (pdist < 8) {
+                            // short period (runs, 2- and 3-byte patterns): the first 8 bytes come from a
+                            // pattern built in registers; behind them the same bytes repeat at a distance
+                            // that is a multiple of the period and >= 8, so the rest is ordinary moves
+                            const uint64_t w = load64(out + op - pdist);      // its low `pdist` bytes are valid
+                            uint64_t pat = 0;
+                            uint32_t j = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                            for (int i = 0; i < 8; ++i) {
+                                pat |= ((w >> (8 * j)) & 0xFFull) << (8 * i);
+                                j = j + 1 == pdist ? 0 : j + 1;
+                            }
+                            store64(out + op, pat);
+                            const uint32_t m = n < 8u ? n : 8u;
+                            op += m; pend -= m; n -= m;
+                            pdist *= (7u + pdist) / pdist;                    // smallest multiple of the period >= 8
+                        }
+                        const uint8_t *from = out + op - pdist;
+                        if (pdist >= ((n + 7u) & ~7u)) {
+                            // the source lies wholly behind the destination: all loads now, the stores in
+                            // the next turn
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                            for (uint32_t k = 0; k < kTurn / 8; ++k)
+                                if (8 * k < n) v[k] = load64(from + 8 * k);
+                            dn = n;
+                            dpos = op;
+                        } else {
+                            for (uint32_t k = 0; k < n; k += 8) store64(out + op + k, load64(from + k));
+                        }
+                    } else {
+                        const uint8_t *from = out + op - pdist;
+                        for (uint32_t k = 0; k < n; ++k) out[op + k] = from[k];      // byte by byte: overlaps repeat
+                    }
+                    op += n;
+                    pend -= n;
+                }
+            }
+            if (err) return err;
+        }
+        if (overrun(in)) return ERR_INPUT;
+        if (last) break;
+    }
+    return op == out_len ? OK : ERR_OUTPUT;
+}
+
+}  // namespace bsig_inflate
+#endif

@@ -27,13 +27,15 @@ def ctx():
     c.close()
 
 
-def _bgzf(data, sizes):
-    """BGZF-compress `data`, cutting it into blocks of the given sizes (cycled)."""
+def _bgzf(data, sizes, levels=((1, 0),)):
+    """BGZF-compress `data`, cutting it into blocks of the given sizes (cycled); `levels` = (zlib
+    level, strategy) pairs, cycled too (level 0: stored blocks; strategy 4: fixed Huffman codes)."""
     out, i, k = b"", 0, 0
     while i < len(data):
         n = sizes[k % len(sizes)]
         chunk = data[i:i + n]
-        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        lv, st = levels[k % len(levels)]
+        co = zlib.compressobj(lv, zlib.DEFLATED, -15, 8, st)
         dd = co.compress(chunk) + co.flush()
         out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(dd) + 25) + dd
                 + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
@@ -466,14 +468,16 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         stream = hdr + b"".join(recs)
         sizes = [int(x) for x in rng.integers(40, 65536, 7)] if rng.random() < 0.7 else [65536]
         path = str(tmp_path / ("f%d.bam" % case))
+        levels = [(int(rng.choice([0, 1, 6, 9])), int(rng.choice([0, 0, 2, 3, 4]))) for _ in range(3)]
         with open(path, "wb") as fh:
-            fh.write(_bgzf(stream, sizes))
+            fh.write(_bgzf(stream, [min(s, 60000) for s in sizes] if any(lv == 0 for lv, _ in levels) else sizes, levels))
         _empty_bai(path + ".bai", n_ref)
         if rng.random() < 0.5:
             monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", "1")
             monkeypatch.setenv("BAMSIGNALS_BATCH_BLOCKS", str(int(rng.integers(1, 9))))
         bam = BamFile(path)
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+        monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu" if case % 2 else "cpu")      # both inflate engines
         dev = Reads.from_bam(ctx, bam)
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
         cpu = Reads.from_bam(ctx, bam)
