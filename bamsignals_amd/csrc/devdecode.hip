@@ -291,7 +291,9 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
                           hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    int lanes = n >= 400000 ? 64 : n >= 160000 ? 32 : n >= 60000 ? 16 : 8;
+    // resident lanes per CU = min(160 KB / 1.2 KB of tables, 8 waves (182 VGPRs) x LANES): 16 lanes
+    // per wave already fill the LDS; fewer leave lanes unused (8: 34 ms instead of 19 for 32,718 blocks)
+    int lanes = n >= 500000 ? 64 : n >= 130000 ? 32 : 16;
     if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
     switch (lanes) {
     case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
@@ -335,14 +337,63 @@ Staging g_staging;
 
 thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
 
+// The deflate data of the listed blocks, packed back to back, to d_comp (through the page-locked
+// halves, several threads per half); in_off[k] = where block k's data begins in d_comp.
+// The caller holds g_staging.mu.  Returns a hipError_t as int (0 = ok).
+int copy_deflate_data(const bsig::BgzfFile &f, const bsig::BgzfBlock *list, size_t n, uint8_t *d_comp, hipStream_t st,
+                      int threads, size_t batch_bytes, int &half, bool (&used)[2], std::vector<uint64_t> &in_off,
+                      double &t_host, double &t_wait)
+{
+    in_off.resize(n);
+    uint64_t packed = 0;
+    std::vector<uint32_t> at;
+    for (size_t b0 = 0; b0 < n;) {
+        size_t b1 = b0;
+        uint64_t bytes = 0;
+        at.clear();
+        while (b1 < n && (b1 == b0 || bytes + list[b1].dlen <= batch_bytes)) {
+            at.push_back((uint32_t)bytes);
+            in_off[b1] = packed + bytes;
+            bytes += list[b1++].dlen;
+        }
+        if (bytes > g_staging.cap) return (int)hipErrorInvalidValue;
+        double t0 = now_s();
+        if (used[half]) {
+            const hipError_t e = hipEventSynchronize(g_staging.ev[half]);
+            if (e != hipSuccess) return (int)e;
+        }
+        t_wait += now_s() - t0;
+        t0 = now_s();
+        uint8_t *dst = g_staging.buf[half];
+        const uint8_t *file = f.data();
+        const size_t per = 64;                                  // blocks per task
+        bsig::pool_for((int64_t)((b1 - b0 + per - 1) / per), threads, [&](int64_t q) {
+            const size_t k1 = std::min(b1, b0 + (size_t)(q + 1) * per);
+            for (size_t k = b0 + (size_t)q * per; k < k1; ++k)
+                memcpy(dst + at[k - b0], file + list[k].coff + list[k].doff, list[k].dlen);
+        });
+        t_host += now_s() - t0;
+        hipError_t e = bytes ? hipMemcpyAsync(d_comp + packed, dst, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+        if (e == hipSuccess) e = hipEventRecord(g_staging.ev[half], st);
+        if (e != hipSuccess) return (int)e;
+        used[half] = true;
+        half ^= 1;
+        packed += bytes;
+        b0 = b1;
+    }
+    return 0;
+}
+
 }  // namespace
 
 namespace bsig {
 
 // > 0: the file (or this build's limits) needs the CPU decode path; nothing was allocated
 constexpr int kNeedsCpuPath = 1;
-// BGZF inflate on the GPU (k_inflate) unless BAMSIGNALS_INFLATE=cpu
-constexpr bool kGpuInflateDefault = false;
+// Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so: k_inflate takes
+// ~19 ms for anything up to one chip-load of blocks (33,000: every lane walks its ~6,500 symbols
+// one after the other), the CPU pool ~10 ms per 9,600 blocks -- the GPU from 16,384 blocks on
+constexpr size_t kGpuInflateMinBlocks = 16384;
 
 namespace {
 
@@ -427,11 +478,12 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
 
     // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
     const char *eng = getenv("BAMSIGNALS_INFLATE");
-    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : kGpuInflateDefault;
+    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : nb >= kGpuInflateMinBlocks;
     uint8_t *d_comp = nullptr, *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
     std::vector<InflateJob> jobs;
+    std::vector<uint64_t> in_off;
     if (gpu_inflate) {
         uint64_t max_comp = 0;
         size_t max_blk = 0;
@@ -525,35 +577,11 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
                 if (header_end < 0) return decline();
                 std::vector<uint8_t>().swap(head);
             }
-            const uint64_t file0 = blocks[B0].coff;
-            for (size_t b0 = B0; b0 < B1;) {
-                size_t b1 = b0;
-                uint64_t bytes = 0;
-                while (b1 < B1 && bytes + blocks[b1].csize <= batch_bytes) bytes += blocks[b1++].csize;
-                if (b1 == b0) return decline();
-                double t0 = now_s();
-                if (used[half]) DD_TRY(hipEventSynchronize(g_staging.ev[half]));
-                t_wait += now_s() - t0;
-                t0 = now_s();
-                {
-                    const uint8_t *src = f.data() + blocks[b0].coff;
-                    uint8_t *dst = g_staging.buf[half];
-                    const uint64_t slice = 1u << 20;
-                    pool_for((int64_t)((bytes + slice - 1) / slice), threads, [&](int64_t q) {
-                        const uint64_t a = (uint64_t)q * slice;
-                        memcpy(dst + a, src + a, (size_t)std::min(slice, bytes - a));
-                    });
-                }
-                t_inflate += now_s() - t0;
-                DD_TRY(hipMemcpyAsync(d_comp + (blocks[b0].coff - file0), g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
-                DD_TRY(hipEventRecord(g_staging.ev[half], st));
-                used[half] = true;
-                half ^= 1;
-                b0 = b1;
-            }
+            DD_TRY((hipError_t)copy_deflate_data(f, blocks.data() + B0, B1 - B0, d_comp, st, threads, batch_bytes, half, used, in_off,
+                                                 t_inflate, t_wait));
             jobs.resize(B1 - B0);
             for (size_t k = B0; k < B1; ++k)
-                jobs[k - B0] = InflateJob{blocks[k].coff + blocks[k].doff - file0, uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize};
+                jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize};
             const double t0 = now_s();
             DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
             DD_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, st));
@@ -865,6 +893,24 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     DR_TRY(tmp.alloc(&d_seg_prev, max_seg));
     if (n_ref) DR_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
     DR_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
+    const char *eng = getenv("BAMSIGNALS_INFLATE");
+    size_t n_island_blocks = 0;
+    for (const Island &I : isl) n_island_blocks += I.blocks.size();
+    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : n_island_blocks >= kGpuInflateMinBlocks;
+    uint8_t *d_comp = nullptr, *d_lens = nullptr;
+    InflateJob *d_jobs = nullptr;
+    int *d_status = nullptr;
+    std::vector<InflateJob> jobs;
+    std::vector<uint64_t> in_off;
+    if (gpu_inflate) {
+        // (a block never inflates to less than it holds compressed, give or take the few bytes of an
+        // empty block: the uncompressed bound of a group bounds its compressed bytes)
+        DR_TRY(tmp.alloc(&d_comp, (size_t)max_group + 64 * max_seg + 64));
+        DR_TRY(tmp.alloc(&d_lens, max_seg * (size_t)bsig_inflate::kLensBytes));
+        DR_TRY(tmp.alloc(&d_jobs, max_seg));
+        DR_TRY(tmp.alloc(&d_status, 4));
+        DR_TRY(hipMemsetAsync(d_status, 0, 4 * sizeof(int), st));
+    }
 
     std::lock_guard<std::mutex> lock(g_staging.mu);
     rc = g_staging.ensure(batch_bytes);
@@ -903,6 +949,27 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
             isl_a.push_back(v0 + I.ub);
             isl_b.push_back(v0 + I.end);
         }
+        if (gpu_inflate) {
+            uint64_t comp_bytes = 0;
+            for (const BgzfBlock &b : list) comp_bytes += b.dlen;
+            if (comp_bytes > max_group + 64 * (uint64_t)max_seg || list.size() > max_seg) return decline();
+            DR_TRY((hipError_t)copy_deflate_data(f, list.data(), list.size(), d_comp, st, threads, batch_bytes, half, used, in_off,
+                                                 t_inflate, t_wait));
+            jobs.resize(list.size());
+            uint64_t at = 0;
+            for (size_t k = 0; k < list.size(); ++k) {
+                jobs[k] = InflateJob{in_off[k], at, list[k].dlen, list[k].isize};
+                at += list[k].isize;
+            }
+            const double ti = now_s();
+            DR_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
+            DR_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_view, d_lens, d_status, st));
+            int status = 0;
+            DR_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+            DR_TRY(hipStreamSynchronize(st));
+            t_inflate += now_s() - ti;
+            if (status) return decline();
+        } else {
         uint64_t copied = 0;
         for (size_t b0 = 0; b0 < list.size();) {
             size_t b1 = b0;
@@ -924,6 +991,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
             b0 = b1;
         }
 
+        }
         // ---- segments: per island its chain start, its inner block borders, its end; what lies
         // between two islands is a gap segment nobody walks ----------------------------------------------
         const double t0 = now_s();
