@@ -337,6 +337,77 @@ Staging g_staging;
 
 thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
 
+// The decode's device scratch (the view of the uncompressed stream, the compressed bytes, record
+// offsets ...: 2.6 GB for config 2's BAM) is handed back to a per-process cache instead of hipFree:
+// allocating and freeing it cost 8-14 ms of a 50-ms decode.  Dropped by bsig_cache_clear(), and
+// trimmed (largest first) above BAMSIGNALS_SCRATCH_CACHE_GB (default 8).
+struct ScratchCache {
+    struct Blk { int dev; void *p; size_t bytes; };
+    std::mutex mu;
+    std::vector<Blk> free_;
+    size_t cached = 0;
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Blk &b : free_) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+        free_.clear();
+        cached = 0;
+    }
+};
+ScratchCache g_scratch;
+
+struct ScratchPool {
+    int device;
+    hipStream_t st;
+    std::vector<ScratchCache::Blk> mine;
+    ScratchPool(int dev, hipStream_t s) : device(dev), st(s) {}
+    template <typename T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
+        {
+            std::lock_guard<std::mutex> lk(g_scratch.mu);
+            size_t best = (size_t)-1;
+            for (size_t k = 0; k < g_scratch.free_.size(); ++k) {
+                const ScratchCache::Blk &b = g_scratch.free_[k];
+                if (b.dev != device || b.bytes < bytes || b.bytes > 2 * bytes + (1u << 20)) continue;
+                if (best == (size_t)-1 || b.bytes < g_scratch.free_[best].bytes) best = k;
+            }
+            if (best != (size_t)-1) {
+                mine.push_back(g_scratch.free_[best]);
+                g_scratch.cached -= g_scratch.free_[best].bytes;
+                g_scratch.free_.erase(g_scratch.free_.begin() + (long)best);
+                *p = (T *)mine.back().p;
+                return hipSuccess;
+            }
+        }
+        void *q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        mine.push_back(ScratchCache::Blk{device, q, bytes});
+        *p = (T *)q;
+        return hipSuccess;
+    }
+    ~ScratchPool()
+    {
+        (void)hipStreamSynchronize(st);          // nothing in flight may still use the blocks
+        size_t limit = (size_t)8 << 30;
+        if (const char *e = getenv("BAMSIGNALS_SCRATCH_CACHE_GB")) limit = (size_t)std::max(0ll, atoll(e)) << 30;
+        std::lock_guard<std::mutex> lk(g_scratch.mu);
+        for (const ScratchCache::Blk &b : mine) { g_scratch.free_.push_back(b); g_scratch.cached += b.bytes; }
+        while (g_scratch.cached > limit && !g_scratch.free_.empty()) {
+            size_t big = 0;
+            for (size_t k = 1; k < g_scratch.free_.size(); ++k)
+                if (g_scratch.free_[k].bytes > g_scratch.free_[big].bytes) big = k;
+            (void)hipSetDevice(g_scratch.free_[big].dev);
+            (void)hipFree(g_scratch.free_[big].p);
+            g_scratch.cached -= g_scratch.free_[big].bytes;
+            g_scratch.free_.erase(g_scratch.free_.begin() + (long)big);
+        }
+        (void)hipSetDevice(device);
+    }
+};
+
 // The deflate data of the listed blocks, packed back to back, to d_comp (through the page-locked
 // halves, several threads per half); in_off[k] = where block k's data begins in d_comp.
 // The caller holds g_staging.mu.  Returns a hipError_t as int (0 = ok).
@@ -397,14 +468,13 @@ constexpr size_t kGpuInflateMinBlocks = 16384;
 
 namespace {
 
-// the columns of one chunk of the stream
+// the columns of one chunk of the stream (scratch: they are re-laid out into the resident arrays)
 struct Piece {
-    DevPool pool;
     int32_t *pos = nullptr, *end = nullptr, *tlen = nullptr;
     uint16_t *flag = nullptr;
     uint8_t *mapq = nullptr;
     int64_t n = 0;
-    hipError_t alloc(int64_t count)
+    hipError_t alloc(ScratchPool &pool, int64_t count)
     {
         n = count;
         hipError_t e = pool.alloc(&pos, (size_t)count);
@@ -465,7 +535,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevPool tmp;
+    ScratchPool tmp(ctx->device, st);
     uint8_t *d_view = nullptr;
     HIP_TRY(tmp.alloc(&d_view, (size_t)(carry_cap + std::min(total, chunk_cap)) + 64));
     uint8_t *const d_data = d_view + carry_cap;        // where every chunk's own bytes begin
@@ -683,7 +753,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         if (n_chunk > 0) {
             pieces.emplace_back(new Piece);
             Piece &pc = *pieces.back();
-            DD_TRY(pc.alloc(n_chunk));
+            DD_TRY(pc.alloc(tmp, n_chunk));
             DD_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             DD_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
             DD_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -722,7 +792,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
     hipError_t e = hipSuccess;
     if (pieces.size() > 1) {
-        e = whole.alloc(n_reads);
+        e = whole.alloc(tmp, n_reads);
         int64_t at = 0;
         for (auto &pp : pieces) {
             Piece &pc = *pp;
@@ -864,7 +934,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         i = j;
     }
 
-    DevPool tmp;
+    ScratchPool tmp(ctx->device, st);
     uint8_t *d_view = nullptr;
     int32_t *d_ref_len = nullptr;
     long long *d_ref_first = nullptr;
@@ -1060,7 +1130,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         if (n_chunk > 0) {
             pieces.emplace_back(new Piece);
             Piece &pc = *pieces.back();
-            DR_TRY(pc.alloc(n_chunk));
+            DR_TRY(pc.alloc(tmp, n_chunk));
             DR_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             DR_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
             DR_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1088,7 +1158,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     Piece whole;
     Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
     if (pieces.size() > 1) {
-        DR_TRY(whole.alloc(n_reads));
+        DR_TRY(whole.alloc(tmp, n_reads));
         int64_t at = 0;
         for (auto &pp : pieces) {
             Piece &pc = *pp;
@@ -1119,6 +1189,8 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     *out = R;
     return BSIG_OK;
 }
+
+void release_decode_scratch() { g_scratch.release_all(); }
 
 }  // namespace bsig
 

@@ -16,6 +16,7 @@
 #include "bamio.h"
 #include "host_util.h"
 
+namespace bsig { void release_decode_scratch(); }
 using bsig::fail;
 
 struct bsig_bam {
@@ -507,6 +508,7 @@ void bsig_cache_clear(void)
     g_cache.clear();
     for (DevSlot &d : g_cache.slots) d.destroy();
     g_cache.slots.clear();
+    bsig::release_decode_scratch();
 }
 
 }  // extern "C"

@@ -70,5 +70,7 @@ namespace bsig {
 int layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_ref, const int32_t *ref_len,
                        const int64_t *ref_off, const int32_t *d_pos, const int32_t *d_end,
                        const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tlen);
+// hands the device-side decode's cached scratch back to the driver (devdecode.hip)
+void release_decode_scratch();
 }  // namespace bsig
 #endif
