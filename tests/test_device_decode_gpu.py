@@ -488,3 +488,26 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", raising=False)
         monkeypatch.delenv("BAMSIGNALS_BATCH_BLOCKS", raising=False)
         os.remove(path); os.remove(path + ".bai")
+
+
+def test_damaged_deflate_data_with_the_gpu_inflate(ctx, tmp_path, monkeypatch):
+    """an invalid DEFLATE stream inside one block: k_inflate reports it, the call takes the CPU path,
+    which names the problem"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    raw = bytearray(open(BAM, "rb").read())
+    # second block: make its first deflate block's type 3 (reserved) -> invalid for any decoder
+    o = struct.unpack_from("<H", raw, 16)[0] + 1
+    xlen = struct.unpack_from("<H", raw, o + 10)[0]
+    raw[o + 12 + xlen] |= 0x06
+    p = tmp_path / "bad.bam"
+    p.write_bytes(bytes(raw))
+    _empty_bai(str(p) + ".bai", 3)
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu")
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "1")
+    with pytest.raises(_lib.BsigError, match="inflate"):
+        Reads.from_bam(ctx, BamFile(str(p)))
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+    with pytest.raises(_lib.BsigError, match="CPU decode path"):
+        Reads.from_bam(ctx, BamFile(str(p)))
