@@ -538,6 +538,64 @@ static int scan_blocks(const MappedFile &f, const std::string &path, std::vector
     // fault after the other: map the pages in from several threads first (8-15 ms -> a few ms for a
     // 300-MB file; the inflate would fault them in anyway).
     if (f.size >= (16u << 20)) populate_spans(f, {{0, f.size}});
+    // Large files: the header chain is walked in K segments at once.  A segment begins at the first
+    // offset behind its cut from which a chain of kHops valid block headers follows (the gzip magic
+    // and the BC subfield make a false start all but impossible; the join below catches one
+    // anyway): the segments' lists are accepted only if every one ends exactly where the next one
+    // begins, otherwise the plain serial walk runs.
+    const int kHops = 4;
+    uint64_t seg_bytes = 32u << 20;
+    if (const char *e = getenv("BAMSIGNALS_SCAN_SEGMENT_KB")) {          // testing: segments on small files
+        const long v = atol(e);
+        if (v > 0) seg_bytes = (uint64_t)v << 10;
+    }
+    if (f.size >= 4 * seg_bytes) {
+        const size_t K = (size_t)std::min<uint64_t>(256, f.size / seg_bytes);
+        std::vector<std::vector<Block>> part(K);
+        std::vector<uint64_t> first(K, 0), last_end(K, 0);
+        std::vector<char> ok(K, 0);
+        parallel_for((int64_t)K, std::min(n_threads(0), 32), [&](int64_t k, int) {
+            const uint64_t cut = (uint64_t)k * (f.size / K), next_cut = k + 1 == (int64_t)K ? f.size : (uint64_t)(k + 1) * (f.size / K);
+            uint64_t start = cut;
+            if (k > 0) {
+                bool found = false;
+                for (uint64_t o = cut; o < next_cut && o + 18 <= f.size && !found; ++o) {
+                    if (f.data[o] != 31 || f.data[o + 1] != 139) continue;
+                    uint64_t q = o;
+                    int hops = 0;
+                    Block b;
+                    while (hops < kHops && q < f.size && parse_block(f, q, b)) { q += b.csize; ++hops; }
+                    if (hops == kHops || (hops > 0 && q == f.size)) { start = o; found = true; }
+                }
+                if (!found) return;
+            }
+            first[(size_t)k] = start;
+            uint64_t o = start;
+            std::vector<Block> &out = part[(size_t)k];
+            while (o < next_cut) {
+                Block b;
+                if (!parse_block(f, o, b)) return;
+                out.push_back(b);
+                o += b.csize;
+            }
+            last_end[(size_t)k] = o;
+            ok[(size_t)k] = 1;
+        });
+        bool good = true;
+        for (size_t k = 0; k < K && good; ++k) {
+            good = ok[k] != 0;
+            if (good && k + 1 < K) good = ok[k + 1] && last_end[k] == first[k + 1];
+            if (good && k + 1 == K) good = last_end[k] == f.size;
+        }
+        if (good) {
+            size_t n = 0;
+            for (const auto &v : part) n += v.size();
+            blocks.reserve(n);
+            for (const auto &v : part) blocks.insert(blocks.end(), v.begin(), v.end());
+            return 0;
+        }
+        blocks.clear();
+    }
     uint64_t off = 0;
     while (off < f.size) {
         Block b;

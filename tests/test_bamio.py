@@ -294,3 +294,24 @@ def test_long_cigar_cg_tag(tmp_path):
     c = BamFile(str(p)).decode()
     assert len(c["pos"]) == 1 and c["cigar_off"][-1] == 80000
     assert np.array_equal(c["cigar"], np.asarray(ops, dtype=np.uint32))
+
+
+def test_block_scan_in_segments(fixture_reads, monkeypatch, tmp_path):
+    """large files have their BGZF header chain walked in segments at once (a segment starts at the
+    first offset from which a chain of valid headers follows; compressed data holds the two magic
+    bytes every 64 kB or so by chance); forced here on the fixture (456 kB) and on a synthetic BAM"""
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    for kb in ("16", "40", "100"):
+        monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", kb)
+        _cols_equal(BamFile(BAM).decode(threads=4), fixture_reads)
+    monkeypatch.delenv("BAMSIGNALS_SCAN_SEGMENT_KB")
+    cols = _synth(400_000, seed=9)
+    p = str(tmp_path / "syn.bam")
+    write_columns_as_bam(p, ["a", "b", "c"], cols)
+    want = BamFile(p).decode(threads=2)
+    assert np.array_equal(want["pos"], cols["pos"])
+    for kb in ("8", "64"):
+        monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", kb)
+        got = BamFile(p).decode(threads=2)
+        for k in ("pos", "flag", "mapq", "tlen", "cigar", "ref_off"):
+            assert np.array_equal(got[k], want[k])
