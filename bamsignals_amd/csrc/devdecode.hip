@@ -291,9 +291,9 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
                           hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    // resident lanes per CU = min(160 KB / 1.2 KB of tables, 8 waves (182 VGPRs) x LANES): 16 lanes
-    // per wave already fill the LDS; fewer leave lanes unused (8: 34 ms instead of 19 for 32,718 blocks)
-    int lanes = n >= 500000 ? 64 : n >= 130000 ? 32 : 16;
+    // resident lanes per CU = min(160 KB / 940 B of tables = 174, 8 waves (182 VGPRs) x LANES) in whole
+    // workgroups: 32 lanes per wave -> five 30-KB workgroups = 160 lanes (16: 128, 64: two 60-KB = 128)
+    int lanes = 32;
     if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
     switch (lanes) {
     case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;

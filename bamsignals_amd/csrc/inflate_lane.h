@@ -5,7 +5,7 @@
 //   * Huffman decoding: a 9-bit (literal/length) and a 6-bit (distance) first-level table answer
 //     nearly every symbol with one 16-bit lookup; longer codes fall back to the canonical walk over
 //     the code lengths (per length the NUMBER of codes, packed two per register, and the symbols
-//     sorted by (length, value): an unrolled compare chain, then one lookup).  1.8 KB per lane
+//     sorted by (length, value): an unrolled compare chain, then one lookup).  936 bytes per lane
 //     (LDS on the device), where zlib-style two-level tables need 5.7 KB;
 //   * one symbol OR a slice of a pending match per turn of the main loop: a lane that copies a
 //     258-byte match does not hold the other lanes of its wave for 258 turns;
@@ -29,14 +29,34 @@ namespace bsig_inflate {
 constexpr int kLFast = 8, kDFast = 0;   // first-level table bits (0: none, every symbol by the walk)
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
-// per-lane working storage (LDS on the device)
+// per-lane working storage (LDS on the device): 936 bytes
 struct LaneTables {
     uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
     uint16_t dfast[kDFast ? (1 << kDFast) : 2];   // distance, likewise
-    uint16_t lsym[288];            // literal/length symbols sorted by (code length, symbol)
-    uint16_t dsym[32];             // distance symbols sorted likewise (30 used)
+    uint32_t lhi[9];               // bit 8 of the literal/length symbols below
     uint16_t offs[16];             // scratch of the table construction
     uint16_t next[16];             // scratch: next canonical code of every length
+    uint8_t lsym[288];             // literal/length symbols sorted by (code length, symbol), low 8 bits
+    uint8_t dsym[32];              // distance symbols sorted likewise (30 used; also the code-length code's)
+};
+
+// the sorted symbols of a code: 9-bit literal/length symbols as a byte + a bit, the others as bytes
+struct LSyms {
+    uint8_t *lo;
+    uint32_t *hi;
+    BSIG_HD void clear() const { for (int k = 0; k < 9; ++k) hi[k] = 0; }
+    BSIG_HD void put(int idx, int s) const
+    {
+        lo[idx] = (uint8_t)s;
+        if (s >> 8) hi[idx >> 5] |= 1u << (idx & 31);
+    }
+    BSIG_HD int get(int idx) const { return (int)lo[idx] | (int)(((hi[idx >> 5] >> (idx & 31)) & 1u) << 8); }
+};
+struct DSyms {
+    uint8_t *v;
+    BSIG_HD void clear() const {}
+    BSIG_HD void put(int idx, int s) const { v[idx] = (uint8_t)s; }
+    BSIG_HD int get(int idx) const { return v[idx]; }
 };
 
 // number of codes of every length 1..15, two 16-bit counts per word (index len >> 1)
@@ -94,7 +114,8 @@ BSIG_HD uint32_t take(BitIn &in, int n)
 BSIG_HD int count_of(const Counts &c, int len) { return (int)((c.w[len >> 1] >> ((len & 1) * 16)) & 0xFFFFu); }
 
 // one symbol of a canonical code by the walk over the code lengths; needs 15 valid bits.  -1: no such code
-BSIG_HD int decode_walk(BitIn &in, const Counts &c, const uint16_t *sym)
+template <typename Syms>
+BSIG_HD int decode_walk(BitIn &in, const Counts &c, const Syms &sym)
 {
     int code = 0, first = 0, index = 0;
     uint64_t b = in.buf;
@@ -108,7 +129,7 @@ BSIG_HD int decode_walk(BitIn &in, const Counts &c, const uint16_t *sym)
         if (code - count < first) {
             in.buf = b;
             in.cnt -= len;
-            return sym[index + (code - first)];
+            return sym.get(index + (code - first));
         }
         index += count;
         first += count;
@@ -118,8 +139,8 @@ BSIG_HD int decode_walk(BitIn &in, const Counts &c, const uint16_t *sym)
     return -1;
 }
 
-template <int FAST>
-BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const uint16_t *sym)
+template <int FAST, typename Syms>
+BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const Syms &sym)
 {
     if (FAST == 0) return decode_walk(in, c, sym);
     const uint32_t e = fast[in.buf & ((1u << FAST) - 1)];
@@ -145,9 +166,10 @@ BSIG_HD uint32_t bit_reverse(uint32_t v, int n)
 
 // counts + sorted symbols + first-level table from n code lengths (0: symbol unused).  Returns
 // false for an over-subscribed set; incomplete sets are accepted (their unused codes decode to -1).
-template <int FAST, typename LenAt>
-BSIG_HD bool construct(Counts &c, uint16_t *fast, uint16_t *sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
+template <int FAST, typename Syms, typename LenAt>
+BSIG_HD bool construct(Counts &c, uint16_t *fast, const Syms &sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
 {
+    sym.clear();
     for (int k = 0; k < 16; ++k) offs[k] = 0;
     for (int i = 0; i < n; ++i) offs[len_at(i)] = (uint16_t)(offs[len_at(i)] + 1);      // offs = counts for now
     for (int k = 0; k < 8; ++k) c.w[k] = 0;
@@ -175,7 +197,7 @@ BSIG_HD bool construct(Counts &c, uint16_t *fast, uint16_t *sym, uint16_t *offs,
     for (int i = 0; i < n; ++i) {
         const int l = len_at(i);
         if (!l) continue;
-        sym[offs[l]++] = (uint16_t)i;
+        sym.put(offs[l]++, i);
         const uint32_t cd = next[l]++;
         if (fast && l <= FAST) {
             const uint16_t e = (uint16_t)((i << 4) | l);
@@ -222,6 +244,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
     in.ahead = peek64(in.p, in.end);
     uint32_t op = 0;
     Counts lc, dc;
+    const LSyms ls{T.lsym, T.lhi};
+    const DSyms ds{T.dsym};
     for (;;) {
         refill(in);
         const uint32_t last = take(in, 1);
@@ -247,8 +271,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
                 auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
                 auto fd = [](int) { return 5; };
-                construct<kLFast>(lc, T.lfast, T.lsym, T.offs, T.next, 288, fl);
-                construct<kDFast>(dc, T.dfast, T.dsym, T.offs, T.next, 30, fd);
+                construct<kLFast>(lc, T.lfast, ls, T.offs, T.next, 288, fl);
+                construct<kDFast>(dc, T.dfast, ds, T.offs, T.next, 30, fd);
             } else {
                 const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
                 if (nlen > 286 || ndist > 30) return ERR_TABLE;
@@ -260,14 +284,14 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 }
                 Counts cc;
                 // the code-length symbols are sorted into dsym (free until the distance code is built)
-                if (!construct<kDFast>(cc, (uint16_t *)nullptr, T.dsym, T.offs, T.next, 19, [&](int i) { return (int)lens[i]; }))
+                if (!construct<kDFast>(cc, (uint16_t *)nullptr, ds, T.offs, T.next, 19, [&](int i) { return (int)lens[i]; }))
                     return ERR_TABLE;
                 // literal/length + distance code lengths, run-length coded
                 int idx = 0;
                 uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
                 while (idx < nlen + ndist) {
                     refill(in);
-                    const int s = decode_walk(in, cc, T.dsym);
+                    const int s = decode_walk(in, cc, ds);
                     if (s < 0) return ERR_CODE;
                     if (s < 16) {
                         ll[idx++] = (uint8_t)s;
@@ -288,8 +312,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     if (overrun(in)) return ERR_INPUT;
                 }
                 if (ll[256] == 0) return ERR_TABLE;               // no end-of-block code
-                if (!construct<kLFast>(lc, T.lfast, T.lsym, T.offs, T.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
-                if (!construct<kDFast>(dc, T.dfast, T.dsym, T.offs, T.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
+                if (!construct<kLFast>(lc, T.lfast, ls, T.offs, T.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
+                if (!construct<kDFast>(dc, T.dfast, ds, T.offs, T.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
                     return ERR_TABLE;
             }
             // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
@@ -305,7 +329,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 bool stop = false;
                 if (pend == 0) {
                     refill(in);
-                    int s = decode<kLFast>(in, T.lfast, lc, T.lsym);
+                    int s = decode<kLFast>(in, T.lfast, lc, ls);
                     if (s < 256) {
                         if (s < 0) { err = ERR_CODE; stop = true; }
                         else if (op >= out_len) { err = ERR_OUTPUT; stop = true; }
@@ -317,7 +341,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         if (s >= 29) { err = ERR_CODE; stop = true; }
                         else {
                             const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
-                            const int d = decode<kDFast>(in, T.dfast, dc, T.dsym);      // <= 20 + 28 of the 56 bits
+                            const int d = decode<kDFast>(in, T.dfast, dc, ds);          // <= 20 + 28 of the 56 bits
                             if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
                             else {
                                 const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
