@@ -659,6 +659,7 @@ int BgzfFile::inflate_list(const BgzfBlock *list, size_t n, uint8_t *dst, int th
     if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
     return 0;
 }
+int decode_threads(int t) { return n_threads(t); }
 void pool_for(int64_t n, int threads, const std::function<void(int64_t)> &body)
 {
     parallel_for(n, n_threads(threads), [&](int64_t i, int) { body(i); });

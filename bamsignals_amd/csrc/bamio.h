@@ -111,6 +111,8 @@ private:
 // index's lower bound, SAM spec 5.3), sorted by file offset and merged: every chunk starts and
 // ends at a record boundary, no two overlap.
 std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<Region> &regions);
+// the number of decode threads a request of `t` (<= 0: default) resolves to
+int decode_threads(int t);
 // runs body(i) for i in [0, n) on the decode thread pool
 void pool_for(int64_t n, int threads, const std::function<void(int64_t)> &body);
 

@@ -461,10 +461,21 @@ namespace bsig {
 
 // > 0: the file (or this build's limits) needs the CPU decode path; nothing was allocated
 constexpr int kNeedsCpuPath = 1;
-// Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so: k_inflate takes
-// ~19 ms for anything up to one chip-load of blocks (33,000: every lane walks its ~6,500 symbols
-// one after the other), the CPU pool ~10 ms per 9,600 blocks -- the GPU from 16,384 blocks on
-constexpr size_t kGpuInflateMinBlocks = 16384;
+// Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so.  Both engines'
+// times follow the COMPRESSED size (the number of Huffman symbols): the CPU pool needs 0.13-0.2 ms per
+// MB with 32 threads (libdeflate; 300 MB of 52-byte records and 315 MB of sequence-bearing records
+// both take ~41 ms), k_inflate ~2.6 ms per KB of the average block per round of 40,960 resident
+// lanes -- every lane walks its block's symbols one after the other -- plus the trip of the
+// compressed bytes.  Few or badly compressible blocks: CPU; many: GPU.
+inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, int threads)
+{
+    if (n_blocks == 0) return false;
+    const double comp_mb = (double)comp_bytes / (1 << 20);
+    const double t_cpu = comp_mb * 0.15 * 32.0 / (double)std::max(1, bsig::decode_threads(threads));
+    const double rounds = (double)((n_blocks + 40959) / 40960);
+    const double t_gpu = rounds * ((double)comp_bytes / (double)n_blocks / 1024.0) * 2.6 + comp_mb * 0.015 + 0.3;
+    return t_gpu < t_cpu;
+}
 
 namespace {
 
@@ -548,7 +559,9 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
 
     // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
     const char *eng = getenv("BAMSIGNALS_INFLATE");
-    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : nb >= kGpuInflateMinBlocks;
+    uint64_t comp_total = 0;
+    for (const BgzfBlock &b : blocks) comp_total += b.dlen;
+    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(nb, comp_total, threads);
     uint8_t *d_comp = nullptr, *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
@@ -965,8 +978,12 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     DR_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
     const char *eng = getenv("BAMSIGNALS_INFLATE");
     size_t n_island_blocks = 0;
-    for (const Island &I : isl) n_island_blocks += I.blocks.size();
-    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : n_island_blocks >= kGpuInflateMinBlocks;
+    uint64_t comp_total = 0;
+    for (const Island &I : isl) {
+        n_island_blocks += I.blocks.size();
+        for (const BgzfBlock &b : I.blocks) comp_total += b.dlen;
+    }
+    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_island_blocks, comp_total, threads);
     uint8_t *d_comp = nullptr, *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;

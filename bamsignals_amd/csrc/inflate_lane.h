@@ -7,8 +7,9 @@
 //     the code lengths (per length the NUMBER of codes, packed two per register, and the symbols
 //     sorted by (length, value): an unrolled compare chain, then one lookup).  936 bytes per lane
 //     (LDS on the device), where zlib-style two-level tables need 5.7 KB;
-//   * one symbol OR a slice of a pending match per turn of the main loop: a lane that copies a
-//     258-byte match does not hold the other lanes of its wave for 258 turns;
+//   * per turn of the main loop one symbol (up to six if they are literals the first-level table
+//     knows) OR a slice of a pending match: a lane that copies a 258-byte match does not hold the
+//     other lanes of its wave for 258 turns;
 //   * the LZ77 window is the output itself (global memory): matches read back what the lane wrote.
 //
 // The same source compiles for the host (tests/test_inflate_lane.py runs it against zlib) and for
@@ -27,6 +28,10 @@
 namespace bsig_inflate {
 
 constexpr int kLFast = 8, kDFast = 0;   // first-level table bits (0: none, every symbol by the walk)
+#ifndef BSIG_MULTI_LIT
+#define BSIG_MULTI_LIT 1
+#endif
+constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
 // per-lane working storage (LDS on the device): 936 bytes
@@ -325,7 +330,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
             for (uint32_t k = 0; k < kTurn / 8; ++k) v[k] = 0;
             int err = OK;
             for (;;) {
-                int lit = -1;
+                uint64_t lit = 0;
+                uint32_t nlit = 0;
                 bool stop = false;
                 if (pend == 0) {
                     refill(in);
@@ -333,7 +339,26 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     if (s < 256) {
                         if (s < 0) { err = ERR_CODE; stop = true; }
                         else if (op >= out_len) { err = ERR_OUTPUT; stop = true; }
-                        else lit = s;
+                        else {
+                            // a literal; up to five more if the first-level table says the next symbols
+                            // are literals too (<= 8 bits each: the 56 bits of the refill cover 15 + 5 x 8)
+                            lit = (uint64_t)s;
+                            nlit = 1;
+                            if (kLFast > 0 && kMultiLit) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                                for (int q = 1; q < 6; ++q) {
+                                    const uint32_t e = T.lfast[in.buf & ((1u << kLFast) - 1)];
+                                    if (e == 0 || (e >> 4) >= 256u || nlit != (uint32_t)q || op + (uint32_t)q >= out_len) break;
+                                    const int len = (int)(e & 15u);
+                                    in.buf >>= len;
+                                    in.cnt -= len;
+                                    lit |= (uint64_t)(e >> 4) << (8 * q);
+                                    nlit = (uint32_t)q + 1;
+                                }
+                            }
+                        }
                     } else if (s == 256) {
                         stop = true;
                     } else {
@@ -363,7 +388,14 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     dn = 0;
                 }
                 if (stop) break;
-                if (lit >= 0) out[op++] = (uint8_t)lit;
+                if (nlit) {
+                    if (op + 8 <= out_len) {
+                        store64(out + op, lit);      // (what lies behind the literals is overwritten by what follows)
+                    } else {
+                        for (uint32_t q = 0; q < nlit; ++q) out[op + q] = (uint8_t)(lit >> (8 * q));
+                    }
+                    op += nlit;
+                }
                 if (pend) {
                     // up to kTurn bytes of the match per turn, in 8-byte moves.  A move may write up to 7
                     // bytes past the match (inside this block's own area: the next symbols overwrite
