@@ -350,7 +350,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
 #endif
                                 for (int q = 1; q < 6; ++q) {
                                     const uint32_t e = T.lfast[in.buf & ((1u << kLFast) - 1)];
-                                    if (e == 0 || (e >> 4) >= 256u || nlit != (uint32_t)q || op + (uint32_t)q >= out_len) break;
+                                    if (e == 0 || (e >> 4) >= 256u || in.cnt < 2 * kLFast || op + (uint32_t)q >= out_len) break;
                                     const int len = (int)(e & 15u);
                                     in.buf >>= len;
                                     in.cnt -= len;
