@@ -505,6 +505,59 @@ uint64_t env_mb(const char *name, uint64_t dflt_mb)
 
 }  // namespace
 
+// The common end of both decodes: the chunks' column pieces joined (when there are several), the
+// first read of every reference read back, the resident layout built.  Returns a new bsig_reads
+// in *out or an error; t_gpu_join receives the time before the layout, t_layout the layout's.
+int finish_reads(bsig_ctx *ctx, hipStream_t st, ScratchPool &tmp, std::vector<std::unique_ptr<Piece>> &pieces, int64_t n_reads,
+                 const BamHeader &hdr, const long long *d_ref_first, double &t_gpu_join, double &t_layout, bsig_reads **out)
+{
+    const double t_join = now_s();
+    const int32_t n_ref = (int32_t)hdr.names.size();
+    bsig_reads *R = new bsig_reads;
+    R->ctx = ctx;
+    std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
+    auto bail = [&](int code) { (void)hipStreamSynchronize(st); delete R; return code; };
+    if (n_reads == 0 || n_ref == 0) {
+        const int rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return bail(rc);
+        *out = R;
+        return BSIG_OK;
+    }
+    Piece whole;
+    Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
+    hipError_t e = hipSuccess;
+    if (pieces.size() > 1) {
+        e = whole.alloc(tmp, n_reads);
+        int64_t at = 0;
+        for (auto &pp : pieces) {
+            Piece &pc = *pp;
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(whole.mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st);
+            at += pc.n;
+        }
+    }
+    std::vector<long long> ref_first((size_t)n_ref + 1, -1);
+    if (e == hipSuccess) e = hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+        return bail(fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "joining the decoded columns failed: %s", hipGetErrorString(e)));
+    ref_off[(size_t)n_ref] = n_reads;
+    for (int32_t r = n_ref - 1; r >= 0; --r)
+        ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
+    ref_off[0] = 0;
+    t_gpu_join = now_s() - t_join;
+    const double t_lay = now_s();
+    const int rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), cols->pos, cols->end, cols->flag,
+                                      cols->mapq, cols->tlen);
+    if (rc) return bail(rc);
+    t_layout = now_s() - t_lay;
+    *out = R;
+    return BSIG_OK;
+}
+
 // Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
 //
 // The uncompressed stream passes through HBM in chunks (default 8 GiB; a 30x human BAM inflates to
@@ -788,55 +841,14 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     T[1] = t_inflate;
     T[2] = t_wait;
 
-    // ---- join the pieces, first read of every reference ----------------------------------------------
-    const double t_join = now_s();
-    bsig_reads *R = new bsig_reads;
-    R->ctx = ctx;
-    std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
-    auto bail = [&](int code) { (void)hipStreamSynchronize(st); delete R; return code; };
-    if (n_reads == 0 || n_ref == 0) {
-        rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
-        if (rc) return bail(rc);
-        *out = R;
-        T[4] = now_s() - t_begin;
-        return BSIG_OK;
-    }
-    Piece whole;
-    Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
-    hipError_t e = hipSuccess;
-    if (pieces.size() > 1) {
-        e = whole.alloc(tmp, n_reads);
-        int64_t at = 0;
-        for (auto &pp : pieces) {
-            Piece &pc = *pp;
-            if (e == hipSuccess) e = hipMemcpyAsync(whole.pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(whole.end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(whole.tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(whole.flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(whole.mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st);
-            at += pc.n;
-        }
-    }
-    std::vector<long long> ref_first((size_t)n_ref + 1, -1);
-    if (e == hipSuccess) e = hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess)
-        return bail(fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "joining the decoded columns failed: %s", hipGetErrorString(e)));
-    if (pieces.size() > 1) pieces.clear();
-    ref_off[(size_t)n_ref] = n_reads;
-    for (int32_t r = n_ref - 1; r >= 0; --r)
-        ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
-    ref_off[0] = 0;
-    T[3] = t_gpu + (now_s() - t_join);
 #undef DD_TRY
-
-    const double t_lay = now_s();
-    rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), cols->pos, cols->end, cols->flag, cols->mapq,
-                            cols->tlen);
-    if (rc) return bail(rc);
-    T[5] = now_s() - t_lay;
+    // ---- join the pieces, first read of every reference, resident layout ---------------------------
+    double t_join = 0, t_layout = 0;
+    rc = finish_reads(ctx, st, tmp, pieces, n_reads, hdr, d_ref_first, t_join, t_layout, out);
+    if (rc) return rc;
+    T[3] = t_gpu + t_join;
+    T[5] = t_layout;
     T[4] = now_s() - t_begin;
-    *out = R;
     return BSIG_OK;
 }
 
@@ -913,16 +925,14 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    bsig_reads *R = new bsig_reads;
-    R->ctx = ctx;
-    auto bail = [&](int code) { (void)hipStreamSynchronize(st); delete R; return code; };
-    std::vector<int64_t> ref_off((size_t)n_ref + 1, 0);
+    ScratchPool tmp(ctx->device, st);
+    std::vector<std::unique_ptr<Piece>> pieces;
+    auto bail = [&](int code) { (void)hipStreamSynchronize(st); return code; };
     if (total == 0 || n_ref == 0) {
-        rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
-        if (rc) return bail(rc);
-        *out = R;
+        double tj = 0, tl = 0;
+        rc = finish_reads(ctx, st, tmp, pieces, 0, hdr, nullptr, tj, tl, out);
         T[4] = now_s() - t_begin;
-        return BSIG_OK;
+        return rc;
     }
 
     const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
@@ -940,14 +950,13 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         uint64_t bytes = 0;
         size_t segs = 0;
         while (j < isl.size() && (j == i || bytes + isl[j].bytes <= chunk_cap)) { bytes += isl[j].bytes; segs += isl[j].blocks.size() + 2; ++j; }
-        if (bytes > (64ull << 30)) { delete R; return kNeedsCpuPath; }      // one island beyond any sensible chunk
+        if (bytes > (64ull << 30)) return kNeedsCpuPath;                    // one island beyond any sensible chunk
         groups.emplace_back(i, j);
         max_group = std::max(max_group, bytes);
         max_seg = std::max(max_seg, segs);
         i = j;
     }
 
-    ScratchPool tmp(ctx->device, st);
     uint8_t *d_view = nullptr;
     int32_t *d_ref_len = nullptr;
     long long *d_ref_first = nullptr;
@@ -1004,7 +1013,6 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     if (rc) return bail(rc);
     auto decline = [&]() { return bail(kNeedsCpuPath); };
 
-    std::vector<std::unique_ptr<Piece>> pieces;
     int64_t n_reads = 0;
     int32_t last_rid = -1, last_pos = -1;
     int half = 0;
@@ -1162,48 +1170,14 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     T[1] = t_inflate;
     T[2] = t_wait;
 
-    // ---- join the pieces, first read of every reference ----------------------------------------------
-    const double t_join = now_s();
-    ref_off.assign((size_t)n_ref + 1, n_reads);
-    if (n_reads == 0) {
-        rc = layout_from_device(ctx, R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
-        if (rc) return bail(rc);
-        *out = R;
-        T[4] = now_s() - t_begin;
-        return BSIG_OK;
-    }
-    Piece whole;
-    Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
-    if (pieces.size() > 1) {
-        DR_TRY(whole.alloc(tmp, n_reads));
-        int64_t at = 0;
-        for (auto &pp : pieces) {
-            Piece &pc = *pp;
-            DR_TRY(hipMemcpyAsync(whole.pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
-            DR_TRY(hipMemcpyAsync(whole.end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
-            DR_TRY(hipMemcpyAsync(whole.tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
-            DR_TRY(hipMemcpyAsync(whole.flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st));
-            DR_TRY(hipMemcpyAsync(whole.mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st));
-            at += pc.n;
-        }
-    }
-    std::vector<long long> ref_first((size_t)n_ref + 1, -1);
-    DR_TRY(hipMemcpyAsync(ref_first.data(), d_ref_first, ((size_t)n_ref + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
-    DR_TRY(hipStreamSynchronize(st));
 #undef DR_TRY
-    if (pieces.size() > 1) pieces.clear();
-    ref_off[(size_t)n_ref] = n_reads;
-    for (int32_t r = n_ref - 1; r >= 0; --r)
-        ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
-    ref_off[0] = 0;
-    T[3] = t_gpu + (now_s() - t_join);
-    const double t_lay = now_s();
-    rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), cols->pos, cols->end, cols->flag, cols->mapq,
-                            cols->tlen);
-    if (rc) return bail(rc);
-    T[5] = now_s() - t_lay;
+    // ---- join the pieces, first read of every reference, resident layout ---------------------------
+    double t_join = 0, t_layout = 0;
+    rc = finish_reads(ctx, st, tmp, pieces, n_reads, hdr, d_ref_first, t_join, t_layout, out);
+    if (rc) return rc;
+    T[3] = t_gpu + t_join;
+    T[5] = t_layout;
     T[4] = now_s() - t_begin;
-    *out = R;
     return BSIG_OK;
 }
 
