@@ -140,6 +140,44 @@ struct Deflater {
     }
 };
 
+uint32_t crc32_of(const uint8_t *p, size_t n);
+}  // namespace
+
+bool crc_check_enabled()
+{
+    static const bool on = getenv("BAMSIGNALS_NO_CRC") == nullptr;
+    return on;
+}
+
+const uint32_t *crc32_slice8_tables()
+{
+    static uint32_t t[8][256];
+    static const bool ready = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int k = 1; k < 8; ++k) t[k][i] = t[0][t[k - 1][i] & 0xFFu] ^ (t[k - 1][i] >> 8);
+        return true;
+    }();
+    (void)ready;
+    return &t[0][0];
+}
+
+namespace {
+
+// inflate one block and compare the CRC32 of what came out with the block's trailer (as htslib does)
+// 0 ok, 1 inflate failed, 2 CRC mismatch
+template <typename Inf>
+int inflate_checked(Inf &inf, const uint8_t *file, const BgzfBlock &b, uint8_t *dst)
+{
+    if (!inf.run(file + b.coff + b.doff, b.dlen, dst, b.isize)) return 1;
+    if (crc_check_enabled() && crc32_of(dst, b.isize) != b.crc) return 2;
+    return 0;
+}
+
 uint32_t crc32_of(const uint8_t *p, size_t n)
 {
     if (ld().ok) return ld().crc32(0, p, n);
@@ -307,6 +345,7 @@ bool parse_block(const MappedFile &f, uint64_t off, Block &b)
     b.doff = 12 + xlen;
     b.dlen = b.csize - b.doff - 8;
     b.isize = rd32(p + b.csize - 4);
+    b.crc = rd32(p + b.csize - 8);
     return true;
 }
 
@@ -617,9 +656,9 @@ static int inflate_batch(const MappedFile &f, const std::vector<Block> &blocks, 
     parallel_for((int64_t)(b1 - b0), threads, [&](int64_t i, int) {
         static thread_local Inflater inf;          // one decompressor per worker thread
         const Block &b = blocks[b0 + (size_t)i];
-        if (!inf.run(f.data + b.coff + b.doff, b.dlen, out.data() + prefix + uoff[(size_t)i], b.isize)) bad = 1;
+        if (const int r = inflate_checked(inf, f.data, b, out.data() + prefix + uoff[(size_t)i])) bad = std::max(bad.load(), r);
     });
-    if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+    if (bad) return fail(BSIG_ERR_FORMAT, bad == 2 ? "BGZF block CRC mismatch (the file is damaged)" : "BGZF inflate failed");
     return 0;
 }
 
@@ -654,9 +693,9 @@ int BgzfFile::inflate_list(const BgzfBlock *list, size_t n, uint8_t *dst, int th
     parallel_for((int64_t)n, n_threads(threads), [&](int64_t i, int) {
         static thread_local Inflater inf;
         const Block &b = list[(size_t)i];
-        if (!inf.run(f.data + b.coff + b.doff, b.dlen, dst + uoff[(size_t)i], b.isize)) bad = 1;
+        if (const int r = inflate_checked(inf, f.data, b, dst + uoff[(size_t)i])) bad = std::max(bad.load(), r);
     });
-    if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+    if (bad) return fail(BSIG_ERR_FORMAT, bad == 2 ? "BGZF block CRC mismatch (the file is damaged)" : "BGZF inflate failed");
     return 0;
 }
 int decode_threads(int t) { return n_threads(t); }
@@ -678,9 +717,9 @@ int BgzfFile::inflate(size_t b0, size_t b1, uint8_t *dst, int threads) const
     parallel_for((int64_t)(b1 - b0), n_threads(threads), [&](int64_t i, int) {
         static thread_local Inflater inf;
         const Block &b = blocks[b0 + (size_t)i];
-        if (!inf.run(f.data + b.coff + b.doff, b.dlen, dst + uoff[(size_t)i], b.isize)) bad = 1;
+        if (const int r = inflate_checked(inf, f.data, b, dst + uoff[(size_t)i])) bad = std::max(bad.load(), r);
     });
-    if (bad) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+    if (bad) return fail(BSIG_ERR_FORMAT, bad == 2 ? "BGZF block CRC mismatch (the file is damaged)" : "BGZF inflate failed");
     return 0;
 }
 
@@ -1008,7 +1047,8 @@ int bam_read_header(const std::string &path, BamHeader &hdr)
         Block b;
         if (!parse_block(f, off, b)) return fail(BSIG_ERR_FORMAT, "malformed BGZF block in %s", path.c_str());
         buf.resize(b.isize);
-        if (!inf.run(f.data + b.coff + b.doff, b.dlen, buf.data(), b.isize)) return fail(BSIG_ERR_FORMAT, "BGZF inflate failed");
+        if (const int r = inflate_checked(inf, f.data, b, buf.data()))
+            return fail(BSIG_ERR_FORMAT, r == 2 ? "BGZF block CRC mismatch (the file is damaged)" : "BGZF inflate failed");
         parser.set_limit(0);     // header only: never parse a record
         const int rc = parser.feed(buf.data(), buf.size());
         if (rc) return rc;
@@ -1194,7 +1234,10 @@ int bam_decode_regions(const std::string &path, const BaiIndex &idx, const std::
             if (b.coff == ce && limit == ~0ull) { limit = upos + ue; parser.set_limit(limit); }
             if (limit != ~0ull && upos >= limit && !parser.pending()) break;
             buf.resize(b.isize);
-            if (!inf.run(f.data + b.coff + b.doff, b.dlen, buf.data(), b.isize)) { bail(fail(BSIG_ERR_FORMAT, "BGZF inflate failed")); return; }
+            if (const int r = inflate_checked(inf, f.data, b, buf.data())) {
+                bail(fail(BSIG_ERR_FORMAT, r == 2 ? "BGZF block CRC mismatch (the file is damaged)" : "BGZF inflate failed"));
+                return;
+            }
             size_t skip = 0;
             if (first) {
                 if (ub > buf.size()) { bail(fail(BSIG_ERR_FORMAT, "BAI offset beyond its BGZF block in %s", path.c_str())); return; }

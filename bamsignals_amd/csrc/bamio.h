@@ -81,6 +81,7 @@ struct BgzfBlock {
     uint32_t doff;       // offset of the deflate data inside the block
     uint32_t dlen;       // deflate bytes
     uint32_t isize;      // uncompressed bytes
+    uint32_t crc;        // CRC32 of the uncompressed bytes (the block's trailer)
 };
 
 // The BGZF layer of a file on its own, for the device-side record decode (devdecode.hip): the
@@ -111,6 +112,10 @@ private:
 // index's lower bound, SAM spec 5.3), sorted by file offset and merged: every chunk starts and
 // ends at a record boundary, no two overlap.
 std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<Region> &regions);
+// false: the CRC32 of inflated BGZF blocks is not compared with their trailers (env BAMSIGNALS_NO_CRC)
+bool crc_check_enabled();
+// the 8 x 256 lookup tables of CRC32 (IEEE, reflected) for 8 bytes per step
+const uint32_t *crc32_slice8_tables();
 // the number of decode threads a request of `t` (<= 0: default) resolves to
 int decode_threads(int t);
 // runs body(i) for i in [0, n) on the decode thread pool

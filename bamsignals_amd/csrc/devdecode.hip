@@ -259,6 +259,7 @@ struct InflateJob {
     uint64_t in_off;     // the block's deflate data in the device copy of the compressed bytes
     uint64_t out_off;    // where its bytes go in the view
     uint32_t in_len, isize;
+    uint32_t crc, pad;   // CRC32 of the block's uncompressed bytes (its BGZF trailer)
 };
 // LaneTables padded to an odd number of dwords: the same field of neighbouring lanes then sits in
 // different LDS banks
@@ -287,8 +288,37 @@ __global__ __launch_bounds__(LANES) void k_inflate(const uint8_t *__restrict__ c
     if (rc) atomicMax(status, rc);
 }
 
+// The CRC32 of every inflated block against its trailer (htslib checks it; so does the CPU path):
+// one lane per block, 8 bytes per step through the slicing-by-8 tables (8 KB, in LDS).
+constexpr int kErrCrc = 7;
+__global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ view, const InflateJob *__restrict__ jobs, int64_t n,
+                                              const uint32_t *__restrict__ tables, int *__restrict__ status)
+{
+    __shared__ uint32_t T[8][256];
+    for (int k = threadIdx.x; k < 8 * 256; k += 64) (&T[0][0])[k] = tables[k];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const InflateJob j = jobs[i];
+    const uint8_t *p = view + j.out_off;
+    uint32_t crc = 0xFFFFFFFFu;
+    uint32_t k = 0;
+    // the words of the next two steps are on their way while this step's eight lookups run
+    uint64_t w0 = j.isize >= 8 ? bsig_inflate::load64(p) : 0, w1 = j.isize >= 16 ? bsig_inflate::load64(p + 8) : 0;
+    for (; k + 8 <= j.isize; k += 8) {
+        const uint64_t w = w0;
+        w0 = w1;
+        w1 = k + 24 <= j.isize ? bsig_inflate::load64(p + k + 16) : 0;
+        const uint32_t lo = crc ^ (uint32_t)w, hi = (uint32_t)(w >> 32);
+        crc = T[7][lo & 0xFFu] ^ T[6][(lo >> 8) & 0xFFu] ^ T[5][(lo >> 16) & 0xFFu] ^ T[4][lo >> 24] ^
+              T[3][hi & 0xFFu] ^ T[2][(hi >> 8) & 0xFFu] ^ T[1][(hi >> 16) & 0xFFu] ^ T[0][hi >> 24];
+    }
+    for (; k < j.isize; ++k) crc = T[0][(crc ^ p[k]) & 0xFFu] ^ (crc >> 8);
+    if ((crc ^ 0xFFFFFFFFu) != j.crc) atomicMax(status, kErrCrc);
+}
+
 hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n, uint8_t *out, uint8_t *lens, int *status,
-                          hipStream_t st)
+                          const uint32_t *crc_tables, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     // resident lanes per CU = min(160 KB / 940 B of tables = 174, 8 waves (182 VGPRs) x LANES) in whole
@@ -302,6 +332,8 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
     case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(4), 4 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
     default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(8), 8 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
     }
+    if (crc_tables)
+        hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, out, jobs, n, crc_tables, status);
     return hipGetLastError();
 }
 
@@ -618,6 +650,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     uint8_t *d_comp = nullptr, *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
+    uint32_t *d_crc_tables = nullptr;
     std::vector<InflateJob> jobs;
     std::vector<uint64_t> in_off;
     if (gpu_inflate) {
@@ -636,6 +669,10 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         HIP_TRY(tmp.alloc(&d_jobs, max_blk));
         HIP_TRY(tmp.alloc(&d_status, 4));
         HIP_TRY(hipMemsetAsync(d_status, 0, 4 * sizeof(int), st));
+        if (crc_check_enabled()) {
+            HIP_TRY(tmp.alloc(&d_crc_tables, 8 * 256));
+            HIP_TRY(hipMemcpyAsync(d_crc_tables, crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
     }
 
     std::lock_guard<std::mutex> lock(g_staging.mu);
@@ -717,10 +754,10 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
                                                  t_inflate, t_wait));
             jobs.resize(B1 - B0);
             for (size_t k = B0; k < B1; ++k)
-                jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize};
+                jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
             const double t0 = now_s();
             DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
-            DD_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, st));
+            DD_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, d_crc_tables, st));
             int status = 0;
             DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
             DD_TRY(hipStreamSynchronize(st));
@@ -996,6 +1033,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     uint8_t *d_comp = nullptr, *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
+    uint32_t *d_crc_tables = nullptr;
     std::vector<InflateJob> jobs;
     std::vector<uint64_t> in_off;
     if (gpu_inflate) {
@@ -1006,6 +1044,10 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         DR_TRY(tmp.alloc(&d_jobs, max_seg));
         DR_TRY(tmp.alloc(&d_status, 4));
         DR_TRY(hipMemsetAsync(d_status, 0, 4 * sizeof(int), st));
+        if (crc_check_enabled()) {
+            DR_TRY(tmp.alloc(&d_crc_tables, 8 * 256));
+            DR_TRY(hipMemcpyAsync(d_crc_tables, crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
     }
 
     std::lock_guard<std::mutex> lock(g_staging.mu);
@@ -1053,12 +1095,12 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
             jobs.resize(list.size());
             uint64_t at = 0;
             for (size_t k = 0; k < list.size(); ++k) {
-                jobs[k] = InflateJob{in_off[k], at, list[k].dlen, list[k].isize};
+                jobs[k] = InflateJob{in_off[k], at, list[k].dlen, list[k].isize, list[k].crc, 0};
                 at += list[k].isize;
             }
             const double ti = now_s();
             DR_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
-            DR_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_view, d_lens, d_status, st));
+            DR_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_view, d_lens, d_status, d_crc_tables, st));
             int status = 0;
             DR_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
             DR_TRY(hipStreamSynchronize(st));

@@ -315,3 +315,18 @@ def test_block_scan_in_segments(fixture_reads, monkeypatch, tmp_path):
         got = BamFile(p).decode(threads=2)
         for k in ("pos", "flag", "mapq", "tlen", "cigar", "ref_off"):
             assert np.array_equal(got[k], want[k])
+
+
+def test_crc_of_bgzf_blocks_is_checked(tmp_path):
+    """a block whose trailer CRC32 does not match what it inflates to is refused (as htslib does)"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    raw = bytearray(open(BAM, "rb").read())
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1           # first block; damage the second one's CRC
+    b2 = struct.unpack_from("<H", raw, bsize + 16)[0] + 1
+    raw[bsize + b2 - 8] ^= 0x5A
+    p = tmp_path / "crc.bam"
+    p.write_bytes(bytes(raw))
+    (tmp_path / "crc.bam.bai").write_bytes(open(BAM + ".bai", "rb").read())
+    with pytest.raises(_lib.BsigError, match="CRC"):
+        BamFile(str(p)).decode()

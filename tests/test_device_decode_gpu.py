@@ -511,3 +511,26 @@ def test_damaged_deflate_data_with_the_gpu_inflate(ctx, tmp_path, monkeypatch):
     monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
     with pytest.raises(_lib.BsigError, match="CPU decode path"):
         Reads.from_bam(ctx, BamFile(str(p)))
+
+
+def test_crc_mismatch_under_both_inflate_engines(ctx, tmp_path, monkeypatch):
+    """a block that inflates fine but not to what its CRC32 says: the GPU's CRC kernel (and the CPU
+    pool's check) refuse it; the call reports it through the CPU path"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    raw = bytearray(open(BAM, "rb").read())
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1
+    b2 = struct.unpack_from("<H", raw, bsize + 16)[0] + 1
+    raw[bsize + b2 - 8] ^= 0x5A
+    p = tmp_path / "crc.bam"
+    p.write_bytes(bytes(raw))
+    _empty_bai(str(p) + ".bai", 3)
+    for eng in ("gpu", "cpu"):
+        monkeypatch.setenv("BAMSIGNALS_INFLATE", eng)
+        monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "1")
+        with pytest.raises(_lib.BsigError, match="CRC"):
+            Reads.from_bam(ctx, BamFile(str(p)))
+        monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+        with pytest.raises(_lib.BsigError, match="CPU decode path"):
+            Reads.from_bam(ctx, BamFile(str(p)))
