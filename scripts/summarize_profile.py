@@ -87,6 +87,6 @@ if dec:
                 "5e7-read BAM, 3 whole-file decodes + index-driven decodes of 100 / 1,000 / 10,000 regions)\n\n")
         f.write("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
         for r in csv.DictReader(open(dec)):
-            if any(s in r["Name"] for s in ("k_inflate", "k_bam_walk", "k_bam_extract", "k_scatter", "k_span_hist", "k_build_idx")):
+            if any(s in r["Name"] for s in ("k_inflate", "k_crc32", "k_bam_walk", "k_bam_extract", "k_scatter", "k_span_hist", "k_build_idx")):
                 f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
 print(open(os.path.join(P, f"{tag}_summary.md")).read())
