@@ -336,6 +336,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 if (pend == 0) {
                     refill(in);
                     int s = decode<kLFast>(in, T.lfast, lc, ls);
+                    uint32_t opx = op;                 // where the next symbol's bytes will go
                     if (s < 256) {
                         if (s < 0) { err = ERR_CODE; stop = true; }
                         else if (op >= out_len) { err = ERR_OUTPUT; stop = true; }
@@ -344,6 +345,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                             // are literals too (<= 8 bits each: the 56 bits of the refill cover 15 + 5 x 8)
                             lit = (uint64_t)s;
                             nlit = 1;
+                            s = -2;                    // nothing more this turn, unless a match follows
                             if (kLFast > 0 && kMultiLit) {
 #if defined(__HIPCC__)
 #pragma unroll
@@ -357,11 +359,22 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                                     lit |= (uint64_t)(e >> 4) << (8 * q);
                                     nlit = (uint32_t)q + 1;
                                 }
+                                // a match right behind the literals rides in the same turn (its bits come
+                                // with a second refill; the words it needs were requested a turn ago)
+                                if (in.cnt >= kLFast) {
+                                    const uint32_t e = T.lfast[in.buf & ((1u << kLFast) - 1)];
+                                    if (e && (e >> 4) > 256u) {
+                                        refill(in);
+                                        s = decode<kLFast>(in, T.lfast, lc, ls);
+                                    }
+                                }
                             }
+                            opx = op + nlit;
                         }
-                    } else if (s == 256) {
+                    }
+                    if (s == 256) {
                         stop = true;
-                    } else {
+                    } else if (s > 256) {
                         s -= 257;
                         if (s >= 29) { err = ERR_CODE; stop = true; }
                         else {
@@ -370,8 +383,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                             if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
                             else {
                                 const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
-                                if (dist > op) { err = ERR_DIST; stop = true; }
-                                else if (op + len > out_len) { err = ERR_OUTPUT; stop = true; }
+                                if (dist > opx) { err = ERR_DIST; stop = true; }
+                                else if (opx + len > out_len) { err = ERR_OUTPUT; stop = true; }
                                 else if (overrun(in)) { err = ERR_INPUT; stop = true; }
                                 else { pend = len; pdist = dist; }
                             }
