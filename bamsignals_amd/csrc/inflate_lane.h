@@ -27,17 +27,17 @@
 
 namespace bsig_inflate {
 
-constexpr int kLFast = 8, kDFast = 0;   // first-level table bits (0: none, every symbol by the walk)
+constexpr int kLFast = 8, kDFast = 5;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit)
 #ifndef BSIG_MULTI_LIT
 #define BSIG_MULTI_LIT 1
 #endif
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
-// per-lane working storage (LDS on the device): 936 bytes
+// per-lane working storage (LDS on the device): 964 bytes
 struct LaneTables {
     uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
-    uint16_t dfast[kDFast ? (1 << kDFast) : 2];   // distance, likewise
+    uint8_t dfast[1 << kDFast];    // distance: (symbol << 3) | code length (<= 5), 0 = longer code
     uint32_t lhi[9];               // bit 8 of the literal/length symbols below
     uint16_t offs[16];             // scratch of the table construction
     uint16_t next[16];             // scratch: next canonical code of every length
@@ -158,6 +158,19 @@ BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const Syms 
     return decode_walk(in, c, sym);
 }
 
+// a distance symbol: the 8-bit first-level table, else the walk
+BSIG_HD int decode_dist(BitIn &in, const uint8_t *fast, const Counts &c, const DSyms &sym)
+{
+    const uint32_t e = fast[in.buf & ((1u << kDFast) - 1)];
+    if (e) {
+        const int len = (int)(e & 7u);
+        in.buf >>= len;
+        in.cnt -= len;
+        return (int)(e >> 3);
+    }
+    return decode_walk(in, c, sym);
+}
+
 BSIG_HD uint32_t bit_reverse(uint32_t v, int n)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -171,8 +184,22 @@ BSIG_HD uint32_t bit_reverse(uint32_t v, int n)
 
 // counts + sorted symbols + first-level table from n code lengths (0: symbol unused).  Returns
 // false for an over-subscribed set; incomplete sets are accepted (their unused codes decode to -1).
-template <int FAST, typename Syms, typename LenAt>
-BSIG_HD bool construct(Counts &c, uint16_t *fast, const Syms &sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
+// first-level tables: 16-bit entries (symbol << 4 | length) or 8-bit ones (symbol << 3 | length)
+struct Fast16 {
+    uint16_t *t;
+    BSIG_HD bool on() const { return t != nullptr; }
+    BSIG_HD void put(uint32_t k, int s, int l) const { t[k] = (uint16_t)((s << 4) | l); }
+    BSIG_HD void zero(uint32_t k) const { t[k] = 0; }
+};
+struct Fast8 {
+    uint8_t *t;
+    BSIG_HD bool on() const { return t != nullptr; }
+    BSIG_HD void put(uint32_t k, int s, int l) const { t[k] = (uint8_t)((s << 3) | l); }
+    BSIG_HD void zero(uint32_t k) const { t[k] = 0; }
+};
+
+template <int FAST, typename FastT, typename Syms, typename LenAt>
+BSIG_HD bool construct(Counts &c, const FastT &fast, const Syms &sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
 {
     sym.clear();
     for (int k = 0; k < 16; ++k) offs[k] = 0;
@@ -196,18 +223,16 @@ BSIG_HD bool construct(Counts &c, uint16_t *fast, const Syms &sym, uint16_t *off
         offs[len] = (uint16_t)acc;
         acc += cnt;
     }
-    if (FAST == 0) fast = nullptr;
-    if (fast)
-        for (int k = 0; k < (1 << FAST); ++k) fast[k] = 0;
+    const bool use_fast = FAST > 0 && fast.on();
+    if (use_fast)
+        for (uint32_t k = 0; k < (1u << FAST); ++k) fast.zero(k);
     for (int i = 0; i < n; ++i) {
         const int l = len_at(i);
         if (!l) continue;
         sym.put(offs[l]++, i);
         const uint32_t cd = next[l]++;
-        if (fast && l <= FAST) {
-            const uint16_t e = (uint16_t)((i << 4) | l);
-            for (uint32_t k = bit_reverse(cd, l); k < (1u << FAST); k += 1u << l) fast[k] = e;
-        }
+        if (use_fast && l <= FAST)
+            for (uint32_t k = bit_reverse(cd, l); k < (1u << FAST); k += 1u << l) fast.put(k, i, l);
     }
     return true;
 }
@@ -276,8 +301,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
                 auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
                 auto fd = [](int) { return 5; };
-                construct<kLFast>(lc, T.lfast, ls, T.offs, T.next, 288, fl);
-                construct<kDFast>(dc, T.dfast, ds, T.offs, T.next, 30, fd);
+                construct<kLFast>(lc, Fast16{T.lfast}, ls, T.offs, T.next, 288, fl);
+                construct<kDFast>(dc, Fast8{T.dfast}, ds, T.offs, T.next, 30, fd);
             } else {
                 const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
                 if (nlen > 286 || ndist > 30) return ERR_TABLE;
@@ -289,7 +314,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 }
                 Counts cc;
                 // the code-length symbols are sorted into dsym (free until the distance code is built)
-                if (!construct<kDFast>(cc, (uint16_t *)nullptr, ds, T.offs, T.next, 19, [&](int i) { return (int)lens[i]; }))
+                if (!construct<0>(cc, Fast8{nullptr}, ds, T.offs, T.next, 19, [&](int i) { return (int)lens[i]; }))
                     return ERR_TABLE;
                 // literal/length + distance code lengths, run-length coded
                 int idx = 0;
@@ -317,8 +342,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     if (overrun(in)) return ERR_INPUT;
                 }
                 if (ll[256] == 0) return ERR_TABLE;               // no end-of-block code
-                if (!construct<kLFast>(lc, T.lfast, ls, T.offs, T.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
-                if (!construct<kDFast>(dc, T.dfast, ds, T.offs, T.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
+                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, T.offs, T.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
+                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, T.offs, T.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
                     return ERR_TABLE;
             }
             // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
@@ -379,7 +404,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         if (s >= 29) { err = ERR_CODE; stop = true; }
                         else {
                             const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
-                            const int d = decode<kDFast>(in, T.dfast, dc, ds);          // <= 20 + 28 of the 56 bits
+                            const int d = decode_dist(in, T.dfast, dc, ds);             // <= 20 + 28 of the 56 bits
                             if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
                             else {
                                 const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
