@@ -496,7 +496,7 @@ constexpr int kNeedsCpuPath = 1;
 // Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so.  Both engines'
 // times follow the COMPRESSED size (the number of Huffman symbols): the CPU pool needs 0.13-0.2 ms per
 // MB with 32 threads (libdeflate; 300 MB of 52-byte records and 315 MB of sequence-bearing records
-// both take ~41 ms), k_inflate ~2.6 ms per KB of the average block per round of 40,960 resident
+// both take ~41 ms), k_inflate 1.9-2.3 ms per KB of the average block per round of 40,960 resident
 // lanes -- every lane walks its block's symbols one after the other -- plus the trip of the
 // compressed bytes.  Few or badly compressible blocks: CPU; many: GPU.
 inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, int threads)
@@ -505,7 +505,7 @@ inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, int threads)
     const double comp_mb = (double)comp_bytes / (1 << 20);
     const double t_cpu = comp_mb * 0.15 * 32.0 / (double)std::max(1, bsig::decode_threads(threads));
     const double rounds = (double)((n_blocks + 40959) / 40960);
-    const double t_gpu = rounds * ((double)comp_bytes / (double)n_blocks / 1024.0) * 2.6 + comp_mb * 0.015 + 0.3;
+    const double t_gpu = rounds * ((double)comp_bytes / (double)n_blocks / 1024.0) * 2.4 + comp_mb * 0.03 + 0.3;
     return t_gpu < t_cpu;
 }
 
