@@ -31,6 +31,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bamio.h"
@@ -651,10 +652,11 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
     uint32_t *d_crc_tables = nullptr;
+    uint8_t *d_comp2[2] = {nullptr, nullptr};
+    uint64_t max_comp = 0;
     std::vector<InflateJob> jobs;
     std::vector<uint64_t> in_off;
     if (gpu_inflate) {
-        uint64_t max_comp = 0;
         size_t max_blk = 0;
         for (size_t b = 0; b < nb;) {
             size_t e = b;
@@ -673,11 +675,54 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             HIP_TRY(tmp.alloc(&d_crc_tables, 8 * 256));
             HIP_TRY(hipMemcpyAsync(d_crc_tables, crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         }
+        d_comp2[0] = d_comp;
+        d_comp2[1] = d_comp;
+        if (total > chunk_cap) HIP_TRY(tmp.alloc(&d_comp2[1], (size_t)max_comp + 64));     // several passes: two buffers
     }
 
     std::lock_guard<std::mutex> lock(g_staging.mu);
     rc = g_staging.ensure(batch_bytes);
     if (rc) return rc;
+
+    // With the GPU inflating, the compressed bytes of pass j + 1 are packed and copied (helper thread,
+    // its own stream, the other buffer) while the GPU inflates and parses pass j.
+    struct Prefetch {
+        std::thread th;
+        hipStream_t cs = nullptr;
+        int rc = 0;
+        size_t B0 = 0, B1 = 0;
+        std::vector<uint64_t> in_off;
+        double t_host = 0, t_wait = 0;
+        int half = 0;
+        bool used[2] = {false, false};
+        bool active = false;
+        void join() { if (th.joinable()) th.join(); active = false; }
+        ~Prefetch()
+        {
+            join();
+            if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+        }
+    } pf;
+    if (gpu_inflate) HIP_TRY(hipStreamCreateWithFlags(&pf.cs, hipStreamNonBlocking));
+    auto chunk_end = [&](size_t b0) {
+        size_t b1 = b0;
+        uint64_t bytes = 0;
+        while (b1 < nb && (b1 == b0 || bytes + blocks[b1].isize <= chunk_cap)) bytes += blocks[b1++].isize;
+        return b1;
+    };
+    int pass = 0;
+    auto start_prefetch = [&](size_t b0, int which) {
+        pf.B0 = b0;
+        pf.B1 = chunk_end(b0);
+        pf.active = true;
+        pf.th = std::thread([&, which] {
+            (void)hipSetDevice(ctx->device);
+            pf.rc = copy_deflate_data(f, blocks.data() + pf.B0, pf.B1 - pf.B0, d_comp2[which], pf.cs, threads, batch_bytes, pf.half,
+                                      pf.used, pf.in_off, pf.t_host, pf.t_wait);
+            if (pf.rc == 0) pf.rc = (int)hipStreamSynchronize(pf.cs);
+        });
+    };
+    if (gpu_inflate) start_prefetch(0, 0);
 
     // a failure from here on must drain the stream before the buffers go away
     auto decline = [&]() { (void)hipStreamSynchronize(st); return kNeedsCpuPath; };
@@ -750,19 +795,29 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
                 if (header_end < 0) return decline();
                 std::vector<uint8_t>().swap(head);
             }
-            DD_TRY((hipError_t)copy_deflate_data(f, blocks.data() + B0, B1 - B0, d_comp, st, threads, batch_bytes, half, used, in_off,
-                                                 t_inflate, t_wait));
+            // this pass's compressed bytes (requested before the previous pass was worked on)
+            const double tj = now_s();
+            pf.join();
+            t_wait += now_s() - tj;
+            if (pf.rc || pf.B0 != B0 || pf.B1 != B1) DD_TRY(pf.rc ? (hipError_t)pf.rc : hipErrorUnknown);
+            in_off.swap(pf.in_off);
+            t_inflate += pf.t_host;
+            t_wait += pf.t_wait;
+            pf.t_host = pf.t_wait = 0;
+            const uint8_t *d_comp_now = d_comp2[pass & 1];
+            if (B1 < nb) start_prefetch(B1, (pass + 1) & 1);
+            ++pass;
             jobs.resize(B1 - B0);
             for (size_t k = B0; k < B1; ++k)
                 jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
             const double t0 = now_s();
             DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
-            DD_TRY(launch_inflate(d_comp, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, d_crc_tables, st));
+            DD_TRY(launch_inflate(d_comp_now, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, d_crc_tables, st));
             int status = 0;
             DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
             DD_TRY(hipStreamSynchronize(st));
             t_inflate += now_s() - t0;
-            if (getenv("BSIG_DIAG_INFLATE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d)\n", (now_s() - t0) * 1e3, jobs.size(), status);
+            if (getenv("BSIG_DIAG_INFLATE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d) at %.3f s\n", (now_s() - t0) * 1e3, jobs.size(), status, now_s() - t_begin);
             if (status) return decline();      // a damaged block: the CPU path reports it
         } else {
         // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
