@@ -1301,6 +1301,7 @@ struct BamWriter::Impl {
         std::vector<uint64_t> linear;
         uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0, n_unmapped = 0;
         uint32_t last_bin = ~0u;
+        std::vector<BaiChunk> *last_chunks = nullptr;     // bins[last_bin] (map nodes do not move)
     };
     std::vector<RefIdx> ridx;
     uint64_t n_no_coor = 0;
@@ -1363,8 +1364,11 @@ struct BamWriter::Impl {
         if (rid < 0) { ++n_no_coor; return; }
         RefIdx &R = ridx[(size_t)rid];
         const uint32_t bin = reg2bin(beg, end);
-        if (bin == R.last_bin && !R.bins[bin].empty()) R.bins[bin].back().end = v1;
-        else R.bins[bin].push_back(BaiChunk{v0, v1});
+        if (bin == R.last_bin && R.last_chunks && !R.last_chunks->empty()) R.last_chunks->back().end = v1;
+        else {
+            R.last_chunks = &R.bins[bin];
+            R.last_chunks->push_back(BaiChunk{v0, v1});
+        }
         R.last_bin = bin;
         const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
         if (R.linear.size() <= w1) R.linear.resize(w1 + 1, ~0ull);
@@ -1525,6 +1529,133 @@ int BamWriter::write_core(int32_t rid, int32_t pos, uint16_t flag, uint8_t mapq,
     if (rc) return rc;
     if (rid >= p_->n_ref) return fail(BSIG_ERR_FORMAT, "record with refID %d but only %d references", rid, p_->n_ref);
     p_->index_push(rid, pos, endpos, v0, p_->tell(), !(flag & 0x4));
+    return 0;
+}
+
+// The columnar fast path for whole files: the same bytes write_core() produces record by record
+// (same block cuts, same index), with the BGZF blocks built and deflated by the worker pool.
+int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_t *pos, const uint16_t *flag,
+                             const uint8_t *mapq, const int32_t *tlen, const int64_t *cigar_off,
+                             const uint32_t *cigar, int threads)
+{
+    Impl &W = *p_;
+    if (n_ref > W.n_ref) return fail(BSIG_ERR_FORMAT, "columns with %d references but the header has %d", n_ref, W.n_ref);
+    const int64_t n = n_ref > 0 ? ref_off[n_ref] : 0;
+    if (n == 0) return 0;
+    // anything unusual takes the record-by-record path
+    bool plain = W.ubuf.empty();
+    for (int64_t i = 0; i < n && plain; ++i) plain = cigar_off[i + 1] - cigar_off[i] <= 64 && cigar_off[i + 1] >= cigar_off[i];
+    if (!plain) {
+        for (int r = 0; r < n_ref; ++r)
+            for (int64_t i = ref_off[r]; i < ref_off[r + 1]; ++i) {
+                const int rc = write_core(r, pos[i], flag[i], mapq[i], tlen[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]));
+                if (rc) return rc;
+            }
+        return 0;
+    }
+    // block cuts: a record never straddles blocks (write_core flushes first), a block that reaches
+    // kBlockData exactly is closed at once
+    std::vector<int64_t> first;            // first record of every block, + n
+    {
+        size_t fill = 0;
+        first.push_back(0);
+        for (int64_t i = 0; i < n; ++i) {
+            const size_t len = 38 + 4 * (size_t)(cigar_off[i + 1] - cigar_off[i]);
+            if (fill + len > Impl::kBlockData && fill) { first.push_back(i); fill = 0; }
+            fill += len;
+            if (fill == Impl::kBlockData && i + 1 < n) { first.push_back(i + 1); fill = 0; }
+        }
+        first.push_back(n);
+    }
+    const int64_t n_blocks = (int64_t)first.size() - 1;
+    const bool tim = getenv("BAMSIGNALS_WRITER_TIMING") != nullptr;
+    double t_par = 0, t_ser = 0, t_mark = tim ? now_s() : 0;
+    auto rid_of = [&](int64_t i, int r) { while (ref_off[r + 1] <= i) ++r; return r; };
+    constexpr int64_t kBatch = 4096;
+    constexpr size_t kSlot = 0x10000 + 64;
+    std::vector<uint8_t> cbuf((size_t)std::min(kBatch, n_blocks) * kSlot);
+    std::vector<uint32_t> csize((size_t)std::min(kBatch, n_blocks));
+    const int nt = n_threads(threads);
+    std::atomic<int> err(0);
+    int r_cur = 0;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += kBatch) {
+        const int64_t nb = std::min(kBatch, n_blocks - b0);
+        parallel_for(nb, nt, [&](int64_t k, int) {
+            thread_local std::vector<uint8_t> u;
+            thread_local Deflater *dfl = nullptr;
+            thread_local int dfl_level = -1;
+            if (!dfl || dfl_level != W.level) { delete dfl; dfl = new Deflater(W.level); dfl_level = W.level; }
+            const int64_t i0 = first[(size_t)(b0 + k)], i1 = first[(size_t)(b0 + k + 1)];
+            u.clear();
+            int r = 0;
+            {   // reference of the block's first record
+                int lo = 0, hi = n_ref;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ref_off[mid] <= i0) lo = mid; else hi = mid; }
+                r = lo;
+            }
+            for (int64_t i = i0; i < i1; ++i) {
+                r = rid_of(i, r);
+                const int nc = (int)(cigar_off[i + 1] - cigar_off[i]);
+                const uint32_t *cg = cigar + cigar_off[i];
+                uint8_t b[4 + 32 + 2 + 4 * 64];
+                const int32_t bs = 32 + 2 + 4 * nc, rid = r, p0 = pos[i], zero = 0, m1 = -1, tl = tlen[i];
+                const uint16_t fl = flag[i];
+                const int64_t endpos = (int64_t)p0 + cigar_rlen(cg, nc, fl);
+                const uint16_t bin = (uint16_t)reg2bin(std::max(p0, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)nc;
+                memcpy(b, &bs, 4); memcpy(b + 4, &rid, 4); memcpy(b + 8, &p0, 4);
+                b[12] = 2; b[13] = mapq[i];
+                memcpy(b + 14, &bin, 2); memcpy(b + 16, &ncig, 2); memcpy(b + 18, &fl, 2);
+                memcpy(b + 20, &zero, 4); memcpy(b + 24, &m1, 4); memcpy(b + 28, &m1, 4); memcpy(b + 32, &tl, 4);
+                b[36] = '*'; b[37] = 0;
+                if (nc) memcpy(b + 38, cg, 4 * (size_t)nc);
+                u.insert(u.end(), b, b + 4 + bs);
+            }
+            uint8_t *out = cbuf.data() + (size_t)k * kSlot;
+            size_t clen = dfl->run(u.data(), u.size(), out + 18, 0x10000 - 18 - 8);
+            if (clen == 0) {
+                Deflater store(0);
+                clen = store.run(u.data(), u.size(), out + 18, kSlot - 18 - 8);
+                if (clen == 0 || clen + 26 > 0x10000) { err.store(1); return; }
+            }
+            static const uint8_t head[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
+            memcpy(out, head, 12);
+            out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+            const uint16_t bsize = (uint16_t)(clen + 25);
+            memcpy(out + 16, &bsize, 2);
+            const uint32_t crc = crc32_of(u.data(), u.size()), isz = (uint32_t)u.size();
+            memcpy(out + 18 + clen, &crc, 4);
+            memcpy(out + 22 + clen, &isz, 4);
+            csize[(size_t)k] = (uint32_t)(clen + 26);
+        });
+        if (err.load()) return fail(BSIG_ERR_IO, "BGZF block does not fit");
+        if (tim) { const double t = now_s(); t_par += t - t_mark; t_mark = t; }
+        // in file order: the bytes, then the index entries of the batch's records
+        for (int64_t k = 0; k < nb; ++k) {
+            const size_t total = csize[(size_t)k];
+            if (fwrite(cbuf.data() + (size_t)k * kSlot, 1, total, W.fp) != total) return fail(BSIG_ERR_IO, "write to %s failed", W.path.c_str());
+            const uint64_t c0 = W.coff, c1 = W.coff + total;
+            const int64_t i0 = first[(size_t)(b0 + k)], i1 = first[(size_t)(b0 + k + 1)];
+            size_t uoff = 0;
+            for (int64_t i = i0; i < i1; ++i) {
+                r_cur = rid_of(i, r_cur);
+                const int nc = (int)(cigar_off[i + 1] - cigar_off[i]);
+                const size_t len = 38 + 4 * (size_t)nc;
+                if (r_cur < W.last_rid || (r_cur == W.last_rid && pos[i] < W.last_pos)) W.sorted = false;
+                W.last_rid = r_cur; W.last_pos = pos[i];
+                const int64_t endpos = (int64_t)pos[i] + cigar_rlen(cigar + cigar_off[i], nc, flag[i]);
+                const uint64_t v0 = c0 << 16 | (uint64_t)uoff;
+                uoff += len;
+                // (a record that fills its block to the brim ends at the start of the next one, as tell() reports)
+                const uint64_t v1 = uoff == Impl::kBlockData ? c1 << 16 : c0 << 16 | (uint64_t)uoff;
+                W.index_push(r_cur, pos[i], endpos, v0, v1, !(flag[i] & 0x4));
+            }
+            W.coff = c1;
+        }
+        if (tim) { const double t = now_s(); t_ser += t - t_mark; t_mark = t; }
+    }
+    if (tim) fprintf(stderr, "write_columns: %lld blocks, build+deflate %.3f s (%d threads), write+index %.3f s\n", (long long)n_blocks, t_par, nt, t_ser);
+    // the last block stays "open" in the record-by-record writer until close(); here it is already
+    // on disk, which yields the same file: ubuf is empty and close() writes the EOF marker next
     return 0;
 }
 

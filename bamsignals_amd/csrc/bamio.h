@@ -160,6 +160,11 @@ public:
     // columnar fast path used for synthetic data: name "*", no sequence
     int write_core(int32_t rid, int32_t pos, uint16_t flag, uint8_t mapq, int32_t tlen,
                    const uint32_t *cigar, int n_cigar);
+    // a whole coordinate-sorted file from columns: write_core() for every read, with the BGZF blocks
+    // built and deflated by the worker pool (same bytes as the record-by-record calls)
+    int write_columns(int32_t n_ref, const int64_t *ref_off, const int32_t *pos, const uint16_t *flag,
+                      const uint8_t *mapq, const int32_t *tlen, const int64_t *cigar_off,
+                      const uint32_t *cigar, int threads);
     int close();                              // flushes, writes EOF block and <path>.bai
 private:
     struct Impl;

@@ -456,12 +456,18 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
     bsig::BamWriter w;
     int rc = w.open(bampath, h, level > 0 ? level : 1);
     if (rc) return rc;
-    for (int r = 0; r < n_ref; ++r)
-        for (int64_t i = c->ref_off[r]; i < c->ref_off[r + 1]; ++i) {
-            rc = w.write_core(r, c->pos[i], c->flag[i], c->mapq[i], c->tlen[i], c->cigar + c->cigar_off[i],
-                              (int)(c->cigar_off[i + 1] - c->cigar_off[i]));
-            if (rc) return rc;
-        }
+    const char *how = getenv("BAMSIGNALS_WRITER");      // "serial": record by record (testing)
+    if (how && !strcmp(how, "serial")) {
+        for (int r = 0; r < n_ref; ++r)
+            for (int64_t i = c->ref_off[r]; i < c->ref_off[r + 1]; ++i) {
+                rc = w.write_core(r, c->pos[i], c->flag[i], c->mapq[i], c->tlen[i], c->cigar + c->cigar_off[i],
+                                  (int)(c->cigar_off[i + 1] - c->cigar_off[i]));
+                if (rc) return rc;
+            }
+    } else {
+        rc = w.write_columns(n_ref, c->ref_off, c->pos, c->flag, c->mapq, c->tlen, c->cigar_off, c->cigar, 0);
+        if (rc) return rc;
+    }
     return w.close();
 }
 

@@ -62,6 +62,25 @@ def gather_signals(local_out, ranges, binsize, ss, dst=0, group=None):
     return out, off
 
 
+def rank_device(group=None):
+    """The GPU this rank's file-level calls should run on: an explicit BAMSIGNALS_DEVICE(S) wins (-1 =
+    leave it to the library); with the nccl backend torch's current device (the one the communicator
+    is bound to); otherwise LOCAL_RANK modulo the number of GPUs, so that ranks never pile up on
+    GPU 0 by default."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("BAMSIGNALS_DEVICES") or os.environ.get("BAMSIGNALS_DEVICE"):
+        return -1
+    n = torch.cuda.device_count()
+    if n <= 0:
+        return -1
+    if dist.get_backend(group) == "nccl":
+        return torch.cuda.current_device()
+    return int(os.environ.get("LOCAL_RANK", dist.get_rank(group))) % n
+
+
 def _sharded(kind, bampath, gr, dst, group, **kw):
     """Run one of the user-level calls on this rank's shard of ``gr`` and gather on ``dst``."""
     import torch
@@ -72,6 +91,7 @@ def _sharded(kind, bampath, gr, dst, group, **kw):
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    wrappers.set_default_device(rank_device(group))
     levels, codes, start, width, strand = gr.flatten()
     ranges = dict(rid=codes, loc=start - 1, len=width)          # any consistent (seq, start) order works
     mine = shard_indices(ranges["rid"], ranges["loc"], rank, world)

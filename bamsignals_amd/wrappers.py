@@ -69,6 +69,23 @@ def _print_sentence(path):
     print(f"Processing {path}: {random.choice(_SENTENCES)}", file=sys.stderr)
 
 
+# GPU the file-level calls run on when the caller passes no ``device``: -1 = the library's own choice
+# (env BAMSIGNALS_DEVICES, else BAMSIGNALS_DEVICE, else GPU 0).  One-process-per-GPU hosts
+# (bamsignals_amd.dist) set it to their rank's GPU.
+_default_device = -1
+
+
+def set_default_device(device):
+    """Make ``device`` (a GPU ordinal, or -1 for the library's choice) the default of bamCount /
+    bamProfile / bamCoverage in this process."""
+    global _default_device
+    _default_device = int(device)
+
+
+def _dev(device):
+    return _default_device if device is None else int(device)
+
+
 def _check_gr(gr):
     if not isinstance(gr, GRanges):
         raise TypeError("must provide a GRanges object")        # ref: src/bamsignals.cpp:93-94
@@ -83,7 +100,7 @@ def _split(out, off, ss):
 
 
 def pileup_core(bampath, gr, tlen_filter, mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
-                filteredF=-1, pe_mid=False, maxgap=16385, device=-1):
+                filteredF=-1, pe_mid=False, maxgap=16385, device=None):
     """The native entry point behind bamCount/bamProfile (ref: R/RcppExports.R:12-14).  Returns the
     R list as a Python list: per-range vectors / 2 x w matrices, or, for binsize <= 0, a list of
     length one holding the count vector / 2 x n matrix."""
@@ -100,14 +117,14 @@ def pileup_core(bampath, gr, tlen_filter, mapqual=0, binsize=1, shift=0, ss=Fals
                                     names, start.ctypes.data, width.ctypes.data, strand.ctypes.data,
                                     tf.ctypes.data, len(tf), int(mapqual), int(binsize), int(shift),
                                     int(bool(ss)), int(requiredF), int(filteredF), int(bool(pe_mid)),
-                                    int(maxgap), int(device), out.ctypes.data, off.ctypes.data))
+                                    int(maxgap), _dev(device), out.ctypes.data, off.ctypes.data))
     if binsize <= 0:
         return [out.reshape(-1, 2).T if ss else out]
     return _split(out, off, ss)
 
 
 def coverage_core(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1, tspan=False,
-                  maxgap=16385, device=-1):
+                  maxgap=16385, device=None):
     """The native entry point behind bamCoverage (ref: R/RcppExports.R:16-18)."""
     _check_gr(gr)
     lib = _lib.load()
@@ -122,7 +139,7 @@ def coverage_core(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1
                                       len(levels), names, start.ctypes.data, width.ctypes.data,
                                       strand.ctypes.data, tf.ctypes.data, len(tf), int(mapqual),
                                       int(requiredF), int(filteredF), int(bool(tspan)), int(maxgap),
-                                      int(device), out.ctypes.data, off.ctypes.data))
+                                      _dev(device), out.ctypes.data, off.ctypes.data))
     return _split(out, off, False)
 
 

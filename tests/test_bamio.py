@@ -330,3 +330,36 @@ def test_crc_of_bgzf_blocks_is_checked(tmp_path):
     (tmp_path / "crc.bam.bai").write_bytes(open(BAM + ".bai", "rb").read())
     with pytest.raises(_lib.BsigError, match="CRC"):
         BamFile(str(p)).decode()
+
+
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_pooled_column_writer_equals_record_by_record(tmp_path, monkeypatch, threads):
+    """bsig_write_columns_as_bam builds and deflates the BGZF blocks on the worker pool; the file and
+    its index must be byte-identical to the record-by-record writer's (same block cuts, same virtual
+    offsets), including a block that a record fills exactly to the brim."""
+    import filecmp
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    cols = synth_reads(400_000, [900_000, 70_000, 400_000], seed=3, paired=True)
+    # 1,536 reads of 42 bytes + one of 46 bytes... make the first block end exactly at 0xff00:
+    # 0xff00 = 65,280 = 1,554 * 42 + 12 -> use 42-byte records (1 op) and one 54-byte record (4 ops)
+    n = 5000
+    brim = dict(ref_len=np.asarray([100_000], np.int32), ref_off=np.asarray([0, n], np.int64),
+                pos=np.arange(n, dtype=np.int32), flag=np.zeros(n, np.uint16), mapq=np.full(n, 9, np.uint8),
+                tlen=np.zeros(n, np.int32))
+    nops = np.ones(n, np.int64)
+    nops[7] = 4                                           # 1,553 * 42 + 54 = 65,280
+    brim["cigar_off"] = np.concatenate([[0], np.cumsum(nops)]).astype(np.int64)
+    brim["cigar"] = np.full(int(brim["cigar_off"][-1]), 10 << 4, np.uint32)
+    monkeypatch.setenv("BAMSIGNALS_THREADS", threads)
+    for tag, c, names in (("syn", cols, ["a", "b", "c"]), ("brim", brim, ["z"])):
+        monkeypatch.setenv("BAMSIGNALS_WRITER", "serial")
+        write_columns_as_bam(str(tmp_path / f"{tag}_s.bam"), names, c)
+        monkeypatch.delenv("BAMSIGNALS_WRITER")
+        write_columns_as_bam(str(tmp_path / f"{tag}_p.bam"), names, c)
+        assert filecmp.cmp(tmp_path / f"{tag}_s.bam", tmp_path / f"{tag}_p.bam", shallow=False), tag
+        assert filecmp.cmp(tmp_path / f"{tag}_s.bam.bai", tmp_path / f"{tag}_p.bam.bai", shallow=False), tag
+        b = BamFile(str(tmp_path / f"{tag}_p.bam"))
+        got = b.decode(threads=2)
+        assert np.array_equal(got["pos"], c["pos"]) and np.array_equal(got["cigar"], c["cigar"])
+        b.close()

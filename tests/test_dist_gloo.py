@@ -55,13 +55,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gather_over_gloo():
+def _gather_over_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)
@@ -69,6 +68,17 @@ def test_two_rank_gather_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == {"profile_ss": True, "count": True, "coverage": True, "partition": True}
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_over_gloo():
+    _gather_over_gloo(2)
+
+
+@pytest.mark.timeout(420)
+def test_eight_rank_gather_over_gloo():
+    """BASELINE config 5's rank count: 301 ragged ranges dealt round-robin to 8 ranks (37-38 each)."""
+    _gather_over_gloo(8)
 
 
 def test_scatter_segments_rejects_bad_shapes():
