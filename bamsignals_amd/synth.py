@@ -82,18 +82,31 @@ def synth_reads(n_reads, ref_len, seed=0xBA51, paired=False, with_cigar=True):
     dup = rng.random(n_reads) < 0.02
     flag = (flag | np.where(dup, 0x400, 0).astype(np.uint16)).astype(np.uint16)
     out = dict(ref_len=ref_len.astype(np.int32), ref_off=ref_off, rid=rid, pos=pos, flag=flag, mapq=mapq,
-               tlen=tlen, end=end)
+               tlen=tlen, end=end, cigar_menu=which)
     if with_cigar:
-        nops = np.asarray([len(m) for m in CIGAR_MENU], dtype=np.int64)[which]
-        cigar_off = np.concatenate([[0], np.cumsum(nops)]).astype(np.int64)
-        cigar = np.empty(int(cigar_off[-1]), dtype=np.uint32)
-        for k, ops in enumerate(CIGAR_MENU):
-            sel = np.nonzero(which == k)[0]
-            for t, op in enumerate(ops):
-                cigar[cigar_off[sel] + t] = op
-        out["cigar_off"] = cigar_off
-        out["cigar"] = cigar
+        add_cigar(out)
     return out
+
+
+def add_cigar(cols):
+    """Adds the packed CIGAR columns (``cigar_off``, ``cigar``) to reads made with ``with_cigar=False``
+    (the choice from CIGAR_MENU is kept in ``cols["cigar_menu"]``)."""
+    which = cols["cigar_menu"]
+    nops = np.asarray([len(m) for m in CIGAR_MENU], dtype=np.int64)[which]
+    cigar_off = np.empty(len(which) + 1, dtype=np.int64)
+    cigar_off[0] = 0
+    np.cumsum(nops, out=cigar_off[1:])
+    del nops
+    cigar = np.full(int(cigar_off[-1]), CIGAR_MENU[0][0], dtype=np.uint32)     # 90 % are the one-op 100M
+    for k, ops in enumerate(CIGAR_MENU):
+        if k == 0:
+            continue
+        sel = cigar_off[:-1][which == k]
+        for t, op in enumerate(ops):
+            cigar[sel + t] = op
+    cols["cigar_off"] = cigar_off
+    cols["cigar"] = cigar
+    return cols
 
 
 def synth_ranges(n, width, ref_len, seed=0xBA52, strands=(1, -1, 0), jitter=0):
