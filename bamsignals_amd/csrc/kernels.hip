@@ -541,6 +541,13 @@ __global__ __launch_bounds__(NT) void k_count(const BsigWorkItem *__restrict__ i
 // ------------------------------------------------------------------------------------------
 // bamCoverage: +1/-1 difference array in LDS, workgroup prefix scan, coalesced store
 // ------------------------------------------------------------------------------------------
+// The difference array holds SIGNED 16-bit cells, two per LDS dword, as k_profile's image does with
+// unsigned ones: the dword is kept equal to hi * 65536 + lo (mod 2^32) by plain integer adds of
+// +-1 and +-65536 (a borrow out of the low half is part of that sum, not an error), and is taken
+// apart at the end as lo = sign-extended low half, hi = sign-extended high half of (word + 0x8000).
+// A tile that is not cut into slices has at most 32,767 reads in its windows (bsig_plan_create's
+// ceiling for coverage), so every cell stays inside [-32767, 32767].  4 KiB instead of 8 KiB of
+// LDS per 2,048-cell tile: 24 instead of 18 single-wave workgroups per CU.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
                                                  int32_t *__restrict__ out,
@@ -548,9 +555,10 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
                                                  const BsigReadsDev R, const BsigKParams P)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    const int img_vec = (P.tile_cells + 8 + 7) / 8;          // 16-B vectors of the image (8 cells each)
     // per-wave scan totals live behind the tile image, inside the dynamic region, so that the
     // image itself starts at the 16-B aligned LDS base
-    int32_t *wtot = lds + P.tile_cells + 8;
+    int32_t *wtot = lds + 4 * img_vec;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const uint32_t tile = tile_of_block(blockIdx.x, n_tiles);
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
     uint2 win[BSIG_MAX_CLASSES];
     load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win, tile);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
-    for (int v = tid; v < (P.tile_cells + 8) / 4; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    for (int v = tid; v < img_vec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     const int nv = w.nc;
     const int sh = (int)(w.out_off & 3);
     const int nvec = (sh + nv + 3) >> 2;
@@ -580,19 +588,27 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
         const int rb = neg_range ? rend1 - start : end - w.loc;
         const int la = ra - w.c0, lb = rb - w.c0;
         if (la >= w.nc || lb < 0) return;                             // :420
-        atomicAdd(&lds[sh + (la > 0 ? la : 0)], 1);
-        if (lb + 1 < w.nc) atomicAdd(&lds[sh + lb + 1], -1);
+        const int ka = sh + (la > 0 ? la : 0);
+        atomicAdd(&lds[ka >> 1], (ka & 1) ? 65536 : 1);
+        if (lb + 1 < w.nc) {
+            const int kb = sh + lb + 1;
+            atomicAdd(&lds[kb >> 1], (kb & 1) ? -65536 : -1);
+        }
     };
     for_each_read<NT>(R, P, win, tid, one);
     block_sync<NT>();
 
-    // cumsum (:464-470): each lane owns 4 consecutive cells, wave scan of the lane totals,
-    // carry across waves and across passes
+    // cumsum (:464-470): each lane owns 4 consecutive cells (two packed dwords), wave scan of the
+    // lane totals, carry across waves and across passes
     int32_t *gbase = out + (w.out_off - sh);
+    const uint2 *lds2 = reinterpret_cast<const uint2 *>(lds);
+    auto lo16 = [](uint32_t d) { return (int)(int16_t)(uint16_t)d; };
+    auto hi16 = [](uint32_t d) { return (int)(int16_t)(uint16_t)((d + 0x8000u) >> 16); };
     int carry = 0;
     for (int base = 0; base < nvec; base += NT) {
         const int v = base + tid;
-        int4 x = v < nvec ? lds4[v] : make_int4(0, 0, 0, 0);
+        const uint2 d = v < nvec ? lds2[v] : make_uint2(0u, 0u);
+        int4 x = make_int4(lo16(d.x), hi16(d.x), lo16(d.y), hi16(d.y));
         x.y += x.x; x.z += x.y; x.w += x.z;
         const int tot = x.w;
         const int incl = wave_inclusive_scan(tot);
@@ -846,7 +862,7 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
         if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
         else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (mode == BSIG_MODE_COVERAGE) {
-        const size_t lds = (size_t)(tile_cells + 8 + NT / 64) * sizeof(int32_t);
+        const size_t lds = (size_t)((tile_cells + 8 + 7) / 8) * 16 + (size_t)(NT / 64) * sizeof(int32_t);   // signed 16-bit cells
         hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else {
         hipLaunchKernelGGL((k_count<NT>), grid, block, 0, st, items, (uint32_t)n_items, out, windows, R, P);

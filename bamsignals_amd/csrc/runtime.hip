@@ -223,7 +223,9 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         C = BsigClassCols{};
         if (class_n[c] == 0) continue;
         if (class_n[c] >= (1ull << 32) - 8) return fail(BSIG_ERR_ARG, "more than 2^32 reads in one span class");
-        const double bp_per_bucket = 16.0 * (double)total_bp / (double)class_n[c];
+        double per_bucket = 16.0;
+        if (const char *v = getenv("BAMSIGNALS_BUCKET_READS")) per_bucket = std::max(1.0, atof(v));
+        const double bp_per_bucket = per_bucket * (double)total_bp / (double)class_n[c];
         int k = 4;
         while (k < BSIG_REF_UNIT_SHIFT && (double)(1ull << (k + 1)) <= bp_per_bucket) ++k;
         k = std::max(k, min_shift);
@@ -592,6 +594,8 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     int64_t heavy_reads = 32768, slice_reads = 8192;
     // (k_profile's 16-bit tile image relies on the 32,768 ceiling: the environment may only lower it)
     if (const char *v = getenv("BAMSIGNALS_HEAVY_READS")) { heavy_reads = std::min<long long>(32768, std::max<long long>(4, atoll(v))); slice_reads = std::max<int64_t>(4, heavy_reads / 4); }
+    // (k_coverage's cells are SIGNED 16-bit: +32,768 starts on one cell would not fit)
+    if (P->kernel_mode == BSIG_MODE_COVERAGE) heavy_reads = std::min<int64_t>(heavy_reads, 32767);
     if (e == hipSuccess && !items.empty()) {
         DevPool tmp;
         uint2 *d_win = nullptr;

@@ -381,6 +381,7 @@ def main():
     got = w.outs[0][:plan.cells].cpu().numpy()
     parity = cpu = e2e = None
     bases = w.step_bases[0]
+    # (the oracle is the checker and the CPU baseline: loaded on rank 0 only, after the timed region)
     if rank == 0:
         from oracle import oracle_c
         orc, parity = w.check_parity(oracle_c, a.seed)
@@ -474,13 +475,11 @@ def main():
         torch.cuda.empty_cache()
         if cpu is not None and not a.no_e2e:
             try:
-                from oracle import oracle_c
                 res["end_to_end"], cpu["with_bam_decode"] = end_to_end(cfg, cols, rg, want_flat, local, oracle_c)
             except Exception as exc:      # e.g. no room for the BAM on local disk: the metric does not depend on it
                 res["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
         del cols, want_flat
         if a.config != "C2" and not a.no_also and not (a.reads or a.ranges or a.width):
-            from oracle import oracle_c
             w2 = Workload(a, "C2", 0, 1, local, stream)
             k2 = max(a.steps, 200)
             el2, kms2 = w2.timed(k2, max(a.warmup, 20), stream, lambda: None)
