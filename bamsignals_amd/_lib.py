@@ -44,7 +44,7 @@ class Params(C.Structure):
                 ("shift", C.c_int32), ("ss", C.c_int32), ("requiredF", C.c_int32),
                 ("filteredF", C.c_int32), ("pe_mid", C.c_int32), ("tspan", C.c_int32),
                 ("n_tlen_filter", C.c_int32), ("tlen_filter", C.c_int32 * 2),
-                ("tile_cells", C.c_int32), ("threads", C.c_int32), ("resolve", C.c_int32)]
+                ("tile_cells", C.c_int32), ("threads", C.c_int32)]
 
 
 class PlanStats(C.Structure):
@@ -89,6 +89,9 @@ def load():
     lib.bsig_reads_clone.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.bsig_reads_free.argtypes = [C.c_void_p]
     lib.bsig_reads_free.restype = None
+    lib.bsig_reads_save.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    lib.bsig_reads_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.bsig_last_call_route.restype = C.c_char_p
     lib.bsig_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_void_p)]
     lib.bsig_plan_offsets.argtypes = [C.c_void_p]
@@ -99,11 +102,6 @@ def load():
     lib.bsig_plan_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.bsig_plan_run_host.argtypes = [C.c_void_p, C.c_void_p]
     lib.bsig_plan_run_host_async.argtypes = [C.c_void_p, C.c_void_p]
-    lib.bsig_graph_begin.argtypes = [C.c_void_p]
-    lib.bsig_graph_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    lib.bsig_graph_launch.argtypes = [C.c_void_p]
-    lib.bsig_graph_free.argtypes = [C.c_void_p]
-    lib.bsig_graph_free.restype = None
     lib.bsig_plan_free.argtypes = [C.c_void_p]
     lib.bsig_plan_free.restype = None
     lib.bsig_pileup_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -114,6 +112,8 @@ def load():
     lib.bsig_bam_path.argtypes = [C.c_void_p]
     lib.bsig_bam_path.restype = C.c_char_p
     lib.bsig_reads_from_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bsig_reads_from_bam_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_int32)]
     lib.bsig_reads_from_bam_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int32, C.POINTER(C.c_void_p)]
     lib.bsig_device_decode_timing.argtypes = [C.POINTER(C.c_double)]

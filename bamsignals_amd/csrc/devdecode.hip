@@ -28,13 +28,16 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
 #include "bamio.h"
+#include "collect.h"
 #include "inflate_lane.h"
 #include "runtime_internal.h"
 
@@ -366,7 +369,18 @@ struct Staging {
         return BSIG_OK;
     }
 };
-Staging g_staging;
+// One staging area per GPU: its events belong to that device (an event recorded on another
+// device's stream is an error), and decodes on different GPUs must not wait for each other.
+Staging &staging_for(int device)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, std::unique_ptr<Staging>>> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : all)
+        if (kv.first == device) return *kv.second;
+    all.emplace_back(device, std::unique_ptr<Staging>(new Staging));
+    return *all.back().second;
+}
 
 thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
 
@@ -443,8 +457,8 @@ struct ScratchPool {
 
 // The deflate data of the listed blocks, packed back to back, to d_comp (through the page-locked
 // halves, several threads per half); in_off[k] = where block k's data begins in d_comp.
-// The caller holds g_staging.mu.  Returns a hipError_t as int (0 = ok).
-int copy_deflate_data(const bsig::BgzfFile &f, const bsig::BgzfBlock *list, size_t n, uint8_t *d_comp, hipStream_t st,
+// The caller holds S.mu (S = the staging area of the stream's device).  Returns a hipError_t as int (0 = ok).
+int copy_deflate_data(Staging &S, const bsig::BgzfFile &f, const bsig::BgzfBlock *list, size_t n, uint8_t *d_comp, hipStream_t st,
                       int threads, size_t batch_bytes, int &half, bool (&used)[2], std::vector<uint64_t> &in_off,
                       double &t_host, double &t_wait)
 {
@@ -460,15 +474,15 @@ int copy_deflate_data(const bsig::BgzfFile &f, const bsig::BgzfBlock *list, size
             in_off[b1] = packed + bytes;
             bytes += list[b1++].dlen;
         }
-        if (bytes > g_staging.cap) return (int)hipErrorInvalidValue;
+        if (bytes > S.cap) return (int)hipErrorInvalidValue;
         double t0 = now_s();
         if (used[half]) {
-            const hipError_t e = hipEventSynchronize(g_staging.ev[half]);
+            const hipError_t e = hipEventSynchronize(S.ev[half]);
             if (e != hipSuccess) return (int)e;
         }
         t_wait += now_s() - t0;
         t0 = now_s();
-        uint8_t *dst = g_staging.buf[half];
+        uint8_t *dst = S.buf[half];
         const uint8_t *file = f.data();
         const size_t per = 64;                                  // blocks per task
         bsig::pool_for((int64_t)((b1 - b0 + per - 1) / per), threads, [&](int64_t q) {
@@ -478,7 +492,7 @@ int copy_deflate_data(const bsig::BgzfFile &f, const bsig::BgzfBlock *list, size
         });
         t_host += now_s() - t0;
         hipError_t e = bytes ? hipMemcpyAsync(d_comp + packed, dst, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
-        if (e == hipSuccess) e = hipEventRecord(g_staging.ev[half], st);
+        if (e == hipSuccess) e = hipEventRecord(S.ev[half], st);
         if (e != hipSuccess) return (int)e;
         used[half] = true;
         half ^= 1;
@@ -492,8 +506,6 @@ int copy_deflate_data(const bsig::BgzfFile &f, const bsig::BgzfBlock *list, size
 
 namespace bsig {
 
-// > 0: the file (or this build's limits) needs the CPU decode path; nothing was allocated
-constexpr int kNeedsCpuPath = 1;
 // Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so.  Both engines'
 // times follow the COMPRESSED size (the number of Huffman symbols): the CPU pool needs 0.13-0.2 ms per
 // MB with 32 threads (libdeflate; 300 MB of 52-byte records and 315 MB of sequence-bearing records
@@ -591,82 +603,95 @@ int finish_reads(bsig_ctx *ctx, hipStream_t st, ScratchPool &tmp, std::vector<st
     return BSIG_OK;
 }
 
-// Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
+namespace {
+
+// One contiguous run of BGZF blocks [Bbeg, Bend) of a file -> column pieces on ctx's device.
+// The whole file on one GPU is the share [0, n_blocks); with several GPUs every GPU takes one share
+// (reads_from_bam_sharded below).
 //
 // The uncompressed stream passes through HBM in chunks (default 8 GiB; a 30x human BAM inflates to
 // hundreds of GB): [carried tail | chunk].  A chunk ends at a BGZF block border; the record that
 // runs past it is carried in front of the next chunk, where the chain of records continues at
-// offset 0.  Every chunk leaves a piece of the columns; the pieces are joined at the end.
-int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, bsig_reads **out)
+// offset 0.  Every chunk leaves a piece of the columns.
+//
+// A share that does not begin the file does not know where the chain of records stands at its
+// first byte: it takes the first record start its lanes propose, and reports that offset
+// (chain_first) together with the offset its own chain ended at (chain_end).  The caller accepts
+// the shares only if every share's chain ends exactly where the next one's begins -- then the
+// shares' walks, laid end to end, are the serial walk of the stream.  A share that does not end the
+// file sees a few blocks beyond its end (kOverlapBlocks), so that its last record, which may run
+// into the next share's blocks, can be read whole; those blocks' own records belong to the next share.
+struct ShareOut {
+    std::unique_ptr<ScratchPool> tmp;                 // owns everything below (ctx's device)
+    std::vector<std::unique_ptr<Piece>> pieces;
+    int64_t n_reads = 0;
+    long long *d_ref_first = nullptr;                 // n_ref + 1: share-local index of the first read with rid >= q
+    uint64_t chain_first = 0, chain_end = 0;          // absolute offsets in the uncompressed stream
+    int32_t first_rid = -1, first_pos = -1, last_rid = -1, last_pos = -1;
+    double t_inflate = 0, t_wait = 0, t_gpu = 0;
+};
+constexpr size_t kOverlapBlocks = 4;
+
+// Returns BSIG_OK, kNeedsCpuPath (this file / this split cannot be proven on the device), or an error.
+int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const std::vector<uint64_t> &uoff, size_t Bbeg,
+                 size_t Bend, int threads, bool gpu_inflate, ShareOut &R)
 {
-    double *T = g_dev_decode_timing;
-    for (int k = 0; k < 6; ++k) T[k] = 0;
-    const double t_begin = now_s();
-    *out = nullptr;
-    BgzfFile f;
-    int rc = f.open(path);
-    if (rc) return rc;
     const std::vector<BgzfBlock> &blocks = f.blocks();
-    if (blocks.empty()) return kNeedsCpuPath;
     const size_t nb = blocks.size();
-    std::vector<uint64_t> uoff(nb + 1, 0);
-    for (size_t k = 0; k < nb; ++k) {
-        if (blocks[k].isize > 65536u) return kNeedsCpuPath;
-        uoff[k + 1] = uoff[k] + blocks[k].isize;
-    }
-    const uint64_t total = uoff[nb];
-    if (total < 12) return kNeedsCpuPath;
-    BamHeader hdr;
-    rc = bam_read_header(path, hdr);
-    if (rc) return kNeedsCpuPath;                      // the CPU path reports what is wrong
+    const bool first_share = Bbeg == 0, last_share = Bend == nb;
     const int32_t n_ref = (int32_t)hdr.names.size();
-    T[0] = now_s() - t_begin;
+    const uint64_t share_bytes = uoff[Bend] - uoff[Bbeg];
 
     const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
-    const uint64_t carry_cap = total <= chunk_cap ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
+    const uint64_t carry_cap = share_bytes <= chunk_cap ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
     size_t batch_bytes = 32u << 20;        // 512 blocks per copy: pinning 2 x 32 MiB is quick, the copies stay hidden
     if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {          // testing: many small batches
         const long v = atol(e);
         if (v > 0) batch_bytes = (size_t)v * 65536u;
     }
+    // the blocks of one pass [b0, b1) and the end of what it sees (b1 + overlap on a share's last pass)
+    auto chunk_end = [&](size_t b0) {
+        size_t b1 = b0;
+        uint64_t bytes = 0;
+        while (b1 < Bend && (b1 == b0 || bytes + blocks[b1].isize <= chunk_cap)) bytes += blocks[b1++].isize;
+        return b1;
+    };
+    auto view_end = [&](size_t b1) { return (b1 == Bend && !last_share) ? std::min(nb, Bend + kOverlapBlocks) : b1; };
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    ScratchPool tmp(ctx->device, st);
+    R.tmp.reset(new ScratchPool(ctx->device, st));
+    ScratchPool &tmp = *R.tmp;
     uint8_t *d_view = nullptr;
-    HIP_TRY(tmp.alloc(&d_view, (size_t)(carry_cap + std::min(total, chunk_cap)) + 64));
+    HIP_TRY(tmp.alloc(&d_view, (size_t)(carry_cap + std::min(share_bytes, chunk_cap)) + kOverlapBlocks * 65536u + 64));
     uint8_t *const d_data = d_view + carry_cap;        // where every chunk's own bytes begin
     int32_t *d_ref_len = nullptr;
-    long long *d_ref_first = nullptr;
     HIP_TRY(tmp.alloc(&d_ref_len, (size_t)std::max(n_ref, 1)));
-    HIP_TRY(tmp.alloc(&d_ref_first, (size_t)n_ref + 1));
+    HIP_TRY(tmp.alloc(&R.d_ref_first, (size_t)n_ref + 1));
     if (n_ref) HIP_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
+    HIP_TRY(hipMemsetAsync(R.d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
 
-    // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
-    const char *eng = getenv("BAMSIGNALS_INFLATE");
-    uint64_t comp_total = 0;
-    for (const BgzfBlock &b : blocks) comp_total += b.dlen;
-    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(nb, comp_total, threads);
-    uint8_t *d_comp = nullptr, *d_lens = nullptr;
+    // sizes of the largest pass
+    size_t max_seg = 0, max_blk = 0;
+    uint64_t max_comp = 0;
+    int n_pass = 0;
+    for (size_t b = Bbeg; b < Bend;) {
+        const size_t e = chunk_end(b), v = view_end(e);
+        max_comp = std::max<uint64_t>(max_comp, blocks[v - 1].coff + blocks[v - 1].csize - blocks[b].coff);
+        max_blk = std::max(max_blk, v - b);
+        max_seg = std::max(max_seg, e - b + 2);
+        ++n_pass;
+        b = e;
+    }
+    uint8_t *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
     uint32_t *d_crc_tables = nullptr;
     uint8_t *d_comp2[2] = {nullptr, nullptr};
-    uint64_t max_comp = 0;
     std::vector<InflateJob> jobs;
     std::vector<uint64_t> in_off;
     if (gpu_inflate) {
-        size_t max_blk = 0;
-        for (size_t b = 0; b < nb;) {
-            size_t e = b;
-            uint64_t bytes = 0;
-            while (e < nb && (e == b || bytes + blocks[e].isize <= chunk_cap)) bytes += blocks[e++].isize;
-            max_comp = std::max<uint64_t>(max_comp, blocks[e - 1].coff + blocks[e - 1].csize - blocks[b].coff);
-            max_blk = std::max(max_blk, e - b);
-            b = e;
-        }
-        HIP_TRY(tmp.alloc(&d_comp, (size_t)max_comp + 64));
+        HIP_TRY(tmp.alloc(&d_comp2[0], (size_t)max_comp + 64));
         HIP_TRY(tmp.alloc(&d_lens, max_blk * (size_t)bsig_inflate::kLensBytes));
         HIP_TRY(tmp.alloc(&d_jobs, max_blk));
         HIP_TRY(tmp.alloc(&d_status, 4));
@@ -675,13 +700,13 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             HIP_TRY(tmp.alloc(&d_crc_tables, 8 * 256));
             HIP_TRY(hipMemcpyAsync(d_crc_tables, crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         }
-        d_comp2[0] = d_comp;
-        d_comp2[1] = d_comp;
-        if (total > chunk_cap) HIP_TRY(tmp.alloc(&d_comp2[1], (size_t)max_comp + 64));     // several passes: two buffers
+        d_comp2[1] = d_comp2[0];
+        if (n_pass > 1) HIP_TRY(tmp.alloc(&d_comp2[1], (size_t)max_comp + 64));     // several passes: two buffers
     }
 
-    std::lock_guard<std::mutex> lock(g_staging.mu);
-    rc = g_staging.ensure(batch_bytes);
+    Staging &S = staging_for(ctx->device);
+    std::lock_guard<std::mutex> lock(S.mu);
+    int rc = S.ensure(batch_bytes);
     if (rc) return rc;
 
     // With the GPU inflating, the compressed bytes of pass j + 1 are packed and copied (helper thread,
@@ -695,8 +720,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         double t_host = 0, t_wait = 0;
         int half = 0;
         bool used[2] = {false, false};
-        bool active = false;
-        void join() { if (th.joinable()) th.join(); active = false; }
+        void join() { if (th.joinable()) th.join(); }
         ~Prefetch()
         {
             join();
@@ -704,87 +728,70 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         }
     } pf;
     if (gpu_inflate) HIP_TRY(hipStreamCreateWithFlags(&pf.cs, hipStreamNonBlocking));
-    auto chunk_end = [&](size_t b0) {
-        size_t b1 = b0;
-        uint64_t bytes = 0;
-        while (b1 < nb && (b1 == b0 || bytes + blocks[b1].isize <= chunk_cap)) bytes += blocks[b1++].isize;
-        return b1;
-    };
     int pass = 0;
     auto start_prefetch = [&](size_t b0, int which) {
         pf.B0 = b0;
-        pf.B1 = chunk_end(b0);
-        pf.active = true;
-        pf.th = std::thread([&, which] {
+        pf.B1 = view_end(chunk_end(b0));
+        auto body = [&, which] {
             (void)hipSetDevice(ctx->device);
-            pf.rc = copy_deflate_data(f, blocks.data() + pf.B0, pf.B1 - pf.B0, d_comp2[which], pf.cs, threads, batch_bytes, pf.half,
+            pf.rc = copy_deflate_data(S, f, blocks.data() + pf.B0, pf.B1 - pf.B0, d_comp2[which], pf.cs, threads, batch_bytes, pf.half,
                                       pf.used, pf.in_off, pf.t_host, pf.t_wait);
             if (pf.rc == 0) pf.rc = (int)hipStreamSynchronize(pf.cs);
-        });
+        };
+        // no thread to be had (std::system_error must not cross the C ABI): copy on this thread
+        try { pf.th = std::thread(body); } catch (const std::system_error &) { body(); }
     };
-    if (gpu_inflate) start_prefetch(0, 0);
+    if (gpu_inflate) start_prefetch(Bbeg, 0);
 
     // a failure from here on must drain the stream before the buffers go away
-    auto decline = [&]() { (void)hipStreamSynchronize(st); return kNeedsCpuPath; };
+    auto decline = [&]() { pf.join(); (void)hipStreamSynchronize(st); return kNeedsCpuPath; };
 #define DD_TRY(expr)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
+            pf.join();                                                                             \
             (void)hipStreamSynchronize(st);                                                        \
             return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,              \
                         "HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
         }                                                                                          \
     } while (0)
 
-    std::vector<std::unique_ptr<Piece>> pieces;
-    int64_t n_reads = 0;
     int32_t last_rid = -1, last_pos = -1;
     uint64_t tail = 0;                         // bytes carried in front of d_data
     int half = 0;
     bool used[2] = {false, false};
-    double t_inflate = 0, t_wait = 0, t_gpu = 0;
     bool first_chunk = true;
-    // per-chunk scratch, sized for the largest chunk
-    size_t max_seg = 0;
-    {
-        size_t b = 0;
-        while (b < nb) {
-            size_t e = b;
-            uint64_t bytes = 0;
-            while (e < nb && (e == b || bytes + blocks[e].isize <= chunk_cap)) bytes += blocks[e++].isize;
-            max_seg = std::max(max_seg, e - b + 2);
-            b = e;
-        }
-    }
+    bool have_chain = first_share;             // is the position of the record chain known?
     uint64_t *d_seg_start = nullptr;
     uint16_t *d_off16 = nullptr;
     SegSummary *d_sum = nullptr;
     uint32_t *d_seg_n = nullptr;
     int64_t *d_seg_base = nullptr;
     int32_t *d_seg_prev = nullptr;
-    HIP_TRY(tmp.alloc(&d_seg_start, max_seg + 1));
-    HIP_TRY(tmp.alloc(&d_off16, max_seg * kMaxRecPerSeg));
-    HIP_TRY(tmp.alloc(&d_sum, max_seg));
-    HIP_TRY(tmp.alloc(&d_seg_n, max_seg));
-    HIP_TRY(tmp.alloc(&d_seg_base, max_seg));
-    HIP_TRY(tmp.alloc(&d_seg_prev, max_seg));
+    DD_TRY(tmp.alloc(&d_seg_start, max_seg + 1));
+    DD_TRY(tmp.alloc(&d_off16, max_seg * kMaxRecPerSeg));
+    DD_TRY(tmp.alloc(&d_sum, max_seg));
+    DD_TRY(tmp.alloc(&d_seg_n, max_seg));
+    DD_TRY(tmp.alloc(&d_seg_base, max_seg));
+    DD_TRY(tmp.alloc(&d_seg_prev, max_seg));
     std::vector<uint64_t> seg_start;
     std::vector<SegSummary> sum;
     std::vector<uint32_t> seg_n;
     std::vector<int64_t> seg_base;
     std::vector<int32_t> seg_prev;
 
-    for (size_t B0 = 0; B0 < nb;) {
-        size_t B1 = B0;
-        uint64_t chunk_bytes = 0;
-        while (B1 < nb && (B1 == B0 || chunk_bytes + blocks[B1].isize <= chunk_cap)) chunk_bytes += blocks[B1++].isize;
-        const bool is_last = B1 == nb;
+    for (size_t B0 = Bbeg; B0 < Bend;) {
+        const size_t B1 = chunk_end(B0), Bv = view_end(B1);
+        const uint64_t own_bytes = uoff[B1] - uoff[B0];        // the blocks whose records this pass walks
+        const uint64_t seen_bytes = uoff[Bv] - uoff[B0];       // ... and what it can read (overlap included)
+        const bool share_end = B1 == Bend;
+        const bool stream_end = Bv == nb;                      // the view ends where the stream ends
 
         int64_t header_end = -1;
         std::vector<uint8_t> head;             // the head of the stream, only if the header spans batches
         if (gpu_inflate) {
             // ---- the compressed bytes travel to HBM as they are; k_inflate turns them into the view ----
-            if (first_chunk) {
+            if (first_chunk && first_share) {
                 // the header is read on the host: inflate leading blocks until it is complete
                 for (size_t k = B0; k < B1 && header_end == -1 && head.size() < (64u << 20); ++k) {
                     const size_t at = head.size();
@@ -798,17 +805,18 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             // this pass's compressed bytes (requested before the previous pass was worked on)
             const double tj = now_s();
             pf.join();
-            t_wait += now_s() - tj;
-            if (pf.rc || pf.B0 != B0 || pf.B1 != B1) DD_TRY(pf.rc ? (hipError_t)pf.rc : hipErrorUnknown);
+            R.t_wait += now_s() - tj;
+            if (pf.rc) DD_TRY((hipError_t)pf.rc);
+            if (pf.B0 != B0 || pf.B1 != Bv) return decline();
             in_off.swap(pf.in_off);
-            t_inflate += pf.t_host;
-            t_wait += pf.t_wait;
+            R.t_inflate += pf.t_host;
+            R.t_wait += pf.t_wait;
             pf.t_host = pf.t_wait = 0;
             const uint8_t *d_comp_now = d_comp2[pass & 1];
-            if (B1 < nb) start_prefetch(B1, (pass + 1) & 1);
+            if (B1 < Bend) start_prefetch(B1, (pass + 1) & 1);
             ++pass;
-            jobs.resize(B1 - B0);
-            for (size_t k = B0; k < B1; ++k)
+            jobs.resize(Bv - B0);
+            for (size_t k = B0; k < Bv; ++k)
                 jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
             const double t0 = now_s();
             DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
@@ -816,62 +824,63 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             int status = 0;
             DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
             DD_TRY(hipStreamSynchronize(st));
-            t_inflate += now_s() - t0;
-            if (getenv("BSIG_DIAG_INFLATE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d) at %.3f s\n", (now_s() - t0) * 1e3, jobs.size(), status, now_s() - t_begin);
+            R.t_inflate += now_s() - t0;
+            if (getenv("BSIG_DIAG_INFLATE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d)\n", (now_s() - t0) * 1e3, jobs.size(), status);
             if (status) return decline();      // a damaged block: the CPU path reports it
         } else {
         // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
-        for (size_t b0 = B0; b0 < B1;) {
+        for (size_t b0 = B0; b0 < Bv;) {
             size_t b1 = b0;
             uint64_t bytes = 0;
-            while (b1 < B1 && bytes + blocks[b1].isize <= batch_bytes) bytes += blocks[b1++].isize;
+            while (b1 < Bv && bytes + blocks[b1].isize <= batch_bytes) bytes += blocks[b1++].isize;
             if (b1 == b0) return decline();    // cannot happen: a block is <= 64 KiB
             double t0 = now_s();
-            if (used[half]) DD_TRY(hipEventSynchronize(g_staging.ev[half]));
-            t_wait += now_s() - t0;
+            if (used[half]) DD_TRY(hipEventSynchronize(S.ev[half]));
+            R.t_wait += now_s() - t0;
             t0 = now_s();
-            rc = f.inflate(b0, b1, g_staging.buf[half], threads);
+            rc = f.inflate(b0, b1, S.buf[half], threads);
             if (rc) return decline();          // the CPU path reports the error
-            t_inflate += now_s() - t0;
-            if (first_chunk && header_end < 0) {
+            R.t_inflate += now_s() - t0;
+            if (first_chunk && first_share && header_end < 0) {
                 // where the records start: read off the head of the stream (it spans several batches
                 // only in the small-batch test mode; only then is anything copied)
-                if (head.empty()) header_end = bam_header_bytes(g_staging.buf[half], bytes);
+                if (head.empty()) header_end = bam_header_bytes(S.buf[half], bytes);
                 if (header_end == -1) {
-                    head.insert(head.end(), g_staging.buf[half], g_staging.buf[half] + bytes);
+                    head.insert(head.end(), S.buf[half], S.buf[half] + bytes);
                     header_end = bam_header_bytes(head.data(), head.size());
                 }
                 if (header_end == -2) return decline();
                 if (header_end >= 0) std::vector<uint8_t>().swap(head);
             }
-            if (bytes) DD_TRY(hipMemcpyAsync(d_data + (uoff[b0] - uoff[B0]), g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
-            DD_TRY(hipEventRecord(g_staging.ev[half], st));
+            if (bytes) DD_TRY(hipMemcpyAsync(d_data + (uoff[b0] - uoff[B0]), S.buf[half], bytes, hipMemcpyHostToDevice, st));
+            DD_TRY(hipEventRecord(S.ev[half], st));
             used[half] = true;
             half ^= 1;
             b0 = b1;
         }
         }
-        if (first_chunk && header_end < 0) return decline();      // header larger than a chunk
+        if (first_chunk && first_share && header_end < 0) return decline();      // header larger than a chunk
 
         // ---- segments of the view [tail | chunk]: from where the chain stands, then one per block --
         const double t0 = now_s();
         const uint8_t *d_stream = d_data - tail;
-        const uint64_t view = tail + chunk_bytes;
-        const uint64_t o0 = first_chunk ? (uint64_t)header_end : 0;
+        const uint64_t own = tail + own_bytes;                 // records that start before this belong to the pass
+        const uint64_t view = tail + seen_bytes;
+        const uint64_t o0 = (first_chunk && first_share) ? (uint64_t)header_end : 0;
         seg_start.clear();
         seg_start.push_back(o0);
         for (size_t k = B0; k <= B1; ++k) {
             const uint64_t a = tail + (uoff[k] - uoff[B0]);
             if (a > o0) seg_start.push_back(a);
         }
-        if (seg_start.back() != view) seg_start.push_back(view);
+        if (seg_start.back() != own) seg_start.push_back(own);
         const int64_t n_seg = (int64_t)seg_start.size() - 1;
         if ((size_t)n_seg > max_seg) return decline();
         sum.assign((size_t)std::max<int64_t>(n_seg, 1), SegSummary{});
         if (n_seg > 0) {
             DD_TRY(hipMemcpyAsync(d_seg_start, seg_start.data(), seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, st, d_stream, view, d_seg_start,
-                               n_seg, n_ref, d_ref_len, is_last ? 1 : 0, nullptr, d_off16, d_sum);
+                               n_seg, n_ref, d_ref_len, stream_end ? 1 : 0, nullptr, d_off16, d_sum);
             DD_TRY(hipGetLastError());
             DD_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
         }
@@ -888,12 +897,21 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         bool cut = false;
         for (int64_t s = 0; s < n_seg; ++s) {
             const uint64_t a = seg_start[(size_t)s], b = seg_start[(size_t)s + 1];
-            if (a == b || o >= b) continue;         // empty block, or the current record runs through all of it
             const SegSummary &g = sum[(size_t)s];
+            if (!have_chain) {
+                // a share in the middle of the file: the first record start a lane proposes is where this
+                // share's chain begins (proven later, against the end of the previous share's chain)
+                if (a == b || g.first >= b) continue;
+                o = g.first;
+                have_chain = true;
+                R.chain_first = uoff[B0] + o - tail;
+            }
+            if (a == b || o >= b) continue;         // empty block, or the current record runs through all of it
             if (g.first != o) return decline();     // a <= o < b: the lane must have chosen exactly this start
             if (g.flags & ~kFlagIncomplete) return decline();          // damaged or unsorted
             if (g.n_placed) {
                 if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return decline();
+                if (R.n_reads + n_chunk == 0) { R.first_rid = g.first_rid; R.first_pos = g.first_pos; }
                 seg_n[(size_t)s] = g.n_placed;
                 seg_base[(size_t)s] = n_chunk;
                 seg_prev[(size_t)s] = last_rid;
@@ -903,22 +921,31 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
             o = g.end;
             if (g.flags & kFlagIncomplete) { cut = true; break; }      // the rest of the view is that record's
         }
-        if (is_last ? (cut || o != view) : (!cut && o < view)) return decline();   // truncated / chain lost
-        const uint64_t new_tail = view - std::min(o, view);
-        if (new_tail > carry_cap || (new_tail && o < tail)) return decline();     // a record larger than the carry
+        uint64_t new_tail = 0;
+        if (share_end) {
+            // the chain must have passed the share's last own byte without being cut off: its last record
+            // lies inside what the pass could see (the end of the stream, or the overlap blocks)
+            if (!have_chain || cut || o < own || o > view) return decline();
+            if (stream_end && last_share && o != view) return decline();          // truncated file
+            R.chain_end = uoff[B0] + o - tail;
+        } else {
+            if (!have_chain || (!cut && o < view)) return decline();              // chain lost
+            new_tail = view - std::min(o, view);
+            if (new_tail > carry_cap || (new_tail && o < tail)) return decline(); // a record larger than the carry
+        }
 
         // ---- this chunk's columns -------------------------------------------------------------------
         if (n_chunk > 0) {
-            pieces.emplace_back(new Piece);
-            Piece &pc = *pieces.back();
+            R.pieces.emplace_back(new Piece);
+            Piece &pc = *R.pieces.back();
             DD_TRY(pc.alloc(tmp, n_chunk));
             DD_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             DD_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
             DD_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)n_seg), dim3(kExtractThreads), 0, st, d_stream, d_seg_start, d_off16,
-                               d_seg_n, d_seg_base, d_seg_prev, pc.pos, pc.flag, pc.mapq, pc.tlen, pc.end, d_ref_first, n_reads);
+                               d_seg_n, d_seg_base, d_seg_prev, pc.pos, pc.flag, pc.mapq, pc.tlen, pc.end, R.d_ref_first, R.n_reads);
             DD_TRY(hipGetLastError());
-            n_reads += n_chunk;
+            R.n_reads += n_chunk;
         }
         // the cut-off record moves in front of the next chunk (source and destination do not overlap:
         // it starts inside this chunk's own bytes)
@@ -927,19 +954,236 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         DD_TRY(hipStreamSynchronize(st));
         tail = new_tail;
         first_chunk = false;
-        t_gpu += now_s() - t0;
+        R.t_gpu += now_s() - t0;
         B0 = B1;
     }
-    T[1] = t_inflate;
-    T[2] = t_wait;
-
 #undef DD_TRY
+    R.last_rid = last_rid; R.last_pos = last_pos;
+    return BSIG_OK;
+}
+
+// what every whole-file decode needs before any GPU is touched
+struct FileScan {
+    BgzfFile f;
+    BamHeader hdr;
+    std::vector<uint64_t> uoff;
+    bool gpu_inflate = false;
+};
+int scan_file(const std::string &path, int threads, FileScan &F)
+{
+    int rc = F.f.open(path);
+    if (rc) return rc;
+    const std::vector<BgzfBlock> &blocks = F.f.blocks();
+    if (blocks.empty()) return kNeedsCpuPath;
+    const size_t nb = blocks.size();
+    F.uoff.assign(nb + 1, 0);
+    uint64_t comp_total = 0;
+    for (size_t k = 0; k < nb; ++k) {
+        if (blocks[k].isize > 65536u) return kNeedsCpuPath;
+        F.uoff[k + 1] = F.uoff[k] + blocks[k].isize;
+        comp_total += blocks[k].dlen;
+    }
+    if (F.uoff[nb] < 12) return kNeedsCpuPath;
+    rc = bam_read_header(path, F.hdr);
+    if (rc) return kNeedsCpuPath;                      // the CPU path reports what is wrong
+    // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
+    const char *eng = getenv("BAMSIGNALS_INFLATE");
+    F.gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(nb, comp_total, threads);
+    return BSIG_OK;
+}
+
+}  // namespace
+
+// Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
+int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, bsig_reads **out)
+{
+    double *T = g_dev_decode_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
+    *out = nullptr;
+    FileScan F;
+    int rc = scan_file(path, threads, F);
+    if (rc) return rc;
+    T[0] = now_s() - t_begin;
+    ShareOut S;
+    rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, F.f.blocks().size(), threads, F.gpu_inflate, S);
+    if (rc) return rc;
+    T[1] = S.t_inflate;
+    T[2] = S.t_wait;
     // ---- join the pieces, first read of every reference, resident layout ---------------------------
     double t_join = 0, t_layout = 0;
-    rc = finish_reads(ctx, st, tmp, pieces, n_reads, hdr, d_ref_first, t_join, t_layout, out);
+    rc = finish_reads(ctx, ctx->stream, *S.tmp, S.pieces, S.n_reads, F.hdr, S.d_ref_first, t_join, t_layout, out);
     if (rc) return rc;
-    T[3] = t_gpu + t_join;
+    T[3] = S.t_gpu + t_join;
     T[5] = t_layout;
+    T[4] = now_s() - t_begin;
+    return BSIG_OK;
+}
+
+
+// Whole BAM -> resident reads on EVERY listed GPU (the single-process multi-GPU route): GPU g
+// inflates and parses share g of the BGZF blocks (the reference's wall time is this stage,
+// bam_itr_next, ref: src/bamsignals.cpp:271), the column shares are all-gathered over xGMI
+// (collect.h), and every GPU builds its own resident layout from the full columns.
+// Returns BSIG_OK, kNeedsCpuPath (the shares could not be proven to tile the stream, or the file
+// needs the CPU path: the caller decodes on one GPU and clones), or an error.
+int reads_from_bam_sharded(const std::vector<bsig_ctx *> &ctxs, const std::string &path, int threads,
+                           std::vector<bsig_reads *> &out, const char **transport)
+{
+    double *T = g_dev_decode_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
+    const size_t n = ctxs.size();
+    out.assign(n, nullptr);
+    if (n == 0) return fail(BSIG_ERR_ARG, "no GPU given");
+    FileScan F;
+    int rc = scan_file(path, threads, F);
+    if (rc) return rc;
+    const std::vector<BgzfBlock> &blocks = F.f.blocks();
+    const size_t nb = blocks.size();
+    const uint64_t total = F.uoff[nb];
+    size_t min_blocks = 16;                                // per share: below ~1 MB a share is not worth a GPU
+    if (const char *e = getenv("BAMSIGNALS_SHARD_MIN_BLOCKS")) min_blocks = (size_t)std::max(1l, atol(e));
+    if (nb < min_blocks * n) return kNeedsCpuPath;
+    std::vector<size_t> cut(n + 1, nb);
+    cut[0] = 0;
+    for (size_t g = 1; g < n; ++g) {
+        const uint64_t want = total / n * g;
+        cut[g] = (size_t)(std::lower_bound(F.uoff.begin(), F.uoff.end(), want) - F.uoff.begin());
+        cut[g] = std::min(std::max(cut[g], cut[g - 1] + 1), nb - (n - g));
+    }
+    T[0] = now_s() - t_begin;
+
+    // ---- every GPU decodes its share (one host thread each) ---------------------------------------
+    std::vector<ShareOut> S(n);
+    std::vector<int> rcs(n, BSIG_OK);
+    std::vector<std::string> msgs(n);
+    const int thr_each = std::max(1, decode_threads(threads) / (int)n);
+    auto run_all = [&](const std::function<int(size_t)> &body) {
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < n; ++g) {
+            auto one = [&, g] {
+                rcs[g] = body(g);
+                if (rcs[g]) msgs[g] = g_last_error;
+            };
+            try { th.emplace_back(one); } catch (const std::system_error &) { one(); }
+        }
+        for (auto &t : th) t.join();
+        for (size_t g = 0; g < n; ++g)
+            if (rcs[g] < 0) return fail(rcs[g], "%s", msgs[g].c_str());
+        for (size_t g = 0; g < n; ++g)
+            if (rcs[g]) return rcs[g];
+        return (int)BSIG_OK;
+    };
+    rc = run_all([&](size_t g) { return decode_share(ctxs[g], F.f, F.hdr, F.uoff, cut[g], cut[g + 1], thr_each, F.gpu_inflate, S[g]); });
+    if (rc) return rc;
+    // the shares' chains must tile the stream, and the reads must stay in coordinate order across them
+    int32_t prid = -1, ppos = -1;
+    int64_t n_reads = 0;
+    std::vector<int64_t> base(n + 1, 0);
+    for (size_t g = 0; g < n; ++g) {
+        if (g && S[g - 1].chain_end != S[g].chain_first) return kNeedsCpuPath;
+        if (S[g].n_reads) {
+            if (S[g].first_rid < prid || (S[g].first_rid == prid && S[g].first_pos < ppos)) return kNeedsCpuPath;
+            prid = S[g].last_rid; ppos = S[g].last_pos;
+        }
+        base[g] = n_reads;
+        n_reads += S[g].n_reads;
+    }
+    base[n] = n_reads;
+    for (size_t g = 0; g < n; ++g) { T[1] = std::max(T[1], S[g].t_inflate); T[2] = std::max(T[2], S[g].t_wait); T[3] = std::max(T[3], S[g].t_gpu); }
+    const double t_x = now_s();
+
+    // ---- first read of every reference (share-local indices -> global) ----------------------------
+    const int32_t n_ref = (int32_t)F.hdr.names.size();
+    std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
+    {
+        std::vector<long long> rf((size_t)n_ref + 1);
+        std::vector<long long> first((size_t)n_ref + 1, -1);
+        for (size_t g = 0; g < n; ++g) {
+            HIP_TRY(hipSetDevice(ctxs[g]->device));
+            HIP_TRY(hipMemcpyAsync(rf.data(), S[g].d_ref_first, rf.size() * sizeof(long long), hipMemcpyDeviceToHost, ctxs[g]->stream));
+            HIP_TRY(hipStreamSynchronize(ctxs[g]->stream));
+            // a share marks every reference up to its first read's as starting at its index 0: the
+            // earliest share that knows a reference is the one that holds its first read
+            for (int32_t q = 0; q <= n_ref; ++q)
+                if (first[(size_t)q] < 0 && rf[(size_t)q] >= 0) first[(size_t)q] = base[g] + rf[(size_t)q];
+        }
+        ref_off[(size_t)n_ref] = n_reads;
+        for (int32_t r = n_ref - 1; r >= 0; --r) ref_off[(size_t)r] = first[(size_t)r] >= 0 ? first[(size_t)r] : ref_off[(size_t)r + 1];
+        ref_off[0] = 0;
+    }
+
+    // ---- full columns on every GPU: own pieces in place, the other shares over xGMI ---------------
+    std::vector<Piece> whole(n);
+    if (n_reads > 0) {
+        rc = run_all([&](size_t k) -> int {
+            HIP_TRY(hipSetDevice(ctxs[k]->device));
+            hipStream_t st = ctxs[k]->stream;
+            HIP_TRY(whole[k].alloc(*S[k].tmp, n_reads));
+            int64_t at = base[k];
+            for (auto &pp : S[k].pieces) {
+                const Piece &pc = *pp;
+                HIP_TRY(hipMemcpyAsync(whole[k].pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st));
+                at += pc.n;
+            }
+            HIP_TRY(hipStreamSynchronize(st));
+            return BSIG_OK;
+        });
+        if (rc) return rc;
+        Exchange *ex = nullptr;
+        rc = exchange_open(ctxs, &ex, transport);
+        if (rc) return rc;
+        std::vector<uint8_t *> bufs(n);
+        std::vector<size_t> off(n), len(n);
+        auto gather_col = [&](size_t elt, const std::function<uint8_t *(Piece &)> &col) {
+            for (size_t g = 0; g < n; ++g) {
+                bufs[g] = col(whole[g]);
+                off[g] = (size_t)base[g] * elt;
+                len[g] = (size_t)S[g].n_reads * elt;
+            }
+            return exchange_allgather(ex, bufs, off, len);
+        };
+        rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.pos; });
+        if (!rc) rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.end; });
+        if (!rc) rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.tlen; });
+        if (!rc) rc = gather_col(2, [](Piece &p) { return (uint8_t *)p.flag; });
+        if (!rc) rc = gather_col(1, [](Piece &p) { return (uint8_t *)p.mapq; });
+        for (size_t k = 0; k < n; ++k) {
+            (void)hipSetDevice(ctxs[k]->device);
+            const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
+            if (e != hipSuccess && !rc) rc = fail(BSIG_ERR_DEVICE, "exchanging the decoded columns failed on GPU %d: %s", ctxs[k]->device, hipGetErrorString(e));
+        }
+        if (rc) return rc;
+    } else if (transport) {
+        *transport = "none";
+    }
+    T[3] += now_s() - t_x;
+
+    // ---- every GPU lays the reads out ---------------------------------------------------------------
+    const double t_lay = now_s();
+    std::vector<bsig_reads *> made(n, nullptr);
+    rc = run_all([&](size_t k) -> int {
+        bsig_reads *R = new bsig_reads;
+        R->ctx = ctxs[k];
+        const int r = n_reads > 0 ? layout_from_device(ctxs[k], R, n_reads, n_ref, F.hdr.lens.data(), ref_off.data(), whole[k].pos,
+                                                       whole[k].end, whole[k].flag, whole[k].mapq, whole[k].tlen)
+                                  : layout_from_device(ctxs[k], R, 0, n_ref, F.hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr,
+                                                       nullptr, nullptr);
+        if (r) { delete R; return r; }
+        made[k] = R;
+        return BSIG_OK;
+    });
+    if (rc) {
+        for (bsig_reads *R : made) delete R;
+        return rc;
+    }
+    out = made;
+    T[5] = now_s() - t_lay;
     T[4] = now_s() - t_begin;
     return BSIG_OK;
 }
@@ -1105,8 +1349,9 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         }
     }
 
-    std::lock_guard<std::mutex> lock(g_staging.mu);
-    rc = g_staging.ensure(batch_bytes);
+    Staging &S = staging_for(ctx->device);
+    std::lock_guard<std::mutex> lock(S.mu);
+    rc = S.ensure(batch_bytes);
     if (rc) return bail(rc);
     auto decline = [&]() { return bail(kNeedsCpuPath); };
 
@@ -1145,7 +1390,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
             uint64_t comp_bytes = 0;
             for (const BgzfBlock &b : list) comp_bytes += b.dlen;
             if (comp_bytes > max_group + 64 * (uint64_t)max_seg || list.size() > max_seg) return decline();
-            DR_TRY((hipError_t)copy_deflate_data(f, list.data(), list.size(), d_comp, st, threads, batch_bytes, half, used, in_off,
+            DR_TRY((hipError_t)copy_deflate_data(S, f, list.data(), list.size(), d_comp, st, threads, batch_bytes, half, used, in_off,
                                                  t_inflate, t_wait));
             jobs.resize(list.size());
             uint64_t at = 0;
@@ -1169,14 +1414,14 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
             while (b1 < list.size() && bytes + list[b1].isize <= batch_bytes) bytes += list[b1++].isize;
             if (b1 == b0) return decline();
             double t0 = now_s();
-            if (used[half]) DR_TRY(hipEventSynchronize(g_staging.ev[half]));
+            if (used[half]) DR_TRY(hipEventSynchronize(S.ev[half]));
             t_wait += now_s() - t0;
             t0 = now_s();
-            rc = f.inflate_list(list.data() + b0, b1 - b0, g_staging.buf[half], threads);
+            rc = f.inflate_list(list.data() + b0, b1 - b0, S.buf[half], threads);
             if (rc) return decline();
             t_inflate += now_s() - t0;
-            if (bytes) DR_TRY(hipMemcpyAsync(d_view + copied, g_staging.buf[half], bytes, hipMemcpyHostToDevice, st));
-            DR_TRY(hipEventRecord(g_staging.ev[half], st));
+            if (bytes) DR_TRY(hipMemcpyAsync(d_view + copied, S.buf[half], bytes, hipMemcpyHostToDevice, st));
+            DR_TRY(hipEventRecord(S.ev[half], st));
             used[half] = true;
             half ^= 1;
             copied += bytes;
@@ -1300,6 +1545,39 @@ int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_read
     if (rc) return rc;
     for (int k = 0; k < 6; ++k) g_dev_decode_timing[k] = 0;
     return bsig_reads_upload(ctx, &cols, reads);
+}
+
+int bsig_reads_from_bam_multi(bsig_ctx *const *ctxs, int32_t n, bsig_bam *bam, int32_t threads, bsig_reads **reads,
+                              int32_t *sharded)
+{
+    if (!ctxs || n <= 0 || !bam || !reads) return fail(BSIG_ERR_ARG, "bad argument to bsig_reads_from_bam_multi");
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k]) return fail(BSIG_ERR_ARG, "context %d is NULL", k);
+        reads[k] = nullptr;
+    }
+    if (sharded) *sharded = 0;
+    const char *mode = getenv("BAMSIGNALS_DEVICE_DECODE");
+    const char *sh = getenv("BAMSIGNALS_SHARDED_DECODE");
+    int rc = bsig::kNeedsCpuPath;
+    if (!(mode && !strcmp(mode, "0")) && !(sh && !strcmp(sh, "0"))) {
+        std::vector<bsig_ctx *> cv(ctxs, ctxs + n);
+        std::vector<bsig_reads *> out;
+        const char *transport = "";
+        rc = bsig::reads_from_bam_sharded(cv, bsig_bam_path(bam), threads, out, &transport);
+        if (rc == BSIG_OK) {
+            for (int k = 0; k < n; ++k) reads[k] = out[(size_t)k];
+            if (sharded) *sharded = 1;
+            return BSIG_OK;
+        }
+    }
+    if (rc != bsig::kNeedsCpuPath) return rc;
+    if (sh && !strcmp(sh, "require"))                                // testing: no silent change of path
+        return fail(BSIG_ERR_FORMAT, "%s cannot be decoded in shares (BAMSIGNALS_SHARDED_DECODE=require)", bsig_bam_path(bam));
+    rc = bsig_reads_from_bam(ctxs[0], bam, threads, &reads[0]);
+    for (int k = 1; k < n && rc == BSIG_OK; ++k) rc = bsig_reads_clone(reads[0], ctxs[k], &reads[k]);
+    if (rc)
+        for (int k = 0; k < n; ++k) { if (reads[k]) bsig_reads_free(reads[k]); reads[k] = nullptr; }
+    return rc;
 }
 
 int bsig_reads_from_bam_regions(bsig_ctx *ctx, bsig_bam *bam, int64_t n_regions, const int32_t *rid,

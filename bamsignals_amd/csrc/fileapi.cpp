@@ -1,22 +1,27 @@
 // File-level half of the C ABI: BAM handles, the drop-in bsig_pileup_core / bsig_coverage_core,
 // the BAM writers.  Pure host code; the compute goes through bsig_reads_upload / bsig_plan_*.
+#include <hip/hip_runtime.h>
 #include <sys/stat.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <list>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
 #include "../../include/bamsignals_abi.h"
 #include "bamio.h"
+#include "collect.h"
 #include "host_util.h"
+#include "runtime_internal.h"
 
-namespace bsig { void release_decode_scratch(); }
 using bsig::fail;
 
 struct bsig_bam {
@@ -32,6 +37,8 @@ namespace {
 // upload + HBM layout, plan + kernels + result download, total; [5] = 1 if the BAM was already
 // resident in HBM
 thread_local double g_call_timing[6] = {0, 0, 0, 0, 0, 0};
+// how the calling thread's last file-level call was carried out (bsig_last_call_route)
+thread_local char g_call_route[160] = "";
 inline double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -53,40 +60,46 @@ void fill_columns(const bsig_bam *b, bsig_columns *c)
     c->cigar = b->cols.cigar.data();
 }
 
-// one BAM decoded to HBM, kept between file-level calls (the reference re-opens file and index on
-// every call, src/bamsignals.cpp:449,479; here the expensive part is the decode + upload)
-struct DevSlot {
-    int device = -1;
-    bsig_ctx *ctx = nullptr;
-    bsig_reads *reads = nullptr;    // the cached whole-file reads of `key`
+// ---------------------------------------------------------------------------------------------
+// What the file-level calls keep between calls (the reference re-opens file and index on every
+// call, src/bamsignals.cpp:449,479; here the expensive part is the decode to HBM):
+//   * the GPUs in use: one context (stream) per listed device;
+//   * opened BAMs: header + parsed BAI of the last few files;
+//   * resident BAMs: whole files decoded to HBM (on every listed GPU), least recently used first
+//     out once their bytes exceed BAMSIGNALS_CACHE_GB per GPU (default 96).
+// A file is identified by path + size + mtime (ns) of the BAM and of its index: a rewritten file is
+// decoded again.  The lock is held for look-ups and updates only, never across a decode or a
+// launch: calls from several host threads on resident BAMs run side by side (cold decodes take
+// turns, they use the whole GPU anyway); an entry in use is kept alive by its shared_ptr.
+// ---------------------------------------------------------------------------------------------
+struct Resident {
     std::string key;
-    void drop_reads()
-    {
-        if (reads) bsig_reads_free(reads);
-        reads = nullptr;
-        key.clear();
-    }
-    void destroy()
-    {
-        drop_reads();
-        if (ctx) bsig_ctx_destroy(ctx);
-        ctx = nullptr;
-        device = -1;
-    }
+    std::vector<bsig_reads *> reads;     // one per slot
+    int64_t bytes = 0;                   // per GPU
+    ~Resident() { for (bsig_reads *r : reads) if (r) bsig_reads_free(r); }
+};
+struct OpenBam {
+    std::string key;
+    bsig_bam *bam = nullptr;
+    ~OpenBam() { if (bam) bsig_bam_close(bam); }
+};
+struct Slots {
+    std::vector<int> devices;
+    std::vector<bsig_ctx *> ctx;
+    ~Slots() { for (bsig_ctx *c : ctx) if (c) bsig_ctx_destroy(c); }
 };
 
 struct Cache {
-    std::mutex mu;
-    std::vector<DevSlot> slots;     // one per GPU the file-level calls drive
-    // the last opened BAM (header + parsed BAI), so that repeated calls do not re-read the index
-    std::string bam_key;
-    bsig_bam *bam = nullptr;
+    std::mutex mu;                                       // guards everything below
+    std::mutex decode_mu;                                // cold decodes take turns
+    std::shared_ptr<Slots> slots;
+    std::list<std::shared_ptr<OpenBam>> bams;            // most recently used first
+    std::list<std::shared_ptr<Resident>> resident;       // most recently used first
     void clear()
     {
-        for (DevSlot &d : slots) d.drop_reads();
-        if (bam) bsig_bam_close(bam);
-        bam = nullptr;
-        bam_key.clear();
+        resident.clear();
+        bams.clear();
+        slots.reset();
     }
 };
 Cache g_cache;
@@ -97,6 +110,33 @@ std::string file_key(const std::string &path)
     if (stat(path.c_str(), &st) != 0) return std::string();
     return path + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtime) +
            "|" + std::to_string((long long)st.st_mtim.tv_nsec);
+}
+
+int64_t cache_budget_bytes()
+{
+    double gb = 96.0;
+    if (const char *e = getenv("BAMSIGNALS_CACHE_GB")) gb = std::max(0.0, atof(e));
+    return (int64_t)(gb * (double)(1ull << 30));
+}
+
+// the reads file ("sidecar") of a BAM, or "" when sidecars are off: BAMSIGNALS_SIDECAR=1 puts it next
+// to the BAM (<bam>.bsig), BAMSIGNALS_SIDECAR_DIR=<dir> into that directory
+std::string sidecar_path(const std::string &bampath)
+{
+    if (const char *d = getenv("BAMSIGNALS_SIDECAR_DIR")) {
+        if (!*d) return std::string();
+        char real[4096];
+        const std::string abs = realpath(bampath.c_str(), real) ? std::string(real) : bampath;
+        uint64_t h = 1469598103934665603ull;                       // FNV-1a of the absolute path
+        for (unsigned char ch : abs) { h ^= ch; h *= 1099511628211ull; }
+        const size_t slash = abs.find_last_of('/');
+        char hex[32];
+        snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
+        return std::string(d) + "/" + abs.substr(slash == std::string::npos ? 0 : slash + 1) + "." + hex + ".bsig";
+    }
+    if (const char *e = getenv("BAMSIGNALS_SIDECAR"))
+        if (*e && strcmp(e, "0") != 0) return bampath + ".bsig";
+    return std::string();
 }
 
 // GPUs a file-level call uses: the `device` argument if >= 0, else BAMSIGNALS_DEVICES ("0,1,2,3":
@@ -118,6 +158,165 @@ std::vector<int> pick_devices(int device)
     return d;
 }
 
+bool env_is(const char *name, const char *value)
+{
+    const char *e = getenv(name);
+    return e && !strcmp(e, value);
+}
+
+// body(k) for every slot on its own host thread (one thread per GPU); the first failure wins and its
+// message becomes the caller's bsig_last_error()
+int for_each_slot(size_t n, const std::function<int(size_t)> &body)
+{
+    std::vector<int> rcs(n, BSIG_OK);
+    std::vector<std::string> msgs(n);
+    auto one = [&](size_t k) {
+        rcs[k] = body(k);
+        if (rcs[k]) msgs[k] = bsig_last_error();
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < n; ++k) {
+        try { th.emplace_back(one, k); } catch (const std::system_error &) { one(k); }
+    }
+    one(0);
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < n; ++k)
+        if (rcs[k]) return fail(rcs[k], "%s", msgs[k].c_str());
+    return BSIG_OK;
+}
+
+// ---- several GPUs: ranges are independent (each owns its output, ref: src/bamsignals.cpp:164,181,186)
+// The (rid, loc)-sorted ranges (ref: :222-226,246) are dealt round-robin to the GPUs; every GPU plans
+// and runs its shard on its own stream, driven by its own host thread.  The shards then
+//   "xgmi" (default): travel to the first GPU over xGMI (RCCL grouped send/recv, or peer copies:
+//           collect.h), are put into the caller's range order there by one kernel, and leave for the
+//           host in ONE copy (no host-side reassembly);
+//   "pcie": are pulled over each GPU's own PCIe link into page-locked buffers and put in place by host
+//           threads (bsig_scatter_segments).
+int run_on_slots(const Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, const int32_t *rid, const int32_t *loc,
+                 const int32_t *width, const int32_t *strand, const bsig_params &prm, int32_t *out, const int64_t *off,
+                 const char **gather_name)
+{
+    const size_t nd = sl.ctx.size();
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        if (rid[a] != rid[b]) return rid[a] < rid[b];
+        return loc[a] < loc[b];
+    });
+    struct Shard {
+        std::vector<int64_t> which;
+        std::vector<int32_t> rid, loc, len, strand;
+        bsig_plan *plan = nullptr;
+        int32_t *host = nullptr;
+        int32_t *dev = nullptr;
+        int64_t cells = 0;
+    };
+    std::vector<Shard> sh(nd);
+    for (int64_t k = 0; k < n; ++k) {
+        Shard &S = sh[(size_t)(k % (int64_t)nd)];
+        const int64_t i = order[(size_t)k];
+        S.which.push_back(i);
+        S.rid.push_back(rid[i]); S.loc.push_back(loc[i]);
+        S.len.push_back(width[i]); S.strand.push_back(strand[i]);
+    }
+    const bool pcie = env_is("BAMSIGNALS_GATHER", "pcie");
+    *gather_name = pcie ? "pcie" : "xgmi";
+    std::vector<void *> dev_tmp;                       // device buffers of the xgmi route (first GPU)
+    auto cleanup = [&]() {
+        for (size_t k = 0; k < nd; ++k) {
+            Shard &S = sh[k];
+            if (S.plan) bsig_plan_free(S.plan);
+            if (S.host) bsig_host_free(S.host);
+            if (S.dev) { (void)hipSetDevice(sl.devices[k]); (void)hipFree(S.dev); }
+        }
+        if (!dev_tmp.empty()) (void)hipSetDevice(sl.devices[0]);
+        for (void *p : dev_tmp) (void)hipFree(p);
+    };
+    // plan + launch, one host thread per GPU
+    int rc = for_each_slot(nd, [&](size_t k) -> int {
+        Shard &S = sh[k];
+        int r = bsig_plan_create(sl.ctx[k], reads[k], (int64_t)S.which.size(), S.rid.data(), S.loc.data(), S.len.data(),
+                                 S.strand.data(), &prm, &S.plan);
+        if (r) return r;
+        S.cells = bsig_plan_cells(S.plan);
+        if (pcie) {
+            r = bsig_host_alloc(S.cells * (int64_t)sizeof(int32_t), (void **)&S.host);
+            if (r) return r;
+            r = bsig_plan_run_host_async(S.plan, S.host);
+        } else {
+            HIP_TRY(hipSetDevice(sl.devices[k]));
+            HIP_TRY(hipMalloc((void **)&S.dev, (size_t)std::max<int64_t>(S.cells, 4) * sizeof(int32_t)));
+            r = bsig_plan_run(S.plan, S.dev);
+        }
+        if (r) return r;
+        return bsig_ctx_sync(sl.ctx[k]);
+    });
+    if (rc) { cleanup(); return rc; }
+    if (pcie) {
+        for (size_t k = 0; k < nd && rc == BSIG_OK; ++k)
+            rc = bsig_scatter_segments((int64_t)sh[k].which.size(), sh[k].host, bsig_plan_offsets(sh[k].plan), out, off,
+                                       sh[k].which.data());
+        cleanup();
+        return rc;
+    }
+    // ---- xgmi: gather on the first GPU, reassemble there, one download ------------------------------
+    const int64_t total = off[n];
+    std::vector<size_t> goff(nd), glen(nd);
+    std::vector<const uint8_t *> src(nd);
+    std::vector<int64_t> seg_off, seg_which;           // all shards' segments behind each other
+    seg_off.reserve((size_t)n + 1);
+    seg_which.reserve((size_t)n);
+    int64_t cells = 0;
+    for (size_t k = 0; k < nd; ++k) {
+        goff[k] = (size_t)cells * sizeof(int32_t);
+        glen[k] = (size_t)sh[k].cells * sizeof(int32_t);
+        src[k] = (const uint8_t *)sh[k].dev;
+        const int64_t *po = bsig_plan_offsets(sh[k].plan);
+        for (size_t j = 0; j < sh[k].which.size(); ++j) {
+            seg_off.push_back(cells + po[j]);
+            seg_which.push_back(sh[k].which[j]);
+        }
+        cells += sh[k].cells;
+    }
+    seg_off.push_back(cells);
+    if (cells != total) { cleanup(); return fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters"); }
+    if (total == 0) { cleanup(); return BSIG_OK; }
+    auto body = [&]() -> int {
+        HIP_TRY(hipSetDevice(sl.devices[0]));
+        hipStream_t st = (hipStream_t)bsig_ctx_stream(sl.ctx[0]);
+        int32_t *d_gather = nullptr, *d_final = nullptr;
+        int64_t *d_seg_off = nullptr, *d_which = nullptr, *d_dst_off = nullptr;
+        auto dalloc = [&](void **p, size_t bytes) { const hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16)); if (e == hipSuccess) dev_tmp.push_back(*p); return e; };
+        HIP_TRY(dalloc((void **)&d_gather, (size_t)total * sizeof(int32_t)));
+        HIP_TRY(dalloc((void **)&d_final, (size_t)total * sizeof(int32_t)));
+        HIP_TRY(dalloc((void **)&d_seg_off, seg_off.size() * sizeof(int64_t)));
+        HIP_TRY(dalloc((void **)&d_which, std::max<size_t>(seg_which.size(), 1) * sizeof(int64_t)));
+        HIP_TRY(dalloc((void **)&d_dst_off, (size_t)(n + 1) * sizeof(int64_t)));
+        HIP_TRY(hipMemcpyAsync(d_seg_off, seg_off.data(), seg_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_which, seg_which.data(), seg_which.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_dst_off, off, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        bsig::Exchange *ex = nullptr;
+        const char *transport = nullptr;
+        int r = bsig::exchange_open(sl.ctx, &ex, &transport);
+        if (r) return r;
+        *gather_name = !strcmp(transport, "rccl") ? "xgmi/rccl" : "xgmi/peer";
+        r = bsig::exchange_gather(ex, src, glen, (uint8_t *)d_gather, goff);
+        if (r) return r;
+        for (size_t k = 1; k < nd; ++k) {              // the senders' streams (RCCL queues the sends there)
+            r = bsig_ctx_sync(sl.ctx[k]);
+            if (r) return r;
+        }
+        HIP_TRY(hipSetDevice(sl.devices[0]));
+        HIP_TRY(bsig::launch_place_segments((int64_t)seg_which.size(), d_gather, d_seg_off, d_final, d_dst_off, d_which, st));
+        return bsig::download_to_host(sl.ctx[0], d_final, out, (size_t)total * sizeof(int32_t));
+    };
+    rc = body();
+    if (rc) for (size_t k = 0; k < nd; ++k) (void)bsig_ctx_sync(sl.ctx[k]);
+    cleanup();
+    return rc;
+}
+
 // the common body of pileup_core / coverage_core
 int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
                const char *const *levels, const int32_t *start, const int32_t *width,
@@ -127,24 +326,41 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (!bampath) return fail(BSIG_ERR_ARG, "bampath is NULL");
     if (n < 0 || (n > 0 && (!seq_code || !start || !width || !strand || !levels)))
         return fail(BSIG_ERR_ARG, "range arrays missing");
+    if (!off) return fail(BSIG_ERR_ARG, "offsets missing");
     double *T = g_call_timing;
     for (int k = 0; k < 6; ++k) T[k] = 0;
+    g_call_route[0] = 0;
     const double t_begin = now_s();
-    std::lock_guard<std::mutex> lock(g_cache.mu);
     // ref: Bamfile ctor :200-214 opens file + index on every call; here an unchanged file (same
     // size and mtime of the BAM and of its index) reuses the parsed header and BAI
     const std::string key = file_key(bampath);
     const std::string bkey = key.empty() ? std::string() : key + "#" + file_key(std::string(bampath) + ".bai");
     int rc = BSIG_OK;
-    if (bkey.empty() || !g_cache.bam || g_cache.bam_key != bkey) {
+    std::shared_ptr<OpenBam> ob;
+    if (!bkey.empty()) {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        for (auto it = g_cache.bams.begin(); it != g_cache.bams.end(); ++it)
+            if ((*it)->key == bkey) {
+                ob = *it;
+                g_cache.bams.erase(it);
+                g_cache.bams.push_front(ob);
+                break;
+            }
+    }
+    if (!ob) {
         bsig_bam *fresh = nullptr;
         rc = bsig_bam_open(bampath, &fresh);
         if (rc) return rc;
-        if (g_cache.bam) bsig_bam_close(g_cache.bam);
-        g_cache.bam = fresh;
-        g_cache.bam_key = bkey;
+        ob = std::make_shared<OpenBam>();
+        ob->key = bkey;
+        ob->bam = fresh;
+        if (!bkey.empty()) {
+            std::lock_guard<std::mutex> lock(g_cache.mu);
+            g_cache.bams.push_front(ob);
+            while (g_cache.bams.size() > 16) g_cache.bams.pop_back();
+        }
     }
-    bsig_bam *bam = g_cache.bam;
+    bsig_bam *bam = ob->bam;
     T[0] = now_s() - t_begin;
 
     // seqnames -> BAM reference ids, by name (ref: parseRegions :113-120)
@@ -169,24 +385,28 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                                                  : std::llabs((long long)prm.shift) + (mid ? prm.tlen_filter[1] : 0);
     if (ext < 0) return fail(BSIG_ERR_EXT, "negative 'ext' values don't make sense");             // ref: :243
 
+    // the GPUs of this call (a changed list drops everything that lives on the old one)
     const std::vector<int> devs = pick_devices(device);
+    std::shared_ptr<Slots> slots;
     {
-        bool same = devs.size() == g_cache.slots.size();
-        for (size_t k = 0; same && k < devs.size(); ++k) same = g_cache.slots[k].device == devs[k];
-        if (!same) {
-            for (DevSlot &d : g_cache.slots) d.destroy();
-            g_cache.slots.assign(devs.size(), DevSlot());
-        }
-        for (size_t k = 0; k < devs.size(); ++k) {
-            DevSlot &d = g_cache.slots[k];
-            if (!d.ctx) {
-                rc = bsig_ctx_create(devs[k], nullptr, &d.ctx);
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        if (!g_cache.slots || g_cache.slots->devices != devs) {
+            g_cache.resident.clear();
+            g_cache.slots.reset();
+            auto fresh = std::make_shared<Slots>();
+            fresh->devices = devs;
+            for (int d : devs) {
+                bsig_ctx *c = nullptr;
+                rc = bsig_ctx_create(d, nullptr, &c);
                 if (rc) return rc;
-                d.device = devs[k];
+                fresh->ctx.push_back(c);
             }
+            g_cache.slots = fresh;
         }
+        slots = g_cache.slots;
     }
     const size_t nd = devs.size();
+    const bool many = nd > 1 || env_is("BAMSIGNALS_FORCE_SHARDED", "1");     // (=1: the multi-GPU route on one GPU, testing)
 
     // How much of the file do the ranges need?  Small queries decode only the BGZF blocks the
     // index lists (ref: one bam_itr_queryi per chunk of ranges, :252-267); large ones decode the
@@ -201,43 +421,69 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (force && !strcmp(force, "all")) whole = true;
     if (force && !strcmp(force, "regions")) whole = false;
 
-    // reads of this call on every device: cached, or decoded once and uploaded to each
-    std::vector<bsig_reads *> reads(nd, nullptr);
-    std::vector<char> owned(nd, 0);
-    bool all_cached = !key.empty();
-    for (size_t k = 0; k < nd; ++k) all_cached = all_cached && g_cache.slots[k].reads && g_cache.slots[k].key == key;
-    auto release = [&]() { for (size_t k = 0; k < nd; ++k) if (owned[k] && reads[k]) bsig_reads_free(reads[k]); };
-    if (all_cached) {
-        for (size_t k = 0; k < nd; ++k) reads[k] = g_cache.slots[k].reads;
+    // ---- the reads of this call on every GPU -------------------------------------------------------
+    std::shared_ptr<Resident> res;
+    std::string how_decoded = "resident";
+    if (!key.empty()) {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        for (auto it = g_cache.resident.begin(); it != g_cache.resident.end(); ++it)
+            if ((*it)->key == bkey) {
+                res = *it;
+                g_cache.resident.erase(it);
+                g_cache.resident.push_front(res);
+                break;
+            }
+    }
+    if (res) {
         T[5] = 1;
     } else {
+        std::lock_guard<std::mutex> dlock(g_cache.decode_mu);
         const double t_dec = now_s();
+        res = std::make_shared<Resident>();
+        res->key = bkey;
+        res->reads.assign(nd, nullptr);
+        auto clone_rest = [&]() -> int {
+            return for_each_slot(nd, [&](size_t k) -> int {
+                return k == 0 ? (int)BSIG_OK : bsig_reads_clone(res->reads[0], slots->ctx[k], &res->reads[k]);
+            });
+        };
+        double t6[6] = {0, 0, 0, 0, 0, 0};
         if (whole) {
-            // the records are taken from the uncompressed stream on the first GPU itself
-            // (devdecode.hip; falls back to the CPU decode inside the call where it must); further
-            // GPUs get device-to-device copies of the resident layout
-            rc = bsig_reads_from_bam(g_cache.slots[0].ctx, bam, 0, &reads[0]);
-            if (rc) return rc;
-            owned[0] = 1;
-            double t6[6];
-            bsig_device_decode_timing(t6);
-            T[2] = t6[5];
-            T[1] = now_s() - t_dec - T[2];
-            const double t_rep = now_s();
-            for (size_t k = 1; k < nd; ++k) {
-                rc = bsig_reads_clone(reads[0], g_cache.slots[k].ctx, &reads[k]);
-                if (rc) { release(); return rc; }
-                owned[k] = 1;
-            }
-            T[2] += now_s() - t_rep;
-            if (!key.empty())
-                for (size_t k = 0; k < nd; ++k) {
-                    DevSlot &d = g_cache.slots[k];
-                    d.drop_reads();
-                    d.reads = reads[k];
-                    d.key = key;
-                    owned[k] = 0;
+            const std::string side = key.empty() ? std::string() : sidecar_path(bampath);
+            bool loaded = false;
+            if (!side.empty()) {
+                // a second process (or a call after the BAM left the cache) skips inflate and parse
+                struct stat sb;
+                if (stat(side.c_str(), &sb) == 0) {
+                    rc = for_each_slot(nd, [&](size_t k) { return bsig_reads_load(slots->ctx[k], side.c_str(), bkey.c_str(), &res->reads[k]); });
+                    loaded = rc == BSIG_OK;
+                    if (!loaded) { for (bsig_reads *&r : res->reads) { if (r) bsig_reads_free(r); r = nullptr; } rc = BSIG_OK; }
                 }
+            }
+            if (loaded) {
+                how_decoded = "sidecar";
+            } else {
+                rc = bsig::kNeedsCpuPath;
+                if (many && !env_is("BAMSIGNALS_DEVICE_DECODE", "0") && !env_is("BAMSIGNALS_SHARDED_DECODE", "0")) {
+                    // every GPU inflates and parses its share of the BGZF blocks; the column shares are
+                    // all-gathered over xGMI (devdecode.hip: reads_from_bam_sharded)
+                    const char *transport = "";
+                    rc = bsig::reads_from_bam_sharded(slots->ctx, bampath, 0, res->reads, &transport);
+                    if (rc == BSIG_OK) how_decoded = std::string("sharded decode, columns over ") + transport;
+                    bsig_device_decode_timing(t6);
+                }
+                if (rc == bsig::kNeedsCpuPath) {
+                    // the records are taken from the uncompressed stream on the first GPU itself
+                    // (devdecode.hip; falls back to the CPU decode inside the call where it must); further
+                    // GPUs get device-to-device copies of the resident layout
+                    rc = bsig_reads_from_bam(slots->ctx[0], bam, 0, &res->reads[0]);
+                    bsig_device_decode_timing(t6);
+                    if (rc == BSIG_OK) rc = clone_rest();
+                    how_decoded = nd > 1 ? "decode on the first GPU + clones" : "decode";
+                }
+                if (rc) return rc;
+                if (!side.empty()) (void)bsig_reads_save(res->reads[0], side.c_str(), bkey.c_str());   // best effort
+            }
         } else {
             // index-driven: only the blocks the BAI lists for the ranges (ref: one bam_itr_queryi per
             // chunk of ranges, :252-267), parsed on the first GPU like the whole file; not cached
@@ -246,77 +492,39 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                 beg[(size_t)i] = (int64_t)loc[(size_t)i] - ext;
                 end[(size_t)i] = (int64_t)loc[(size_t)i] + width[i] + ext;
             }
-            rc = bsig_reads_from_bam_regions(g_cache.slots[0].ctx, bam, n, rid.data(), beg.data(), end.data(), 0, &reads[0]);
-            if (rc) return rc;
-            owned[0] = 1;
-            double t6[6];
+            rc = bsig_reads_from_bam_regions(slots->ctx[0], bam, n, rid.data(), beg.data(), end.data(), 0, &res->reads[0]);
             bsig_device_decode_timing(t6);
-            T[2] = t6[5];
-            T[1] = now_s() - t_dec - T[2];
-            const double t_rep = now_s();
-            for (size_t k = 1; k < nd; ++k) {
-                rc = bsig_reads_clone(reads[0], g_cache.slots[k].ctx, &reads[k]);
-                if (rc) { release(); return rc; }
-                owned[k] = 1;
+            if (rc == BSIG_OK) rc = clone_rest();
+            if (rc) return rc;
+            how_decoded = "index-driven decode";
+        }
+        T[2] = t6[5];
+        T[1] = now_s() - t_dec - T[2];
+        if (whole && !key.empty()) {
+            bsig_reads_info inf;
+            if (bsig_reads_get_info(res->reads[0], &inf) == BSIG_OK) res->bytes = inf.hbm_bytes;
+            std::lock_guard<std::mutex> lock(g_cache.mu);
+            if (g_cache.slots == slots) {                  // (the GPU list may have changed meanwhile)
+                g_cache.resident.push_front(res);
+                const int64_t budget = cache_budget_bytes();
+                int64_t held = 0;
+                for (auto it = g_cache.resident.begin(); it != g_cache.resident.end();) {
+                    held += (*it)->bytes;
+                    if (held > budget && it != g_cache.resident.begin()) it = g_cache.resident.erase(it);
+                    else ++it;
+                }
             }
-            T[2] += now_s() - t_rep;
         }
     }
 
     const double t_run = now_s();
-    if (nd == 1) {
-        rc = bsig_pileup_columns(g_cache.slots[0].ctx, reads[0], n, rid.data(), loc.data(), width, strand, &prm, out, off);
-    } else {
-        // ranges are independent (each owns its output, ref: :164,181,186): the (rid, loc)-sorted
-        // ranges are dealt round-robin to the GPUs, every GPU runs its shard on its own stream, the
-        // shards come back over each GPU's own PCIe link and are put back at the ranges' offsets
-        std::vector<int64_t> order((size_t)n);
-        for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-            if (rid[(size_t)a] != rid[(size_t)b]) return rid[(size_t)a] < rid[(size_t)b];
-            return loc[(size_t)a] < loc[(size_t)b];
-        });
-        struct Shard {
-            std::vector<int64_t> which;
-            std::vector<int32_t> rid, loc, len, strand;
-            bsig_plan *plan = nullptr;
-            int32_t *host = nullptr;
-        };
-        std::vector<Shard> sh(nd);
-        for (int64_t k = 0; k < n; ++k) {
-            Shard &S = sh[(size_t)(k % (int64_t)nd)];
-            const int64_t i = order[(size_t)k];
-            S.which.push_back(i);
-            S.rid.push_back(rid[(size_t)i]); S.loc.push_back(loc[(size_t)i]);
-            S.len.push_back(width[i]); S.strand.push_back(strand[i]);
-        }
-        auto cleanup = [&]() {
-            for (Shard &S : sh) {
-                if (S.plan) bsig_plan_free(S.plan);
-                if (S.host) bsig_host_free(S.host);
-            }
-        };
-        for (size_t k = 0; k < nd && rc == BSIG_OK; ++k) {
-            Shard &S = sh[k];
-            rc = bsig_plan_create(g_cache.slots[k].ctx, reads[k], (int64_t)S.which.size(), S.rid.data(), S.loc.data(),
-                                  S.len.data(), S.strand.data(), &prm, &S.plan);
-            if (rc) break;
-            rc = bsig_host_alloc(bsig_plan_cells(S.plan) * (int64_t)sizeof(int32_t), (void **)&S.host);
-            if (rc) break;
-            rc = bsig_plan_run_host_async(S.plan, S.host);        // all GPUs work concurrently
-        }
-        for (size_t k = 0; k < nd; ++k) {
-            const int rc2 = bsig_ctx_sync(g_cache.slots[k].ctx);
-            if (rc == BSIG_OK) rc = rc2;
-        }
-        for (size_t k = 0; k < nd && rc == BSIG_OK; ++k)
-            rc = bsig_scatter_segments((int64_t)sh[k].which.size(), sh[k].host, bsig_plan_offsets(sh[k].plan), out, off,
-                                       sh[k].which.data());
-        cleanup();
-    }
+    const char *gather = "";
+    if (!many) rc = bsig_pileup_columns(slots->ctx[0], res->reads[0], n, rid.data(), loc.data(), width, strand, &prm, out, off);
+    else rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, &gather);
     T[3] = now_s() - t_run;
-    release();
     T[4] = now_s() - t_begin;
+    snprintf(g_call_route, sizeof g_call_route, "%zu GPU slot(s); reads: %s; result: %s", nd, how_decoded.c_str(),
+             many ? gather : "download");
     return rc;
 }
 
@@ -510,11 +718,14 @@ int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off,
 
 void bsig_cache_clear(void)
 {
-    std::lock_guard<std::mutex> lock(g_cache.mu);
-    g_cache.clear();
-    for (DevSlot &d : g_cache.slots) d.destroy();
-    g_cache.slots.clear();
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        g_cache.clear();
+    }
+    bsig::exchange_close_all();
     bsig::release_decode_scratch();
 }
+
+const char *bsig_last_call_route(void) { return g_call_route; }
 
 }  // extern "C"

@@ -5,12 +5,18 @@
 // and fails with BSIG_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -55,7 +61,6 @@ struct bsig_plan {
     std::vector<int64_t> off;
     DevPool pool;
     BsigWorkItem *items = nullptr;
-    void *windows = nullptr;       // [n_items][BSIG_MAX_CLASSES] read windows, rewritten by every run
     int32_t *d_out = nullptr;      // device result buffer of bsig_plan_run_host, kept between calls
     // slices of heavy tiles (tiles whose read windows hold more than kHeavyReads reads): the same
     // kernels run a second time over these items with fixed windows and accumulate = 1
@@ -411,6 +416,314 @@ int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **out)
     return BSIG_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Result download into PAGEABLE host memory (an R vector, a numpy array): the runtime's own
+// pageable path stages through one buffer and is first-touch bound on the destination pages
+// (80 MB in 8 ms).  Here the result crosses PCIe by DMA into two page-locked halves and a few
+// threads move each half on into the destination while the next one is in flight.
+struct DownloadStage {
+    std::mutex mu;
+    uint8_t *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr size_t kHalf = 32u << 20;
+    int ensure()
+    {
+        for (int k = 0; k < 2; ++k) {
+            if (!buf[k]) HIP_TRY(hipHostMalloc((void **)&buf[k], kHalf, hipHostMallocDefault));
+            if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        return BSIG_OK;
+    }
+};
+// one per GPU: the events belong to the device they were created on
+DownloadStage &download_for(int device)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, DownloadStage *>> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : all)
+        if (kv.first == device) return *kv.second;
+    all.emplace_back(device, new DownloadStage);
+    return *all.back().second;
+}
+
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t *dst, size_t bytes)
+{
+    DownloadStage &g_download = download_for(device);
+    std::lock_guard<std::mutex> lock(g_download.mu);
+    HIP_TRY(hipSetDevice(device));
+    const int rc = g_download.ensure();
+    if (rc) return rc;
+    const size_t half = DownloadStage::kHalf;
+    const size_t n_chunks = (bytes + half - 1) / half;
+    int n_thr = 8;
+    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    std::atomic<int64_t> ready(-1);                 // chunks 0..ready are in their half
+    std::vector<std::atomic<int>> done(n_chunks);   // workers finished with chunk c
+    for (auto &d : done) d.store(0);
+    std::atomic<bool> abort(false);
+    auto worker = [&](int t) {
+        for (size_t c = 0; c < n_chunks; ++c) {
+            while (ready.load(std::memory_order_acquire) < (int64_t)c) {
+                if (abort.load()) return;
+                std::this_thread::yield();
+            }
+            const size_t len = std::min(half, bytes - c * half);
+            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * (size_t)(t + 1) / (size_t)n_thr;
+            if (b > a) memcpy(dst + c * half + a, g_download.buf[c & 1] + a, b - a);
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; ++t) th.emplace_back(worker, t);
+    hipError_t e = hipSuccess;
+    auto issue = [&](size_t c) {
+        const size_t len = std::min(half, bytes - c * half);
+        e = hipMemcpyAsync(g_download.buf[c & 1], src_dev + c * half, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(g_download.ev[c & 1], st);
+    };
+    for (size_t c = 0; c < std::min<size_t>(2, n_chunks) && e == hipSuccess; ++c) issue(c);
+    for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+        e = hipEventSynchronize(g_download.ev[c & 1]);
+        if (e != hipSuccess) break;
+        ready.store((int64_t)c, std::memory_order_release);
+        {   // the calling thread is worker 0 of this chunk
+            const size_t len = std::min(half, bytes - c * half);
+            const size_t b = len / (size_t)n_thr;
+            if (b) memcpy(dst + c * half, g_download.buf[c & 1], b);
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+        while (done[c].load(std::memory_order_acquire) < n_thr) std::this_thread::yield();
+        if (c + 2 < n_chunks) issue(c + 2);       // this half is free again
+    }
+    if (e != hipSuccess) abort.store(true);
+    ready.store((int64_t)n_chunks, std::memory_order_release);
+    for (auto &t : th) t.join();
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
+    }
+    return BSIG_OK;
+}
+
+}  // namespace
+
+int bsig::download_to_host(bsig_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes)
+{
+    if (bytes == 0) return BSIG_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes >= (8u << 20) && !is_pinned_host(dst_host))
+        return download_staged(ctx->device, ctx->stream, (const uint8_t *)src_dev, (uint8_t *)dst_host, bytes);
+    hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
+    return BSIG_OK;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// the resident layout as a file (the decoded-column sidecar of SURVEY 8f.4)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SidecarClass {
+    int64_t n;
+    int32_t maxspan, kshift;
+    uint64_t col_cap, idx_entries;
+};
+struct SidecarHeader {
+    char magic[8];                  // "BSIGRDS1"
+    uint32_t version, n_ref;
+    int64_t n_reads;
+    uint32_t stamp_len, n_classes;
+    uint64_t file_bytes;
+    SidecarClass cls[BSIG_MAX_CLASSES];
+};
+constexpr uint32_t kSidecarVersion = 1;
+inline uint64_t pad64(uint64_t v) { return (v + 63) & ~(uint64_t)63; }
+}  // namespace
+
+int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp)
+{
+    if (!reads || !path || !stamp) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_save");
+    HIP_TRY(hipSetDevice(reads->ctx->device));
+    SidecarHeader H;
+    memset(&H, 0, sizeof H);
+    memcpy(H.magic, "BSIGRDS1", 8);
+    H.version = kSidecarVersion;
+    H.n_ref = (uint32_t)reads->n_ref;
+    H.n_reads = reads->info.n_reads;
+    H.stamp_len = (uint32_t)strlen(stamp);
+    H.n_classes = (uint32_t)reads->info.n_classes;
+    uint64_t bytes = pad64(sizeof H) + pad64(H.stamp_len) + 3 * pad64((uint64_t)H.n_ref * 4);
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = reads->dev.cls[c];
+        H.cls[c] = SidecarClass{C.n, C.maxspan, C.kshift, C.n ? reads->col_cap[c] : 0, C.n ? reads->idx_entries[c] : 0};
+        if (!C.n) continue;
+        bytes += (c ? 4 : 3) * pad64(H.cls[c].col_cap * 4) + pad64(H.cls[c].idx_entries * 4);
+    }
+    H.file_bytes = bytes;
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return fail(BSIG_ERR_IO, "cannot write %s", tmp.c_str());
+    bool ok = true;
+    static const char zeros[64] = {0};
+    auto put = [&](const void *p, uint64_t n) {
+        ok = ok && (n == 0 || fwrite(p, 1, n, fp) == n);
+        const uint64_t pad = pad64(n) - n;
+        ok = ok && (pad == 0 || fwrite(zeros, 1, pad, fp) == pad);
+    };
+    put(&H, sizeof H);
+    put(stamp, H.stamp_len);
+    put(reads->ref_len.data(), (uint64_t)H.n_ref * 4);
+    put(reads->ref_unit0.data(), (uint64_t)H.n_ref * 4);
+    put(reads->ref_units.data(), (uint64_t)H.n_ref * 4);
+    std::vector<uint8_t> host;
+    int rc = BSIG_OK;
+    auto put_dev = [&](const void *d, uint64_t n) {
+        if (rc || !ok) return;
+        host.resize(n);
+        rc = bsig::download_to_host(reads->ctx, d, host.data(), n);
+        if (!rc) put(host.data(), n);
+    };
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        const BsigClassCols &C = reads->dev.cls[c];
+        if (!C.n) continue;
+        put_dev(C.pos, H.cls[c].col_cap * 4);
+        if (c) put_dev(C.end, H.cls[c].col_cap * 4);
+        put_dev(C.fm, H.cls[c].col_cap * 4);
+        put_dev(C.tlen, H.cls[c].col_cap * 4);
+        put_dev(C.idx, H.cls[c].idx_entries * 4);
+    }
+    ok = (fclose(fp) == 0) && ok;
+    if (rc || !ok || rename(tmp.c_str(), path) != 0) {
+        remove(tmp.c_str());
+        return rc ? rc : fail(BSIG_ERR_IO, "writing %s failed", path);
+    }
+    return BSIG_OK;
+}
+
+namespace {
+// pageable host memory -> device through two page-locked halves filled by a few threads (the
+// mirror image of download_staged)
+int upload_staged(int device, hipStream_t st, const uint8_t *src, uint8_t *dst_dev, size_t bytes)
+{
+    DownloadStage &D = download_for(device);
+    std::lock_guard<std::mutex> lock(D.mu);
+    HIP_TRY(hipSetDevice(device));
+    const int rc = D.ensure();
+    if (rc) return rc;
+    const size_t half = DownloadStage::kHalf;
+    int n_thr = 8;
+    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    bool used[2] = {false, false};
+    size_t c = 0;
+    for (size_t at = 0; at < bytes; at += half, ++c) {
+        const size_t len = std::min(half, bytes - at);
+        const int h = (int)(c & 1);
+        if (used[h]) HIP_TRY(hipEventSynchronize(D.ev[h]));
+        std::vector<std::thread> th;
+        auto part = [&](int t) {
+            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * (size_t)(t + 1) / (size_t)n_thr;
+            if (b > a) memcpy(D.buf[h] + a, src + at + a, b - a);
+        };
+        for (int t = 1; t < n_thr; ++t) th.emplace_back(part, t);
+        part(0);
+        for (auto &x : th) x.join();
+        HIP_TRY(hipMemcpyAsync(dst_dev + at, D.buf[h], len, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(D.ev[h], st));
+        used[h] = true;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return BSIG_OK;
+}
+}  // namespace
+
+int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_reads **out)
+{
+    if (!ctx || !path || !stamp || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_load");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(BSIG_ERR_IO, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(SidecarHeader)) { close(fd); return fail(BSIG_ERR_FORMAT, "%s is not a reads file", path); }
+    const size_t size = (size_t)sb.st_size;
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(BSIG_ERR_IO, "cannot map %s", path);
+    const uint8_t *base = (const uint8_t *)map;
+    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, size};
+    SidecarHeader H;
+    memcpy(&H, base, sizeof H);
+    if (memcmp(H.magic, "BSIGRDS1", 8) != 0 || H.version != kSidecarVersion || H.file_bytes != size)
+        return fail(BSIG_ERR_FORMAT, "%s is not a reads file of this version (or is truncated)", path);
+    uint64_t at = pad64(sizeof H);
+    auto take = [&](uint64_t n) -> const uint8_t * {
+        if (at + pad64(n) > size) return nullptr;
+        const uint8_t *p = base + at;
+        at += pad64(n);
+        return p;
+    };
+    const uint8_t *st_p = take(H.stamp_len);
+    if (!st_p || H.stamp_len != strlen(stamp) || memcmp(st_p, stamp, H.stamp_len) != 0)
+        return fail(BSIG_ERR_FORMAT, "%s was made from another version of the BAM file", path);
+    if (H.n_ref > (1u << 28)) return fail(BSIG_ERR_FORMAT, "%s is damaged", path);
+    const uint8_t *p_len = take((uint64_t)H.n_ref * 4), *p_u0 = take((uint64_t)H.n_ref * 4), *p_un = take((uint64_t)H.n_ref * 4);
+    if (!p_len || !p_u0 || !p_un) return fail(BSIG_ERR_FORMAT, "%s is truncated", path);
+    std::unique_ptr<bsig_reads> R(new bsig_reads);
+    R->ctx = ctx;
+    R->n_ref = (int32_t)H.n_ref;
+    R->ref_len.assign((const int32_t *)p_len, (const int32_t *)p_len + H.n_ref);
+    R->ref_unit0.assign((const uint32_t *)p_u0, (const uint32_t *)p_u0 + H.n_ref);
+    R->ref_units.assign((const uint32_t *)p_un, (const uint32_t *)p_un + H.n_ref);
+    R->info = bsig_reads_info{};
+    R->info.n_reads = H.n_reads;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+        BsigClassCols &C = R->dev.cls[c];
+        C = BsigClassCols{};
+        const SidecarClass &K = H.cls[c];
+        if (K.n <= 0) continue;
+        if (K.col_cap < (uint64_t)K.n || K.col_cap > (1ull << 33) || K.idx_entries < 2 || K.idx_entries > (1ull << 33) ||
+            K.kshift < 0 || K.kshift > 62)
+            return fail(BSIG_ERR_FORMAT, "%s is damaged", path);
+        auto load = [&](uint64_t count, const void **dst) -> int {
+            const uint8_t *src = take(count * 4);
+            if (!src) return fail(BSIG_ERR_FORMAT, "%s is truncated", path);
+            uint32_t *d = nullptr;
+            HIP_TRY(R->pool.alloc(&d, (size_t)count));
+            *dst = d;
+            return upload_staged(ctx->device, ctx->stream, src, (uint8_t *)d, (size_t)count * 4);
+        };
+        int rc = load(K.col_cap, (const void **)&C.pos);
+        if (!rc && c) rc = load(K.col_cap, (const void **)&C.end);
+        if (!rc) rc = load(K.col_cap, (const void **)&C.fm);
+        if (!rc) rc = load(K.col_cap, (const void **)&C.tlen);
+        if (!rc) rc = load(K.idx_entries, (const void **)&C.idx);
+        if (rc) return rc;
+        C.n = K.n; C.maxspan = K.maxspan; C.kshift = K.kshift;
+        R->col_cap[c] = K.col_cap;
+        R->idx_entries[c] = K.idx_entries;
+        R->info.class_n[c] = K.n;
+        R->info.class_maxspan[c] = K.maxspan;
+        R->info.class_bucket_shift[c] = K.kshift;
+        R->info.n_classes += 1;
+    }
+    R->info.hbm_bytes = R->pool.bytes;
+    *out = R.release();
+    return BSIG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------
@@ -578,11 +891,6 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     if (P->n_items >= (1ll << 31)) { delete P; return fail(BSIG_ERR_ARG, "too many tiles for one launch"); }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = P->pool.alloc(&P->items, std::max<size_t>(items.size(), 1));
-    if (e == hipSuccess && prm->resolve == 1) {
-        uint64_t *wbuf = nullptr;
-        e = P->pool.alloc(&wbuf, std::max<size_t>(items.size(), 1) * BSIG_MAX_CLASSES);
-        P->windows = wbuf;
-    }
     if (e == hipSuccess && !items.empty())
         e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -672,7 +980,7 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (p->kernel_mode == BSIG_MODE_COUNT)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
     HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
-                                p->tile_cells, p->windows, true, out_dev, st));
+                                p->tile_cells, nullptr, false, out_dev, st));
     if (p->n_heavy_slices) {
         // the first launch zero-filled the heavy tiles; their slices now add their partial images
         BsigKParams acc = p->kp;
@@ -682,99 +990,6 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     }
     return BSIG_OK;
 }
-
-}  // extern "C"
-
-namespace {
-
-// Result download into PAGEABLE host memory (an R vector, a numpy array): the runtime's own
-// pageable path stages through one buffer and is first-touch bound on the destination pages
-// (80 MB in 8 ms).  Here the result crosses PCIe by DMA into two page-locked halves and a few
-// threads move each half on into the destination while the next one is in flight.
-struct DownloadStage {
-    std::mutex mu;
-    uint8_t *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    static constexpr size_t kHalf = 32u << 20;
-    int ensure()
-    {
-        for (int k = 0; k < 2; ++k) {
-            if (!buf[k]) HIP_TRY(hipHostMalloc((void **)&buf[k], kHalf, hipHostMallocDefault));
-            if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-        }
-        return BSIG_OK;
-    }
-};
-DownloadStage g_download;
-
-bool is_pinned_host(const void *p)
-{
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
-
-int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t *dst, size_t bytes)
-{
-    std::lock_guard<std::mutex> lock(g_download.mu);
-    HIP_TRY(hipSetDevice(device));
-    const int rc = g_download.ensure();
-    if (rc) return rc;
-    const size_t half = DownloadStage::kHalf;
-    const size_t n_chunks = (bytes + half - 1) / half;
-    int n_thr = 8;
-    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
-    std::atomic<int64_t> ready(-1);                 // chunks 0..ready are in their half
-    std::vector<std::atomic<int>> done(n_chunks);   // workers finished with chunk c
-    for (auto &d : done) d.store(0);
-    std::atomic<bool> abort(false);
-    auto worker = [&](int t) {
-        for (size_t c = 0; c < n_chunks; ++c) {
-            while (ready.load(std::memory_order_acquire) < (int64_t)c) {
-                if (abort.load()) return;
-                std::this_thread::yield();
-            }
-            const size_t len = std::min(half, bytes - c * half);
-            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * (size_t)(t + 1) / (size_t)n_thr;
-            if (b > a) memcpy(dst + c * half + a, g_download.buf[c & 1] + a, b - a);
-            done[c].fetch_add(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_thr; ++t) th.emplace_back(worker, t);
-    hipError_t e = hipSuccess;
-    auto issue = [&](size_t c) {
-        const size_t len = std::min(half, bytes - c * half);
-        e = hipMemcpyAsync(g_download.buf[c & 1], src_dev + c * half, len, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipEventRecord(g_download.ev[c & 1], st);
-    };
-    for (size_t c = 0; c < std::min<size_t>(2, n_chunks) && e == hipSuccess; ++c) issue(c);
-    for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
-        e = hipEventSynchronize(g_download.ev[c & 1]);
-        if (e != hipSuccess) break;
-        ready.store((int64_t)c, std::memory_order_release);
-        {   // the calling thread is worker 0 of this chunk
-            const size_t len = std::min(half, bytes - c * half);
-            const size_t b = len / (size_t)n_thr;
-            if (b) memcpy(dst + c * half, g_download.buf[c & 1], b);
-            done[c].fetch_add(1, std::memory_order_release);
-        }
-        while (done[c].load(std::memory_order_acquire) < n_thr) std::this_thread::yield();
-        if (c + 2 < n_chunks) issue(c + 2);       // this half is free again
-    }
-    if (e != hipSuccess) abort.store(true);
-    ready.store((int64_t)n_chunks, std::memory_order_release);
-    for (auto &t : th) t.join();
-    if (e != hipSuccess) {
-        (void)hipStreamSynchronize(st);
-        return fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
-    }
-    return BSIG_OK;
-}
-
-}  // namespace
-
-extern "C" {
 
 int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
 {
@@ -809,58 +1024,6 @@ int bsig_plan_run_host_async(bsig_plan *p, int32_t *out_host)
     return BSIG_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// launch trains as HIP graphs: a fixed sequence of bsig_plan_run() calls on one context is
-// captured once and replayed with one host call per replay (a step of config 2 is 23 us of GPU
-// time: a host thread that issues every launch itself must never be late by more than that)
-// ---------------------------------------------------------------------------------------------
-struct bsig_graph {
-    bsig_ctx *ctx = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-};
-
-int bsig_graph_begin(bsig_ctx *ctx)
-{
-    if (!ctx) return fail(BSIG_ERR_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    return BSIG_OK;
-}
-
-int bsig_graph_end(bsig_ctx *ctx, bsig_graph **out)
-{
-    if (!ctx || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_graph_end");
-    *out = nullptr;
-    hipGraph_t g = nullptr;
-    HIP_TRY(hipStreamEndCapture(ctx->stream, &g));
-    hipGraphExec_t ex = nullptr;
-    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        return fail(BSIG_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
-    }
-    bsig_graph *G = new bsig_graph;
-    G->ctx = ctx; G->graph = g; G->exec = ex;
-    *out = G;
-    return BSIG_OK;
-}
-
-int bsig_graph_launch(bsig_graph *g)
-{
-    if (!g) return fail(BSIG_ERR_ARG, "graph is NULL");
-    HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
-    return BSIG_OK;
-}
-
-void bsig_graph_free(bsig_graph *g)
-{
-    if (!g) return;
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
-    delete g;
-}
-
 int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
 {
     if (!p || !s) return fail(BSIG_ERR_ARG, "NULL argument");
@@ -884,10 +1047,8 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         t.streamed = (int64_t)acc[4];
         t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // pos + packed flag/mapq/span [+ tlen]
         t.bytes_per_visit_long = p->kp.use_tlen ? 16 : 12;     // pos + end + flag/mapq [+ tlen]
-        // reads + work items + index entries + result cells; with the separate resolve kernel the
-        // work items are read twice and the windows written once and read once
-        const int64_t per_item = p->windows ? 2 * (int64_t)sizeof(BsigWorkItem) + 2 * 8 * BSIG_MAX_CLASSES
-                                            : (int64_t)sizeof(BsigWorkItem);
+        // reads + work items + index entries + result cells
+        const int64_t per_item = (int64_t)sizeof(BsigWorkItem);
         t.algorithmic_bytes = t.bytes_per_visit_short * t.visits_short +
                               t.bytes_per_visit_long * (t.visits - t.visits_short) + per_item * t.n_items +
                               8 * t.n_items * p->reads->info.n_classes + 4 * t.cells;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "../../include/bamsignals_abi.h"
@@ -72,5 +73,14 @@ int layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_ref, c
                        const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tlen);
 // hands the device-side decode's cached scratch back to the driver (devdecode.hip)
 void release_decode_scratch();
+// > 0: the file (or this build's limits) needs another decode path; nothing was allocated
+constexpr int kNeedsCpuPath = 1;
+// Whole BAM -> resident reads on every listed GPU: each GPU decodes one share of the BGZF blocks, the
+// column shares are all-gathered over xGMI (devdecode.hip).  BSIG_OK, kNeedsCpuPath or an error.
+int reads_from_bam_sharded(const std::vector<bsig_ctx *> &ctxs, const std::string &path, int threads,
+                           std::vector<bsig_reads *> &out, const char **transport);
+// a device buffer to (pageable or page-locked) host memory, staged through page-locked halves where
+// that is faster (runtime.hip)
+int download_to_host(bsig_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes);
 }  // namespace bsig
 #endif

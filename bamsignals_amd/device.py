@@ -135,6 +135,27 @@ class Reads:
         return self
 
     @classmethod
+    def from_bam_multi(cls, ctxs, bam, threads=0):
+        """The whole BAM resident on every context's GPU: each GPU decodes one share of the BGZF blocks,
+        the column shares are exchanged over xGMI.  Returns (list of Reads, sharded?)."""
+        lib = _lib.load()
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c._h for c in ctxs])
+        hs = (C.c_void_p * n)()
+        sharded = C.c_int32(0)
+        _lib.check(lib.bsig_reads_from_bam_multi(arr, n, bam._h, int(threads), hs, C.byref(sharded)))
+        out = []
+        for k in range(n):
+            self = cls.__new__(cls)
+            self._lib = lib
+            self.ctx = ctxs[k]
+            self._h = C.c_void_p(hs[k])
+            self.n_ref = len(bam.ref_len)
+            self.n_reads = self.info()["n_reads"]
+            out.append(self)
+        return out, bool(sharded.value)
+
+    @classmethod
     def from_bam_regions(cls, ctx, bam, rid, beg, end, threads=0):
         """The records the BAI lists for the regions [beg, end) (0-based) decoded to HBM -- a superset
         of the overlapping records, each once, in file order (what ``BamFile.decode(rid, beg, end)``
@@ -153,6 +174,23 @@ class Reads:
         self._h = h
         self.n_ref = len(bam.ref_len)
         self.n_reads = self.info()["n_reads"]
+        return self
+
+    def save(self, path, stamp=""):
+        """Write the resident layout to ``path`` (bsig_reads_save); ``stamp`` ties it to its source."""
+        _lib.check(self._lib.bsig_reads_save(self._h, str(path).encode(), str(stamp).encode()))
+
+    @classmethod
+    def load(cls, ctx, path, stamp=""):
+        """Resident reads from a file written by ``save`` (fails if ``stamp`` differs)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.ctx = ctx
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_reads_load(ctx._h, str(path).encode(), str(stamp).encode(), C.byref(h)))
+        self._h = h
+        self.n_reads = self.info()["n_reads"]
+        self.n_ref = None
         return self
 
     def clone(self, ctx):
@@ -190,7 +228,7 @@ class Reads:
 
 
 def make_params(mode, tlen_filter=(), mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
-                filteredF=-1, pe_mid=False, tspan=False, tile_cells=0, threads=0, resolve=0):
+                filteredF=-1, pe_mid=False, tspan=False, tile_cells=0, threads=0):
     p = _lib.Params()
     p.mode = mode
     p.mapqual = int(mapqual)
@@ -209,7 +247,6 @@ def make_params(mode, tlen_filter=(), mapqual=0, binsize=1, shift=0, ss=False, r
         p.tlen_filter[i] = v
     p.tile_cells = int(tile_cells)
     p.threads = int(threads)
-    p.resolve = int(resolve)
     return p
 
 
@@ -254,44 +291,6 @@ class Plan:
     def close(self):
         if getattr(self, "_h", None):
             self._lib.bsig_plan_free(self._h)
-            self._h = None
-
-    def __del__(self):
-        self.close()
-
-
-class LaunchGraph:
-    """A train of ``Plan.run_device`` calls on one context captured as a HIP graph::
-
-        with LaunchGraph(ctx) as g:
-            for plan, out in zip(plans, outs):
-                plan.run_device(out.data_ptr())      # recorded, not executed
-        g.launch()                                   # one host call replays the whole train
-    """
-
-    def __init__(self, ctx):
-        self._lib = _lib.load()
-        self.ctx = ctx
-        self._h = None
-
-    def __enter__(self):
-        _lib.check(self._lib.bsig_graph_begin(self.ctx._h))
-        return self
-
-    def __exit__(self, exc_type, exc, tb):
-        h = C.c_void_p()
-        rc = self._lib.bsig_graph_end(self.ctx._h, C.byref(h))
-        if exc_type is None:
-            _lib.check(rc)
-        self._h = h if rc == 0 else None
-        return False
-
-    def launch(self):
-        _lib.check(self._lib.bsig_graph_launch(self._h))
-
-    def close(self):
-        if getattr(self, "_h", None):
-            self._lib.bsig_graph_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -151,6 +151,11 @@ def last_call_timing():
                 bam_was_resident=bool(t[5]))
 
 
+def last_call_route():
+    """How this thread's last file-level call was carried out (GPUs, decode route, result route)."""
+    return _lib.load().bsig_last_call_route().decode()
+
+
 def bamCount(bampath, gr, mapqual=0, shift=0, ss=False, paired_end=("ignore", "filter", "midpoint"),  # noqa: N802
              tlenFilter=None, filteredFlag=-1, verbose=True):  # noqa: N803
     """For each range, count the reads whose 5' end maps in it (R/wrappers.R:101-120).

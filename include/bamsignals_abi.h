@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BSIG_ABI_VERSION 1
+#define BSIG_ABI_VERSION 2
 
 enum {
     BSIG_OK = 0,
@@ -107,6 +107,13 @@ void bsig_reads_free(bsig_reads *reads);
 /* a copy of resident reads on another GPU (device-to-device over xGMI where peer access exists):
  * how the single-process multi-GPU path replicates a BAM that was decoded once                 */
 int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **reads);
+/* The resident layout as a file (the decoded-column "sidecar" of a BAM): a later process loads it and
+ * skips BGZF inflate and record parsing (the reference pays both on every call, ref:
+ * src/bamsignals.cpp:449,479 + :271).  `stamp` ties the file to what it was made from (the
+ * file-level calls use path + size + mtime of the BAM and of its index); bsig_reads_load fails with
+ * BSIG_ERR_FORMAT when the stamp differs or the file is damaged, BSIG_ERR_IO when it is absent.   */
+int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp);
+int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_reads **reads);
 
 /* ------------------------------------------------------------------------------------------
  * A plan = ranges + call parameters resident in HBM, ready to run any number of times.
@@ -128,8 +135,6 @@ typedef struct {
     /* tuning knobs, 0 = default */
     int32_t tile_cells;        /* output cells per workgroup tile (default 2048)                */
     int32_t threads;           /* 64, 128 or 256 threads per workgroup (default 64)             */
-    int32_t resolve;           /* 0: index lookup inside the pileup kernel (default);           */
-                               /* 1: separate k_resolve launch in front of it                   */
 } bsig_params;
 
 typedef struct bsig_plan bsig_plan;
@@ -161,15 +166,6 @@ int bsig_plan_run_host(bsig_plan *plan, int32_t *out_host);
  * lets one host thread keep several GPUs busy; finish with bsig_ctx_sync() on the plan's context */
 int bsig_plan_run_host_async(bsig_plan *plan, int32_t *out_host);
 void bsig_plan_free(bsig_plan *plan);
-
-/* A fixed train of bsig_plan_run() calls on one context, captured once as a HIP graph and replayed
- * with one host call per replay: between bsig_graph_begin and bsig_graph_end the bsig_plan_run
- * calls on that context are recorded instead of executed.                                      */
-typedef struct bsig_graph bsig_graph;
-int bsig_graph_begin(bsig_ctx *ctx);
-int bsig_graph_end(bsig_ctx *ctx, bsig_graph **graph);
-int bsig_graph_launch(bsig_graph *graph);
-void bsig_graph_free(bsig_graph *graph);
 
 /* one-shot: columns already in HBM -> host result (upload ranges, run, download)               */
 int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,
@@ -212,6 +208,16 @@ void bsig_bam_decode_timing(double *t6);
  * messages.  env BAMSIGNALS_DEVICE_DECODE=0 forces the CPU decode, =require fails instead of
  * falling back (testing).                                                                      */
 int bsig_reads_from_bam(bsig_ctx *ctx, bsig_bam *bam, int32_t threads, bsig_reads **reads);
+/* Whole BAM -> resident reads on each of n contexts (one per GPU; the single-process multi-GPU route):
+ * GPU g inflates and parses share g of the BGZF blocks (the stage the reference spends its wall time
+ * in, ref: src/bamsignals.cpp:271), the column shares are all-gathered over xGMI (RCCL grouped
+ * send/recv, or peer copies: env BAMSIGNALS_EXCHANGE=rccl|peer), every GPU builds its resident layout.
+ * The shares are accepted only if their record chains tile the stream exactly; otherwise (and for
+ * files the device path declines, or smaller than 16 blocks per GPU) the file is decoded on the first
+ * GPU and cloned.  *sharded (may be NULL) receives 1 if the sharded route was taken.
+ * env BAMSIGNALS_SHARDED_DECODE=0 / =require as BAMSIGNALS_DEVICE_DECODE.                           */
+int bsig_reads_from_bam_multi(bsig_ctx *const *ctxs, int32_t n, bsig_bam *bam, int32_t threads,
+                              bsig_reads **reads, int32_t *sharded);
 /* The same for an index-driven query: the records the BAI lists for the regions [beg, end) (what
  * one bam_itr_queryi per chunk of ranges returns, ref: src/bamsignals.cpp:252-271): a superset of
  * the overlapping records, each at most once, in file order.  Falls back like bsig_reads_from_bam. */
@@ -227,9 +233,13 @@ void bsig_device_decode_timing(double *t6);
  * Ranges come as GRanges slots flattened by the shim (ref: parseRegions, src/bamsignals.cpp:
  * 92-135): seq_code[i] indexes seq_levels (the factor levels of seqnames, mapped to BAM ids BY
  * NAME), start is 1-based, strand is +1 / -1 / 0.  out/off as in bsig_layout().
- * device < 0: the GPUs listed in env BAMSIGNALS_DEVICES ("0,1,...,7": the sorted ranges are dealt
- * round-robin to them, one stream per GPU, results reassembled on the host), else env
- * BAMSIGNALS_DEVICE, else GPU 0.  maxgap is accepted for signature parity with the
+ * device < 0: the GPUs listed in env BAMSIGNALS_DEVICES ("0,1,...,7"), else env BAMSIGNALS_DEVICE,
+ * else GPU 0.  With several GPUs every GPU inflates and parses its share of the BGZF blocks and the
+ * column shares are all-gathered over xGMI; the (rid, loc)-sorted ranges are dealt round-robin to the
+ * GPUs (one host thread and stream each); the result shards are gathered on the first GPU over xGMI
+ * (RCCL grouped send/recv; env BAMSIGNALS_EXCHANGE=peer: peer copies), put into range order there and
+ * downloaded once (env BAMSIGNALS_GATHER=pcie: every GPU's shard over its own PCIe link instead,
+ * reassembled by host threads).  maxgap is accepted for signature parity with the
  * reference (ref: src/bamsignals.cpp:446,476) and does not influence the result.
  * ------------------------------------------------------------------------------------------ */
 /* replaces bamsignals_pileup_core (ref: src/RcppExports.cpp:33-52 -> src/bamsignals.cpp:444-461) */
@@ -253,8 +263,17 @@ int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath);
 /* columnar writer used for synthetic BAMs: coordinate-sorted columns -> BAM + BAI             */
 int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *const *ref_names,
                               const bsig_columns *cols, int32_t level);
-/* drops the per-process cache of BAMs decoded to HBM by the file-level entry points           */
+/* The file-level entry points keep, per process: one context per listed GPU, the parsed header +
+ * BAI of the last 16 BAMs, and whole BAMs decoded to HBM -- least recently used first out above
+ * env BAMSIGNALS_CACHE_GB (per GPU, default 96).  A file is identified by path + size + mtime of the
+ * BAM and of its index: a rewritten file is decoded again.  env BAMSIGNALS_SIDECAR=1 (next to the BAM,
+ * <bam>.bsig) or BAMSIGNALS_SIDECAR_DIR=<dir> additionally keeps the resident layout on disk
+ * (bsig_reads_save) so that another process skips the decode.  bsig_cache_clear drops all of it
+ * (not the sidecar files).                                                                      */
 void bsig_cache_clear(void);
+/* how the calling thread's last file-level call was carried out, e.g.
+ * "8 GPU slot(s); reads: sharded decode, columns over rccl; result: xgmi/rccl"                  */
+const char *bsig_last_call_route(void);
 /* stage seconds of the calling thread's last bsig_pileup_core / bsig_coverage_core: open (header +
  * BAI), decode, upload + HBM layout, plan + kernels + download, total; t6[5] = 1 if the BAM was
  * already resident in HBM                                                                      */

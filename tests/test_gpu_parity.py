@@ -16,15 +16,15 @@ def ctx():
     c.close()
 
 
-def _gpu(ctx, reads, ranges, kind, tile_cells=0, threads=0, resolve=0, **a):
+def _gpu(ctx, reads, ranges, kind, tile_cells=0, threads=0, **a):
     from bamsignals_amd import _lib
     from bamsignals_amd.device import Plan, make_params
     if kind == "coverage":
-        p = make_params(_lib.MODE_COVERAGE, tile_cells=tile_cells, threads=threads, resolve=resolve, **a)
+        p = make_params(_lib.MODE_COVERAGE, tile_cells=tile_cells, threads=threads, **a)
     else:
         bs = a.pop("binsize", 1)
         mode = _lib.MODE_COUNT if bs <= 0 else _lib.MODE_PROFILE
-        p = make_params(mode, binsize=bs, tile_cells=tile_cells, threads=threads, resolve=resolve, **a)
+        p = make_params(mode, binsize=bs, tile_cells=tile_cells, threads=threads, **a)
     plan = Plan(ctx, reads, ranges["rid"], ranges["loc"], ranges["len"], ranges["strand"], p)
     out = plan.run_host()
     off = plan.offsets
@@ -318,12 +318,12 @@ def test_fuzz_small_inputs(ctx):
                     ss=bool(rng.integers(0, 2)), pe_mid=bool(pe and rng.integers(0, 2)))
         want, woff = oracle_c.pileup_core(orc, rg, **pile)
         got, off = _gpu(ctx, gpu, rg, "pileup", tile_cells=int(rng.choice([0, 64, 256, 1000])),
-                        threads=int(rng.choice([0, 64, 128, 256])), resolve=int(rng.integers(0, 2)), **dict(pile))
+                        threads=int(rng.choice([0, 64, 128, 256])), **dict(pile))
         assert np.array_equal(off, woff) and np.array_equal(got, want), (case, pile)
         cov = dict(common, tspan=bool(pe and rng.integers(0, 2)))
         want, woff = oracle_c.coverage_core(orc, rg, **cov)
         got, off = _gpu(ctx, gpu, rg, "coverage", tile_cells=int(rng.choice([0, 64, 256, 1000])),
-                        threads=int(rng.choice([0, 64, 128, 256])), resolve=int(rng.integers(0, 2)), **dict(cov))
+                        threads=int(rng.choice([0, 64, 128, 256])), **dict(cov))
         assert np.array_equal(off, woff) and np.array_equal(got, want), (case, cov)
         gpu.close()
 
@@ -360,9 +360,8 @@ def test_heavy_tile_slices(ctx, synth, monkeypatch):
         for a in (dict(binsize=1, ss=True, shift=20), dict(binsize=40, requiredF=66, tlen_filter=(0, 900), pe_mid=True),
                   dict(binsize=-1, ss=True), dict(binsize=3000), dict(binsize=70_000, ss=True)):
             want, _ = oracle_c.pileup_core(orc, rg, **a)
-            for resolve in (0, 1):
-                got, _ = _gpu(ctx, gpu, rg, "pileup", resolve=resolve, **dict(a))
-                assert np.array_equal(got, want), (thr, a, resolve)
+            got, _ = _gpu(ctx, gpu, rg, "pileup", **dict(a))
+            assert np.array_equal(got, want), (thr, a)
         for a in (dict(), dict(requiredF=66, tlen_filter=(0, 900), tspan=True)):
             want, _ = oracle_c.coverage_core(orc, rg, **a)
             got, _ = _gpu(ctx, gpu, rg, "coverage", threads=128, **dict(a))
@@ -390,38 +389,3 @@ def test_heavy_tile_slices(ctx, synth, monkeypatch):
         assert np.array_equal(got, want), (kind, a)
     hot.close()
 
-
-def test_launch_graph_replays_the_same_launches(synth):
-    """bsig_graph_*: a train of plan runs (profile, count with its zero fill, coverage) captured as a
-    HIP graph gives, on every replay, what the direct launches give."""
-    import torch
-    from bamsignals_amd import _lib
-    from bamsignals_amd.device import Context, LaunchGraph, Plan, make_params
-    gpu, orc, cols, _ = synth["se"]
-    rng = np.random.default_rng(12)
-    rg = _rand_ranges(rng, cols["ref_len"], 300, 5000)
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        c2 = Context(0, stream=stream.cuda_stream)
-        twin = gpu.clone(c2)
-        plans = [Plan(c2, twin, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(m, **a))
-                 for m, a in ((_lib.MODE_PROFILE, dict(binsize=1, ss=True, shift=11)), (_lib.MODE_COUNT, dict(binsize=-1)),
-                              (_lib.MODE_COVERAGE, dict()))]
-        want = [p.run_host().copy() for p in plans]
-        outs = [torch.full((max(p.cells, 4),), -7, dtype=torch.int32, device="cuda") for p in plans]
-        g = LaunchGraph(c2)
-        with g:
-            for p, o in zip(plans, outs):
-                p.run_device(o.data_ptr())
-        for _ in range(3):
-            for o in outs:
-                o.fill_(-7)
-            g.launch()
-            c2.sync()
-            for p, o, w in zip(plans, outs, want):
-                assert np.array_equal(o[:p.cells].cpu().numpy(), w)
-        g.close()
-        for p in plans:
-            p.close()
-        twin.close()
-        c2.close()

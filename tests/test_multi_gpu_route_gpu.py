@@ -1,0 +1,314 @@
+"""GPU: the single-process multi-GPU route and what the file-level calls keep between calls.
+
+* sharded decode: every listed GPU inflates and parses its share of the BGZF blocks, the column
+  shares are exchanged, every GPU lays the reads out (csrc/devdecode.hip: reads_from_bam_sharded) —
+  against the single-GPU decode and the CPU decode, on htslib's fixture, on files whose records
+  cross block (and therefore share) borders, with several passes per share, with both inflate engines;
+* result gather on the first GPU (peer copies here; RCCL with a one-rank communicator) + device-side
+  reassembly, against the per-GPU PCIe route and the oracle;
+* the resident-BAM cache: least recently used out under BAMSIGNALS_CACHE_GB, a rewritten file is
+  decoded again, the on-disk sidecar is loaded by a "second process" (a cleared cache).
+
+The pool's boxes have ONE GPU: it is listed several times (separate contexts, streams, resident
+copies and host threads: the same code path, with peer copies standing in for RCCL, which refuses
+a GPU listed twice)."""
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_device_decode_gpu import _bgzf, _empty_bai, _results
+
+pytestmark = pytest.mark.gpu
+
+BAM = os.path.join(GOLDEN, "randomBam.bam")
+
+
+def _contexts(n):
+    from bamsignals_amd.device import Context
+    return [Context(0) for _ in range(n)]
+
+
+def _sharded_vs_single(path, n, monkeypatch, expect_sharded=True):
+    """Decode `path` in n shares and on one GPU; every slot's resident reads must be indistinguishable
+    from the single-GPU decode's."""
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    bam = BamFile(path)
+    ctxs = _contexts(n)
+    monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+    monkeypatch.setenv("BAMSIGNALS_SHARDED_DECODE", "require" if expect_sharded else "1")
+    many, sharded = Reads.from_bam_multi(ctxs, bam)
+    assert sharded == expect_sharded
+    monkeypatch.setenv("BAMSIGNALS_SHARDED_DECODE", "0")
+    one, s2 = Reads.from_bam_multi(ctxs[:1], bam)
+    assert not s2
+    want = _results(ctxs[0], one[0], bam.ref_len)
+    for k in range(n):
+        assert many[k].info() == one[0].info(), k
+        for a, b in zip(_results(ctxs[k], many[k], bam.ref_len), want):
+            assert np.array_equal(a, b), k
+    n_reads = one[0].n_reads
+    for r in many + one:
+        r.close()
+    for c in ctxs:
+        c.close()
+    bam.close()
+    return n_reads
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("inflate", ["cpu", "gpu"])
+def test_sharded_decode_of_the_reference_fixture(n, inflate, monkeypatch):
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", inflate)
+    assert _sharded_vs_single(BAM, n, monkeypatch) == 99000
+
+
+@pytest.mark.parametrize("inflate", ["cpu", "gpu"])
+def test_sharded_decode_with_records_across_share_borders(tmp_path, inflate, monkeypatch):
+    """htsjdk-style files: records run across BGZF block borders, so a share begins in the middle of a
+    record; its lanes propose the first record start and the host accepts the shares only because
+    every share's chain ends exactly where the next one's begins.  Also several passes per share
+    (1-MiB chunks) with the cut-off record carried."""
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", inflate)
+    stream = gzip.decompress(open(BAM, "rb").read())
+    for k, sizes in enumerate(([4000, 9001, 517, 65000], [65536], [33000, 70, 1000])):
+        p = tmp_path / ("straddle%d.bam" % k)
+        p.write_bytes(_bgzf(stream, sizes))
+        _empty_bai(str(p) + ".bai", 3)
+        for n in (2, 5):
+            assert _sharded_vs_single(str(p), n, monkeypatch) == 99000
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", "1")
+    monkeypatch.setenv("BAMSIGNALS_BATCH_BLOCKS", "3")
+    p = tmp_path / "straddle0.bam"
+    assert _sharded_vs_single(str(p), 3, monkeypatch) == 99000
+
+
+def test_sharded_decode_declines_what_it_cannot_prove(tmp_path, monkeypatch):
+    """A 6-MB record in the middle of the file: the border between two shares falls inside it, megabytes
+    in front of its end, far beyond the few blocks a share sees behind its own.  The sharded route steps
+    aside and the call returns the single-GPU result."""
+    import struct
+    text = b"@SQ\tSN:c\tLN:3000000\n"
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\x00" + struct.pack("<i", 3000000)
+
+    def rec(pos, lseq):
+        name = b"q\x00"
+        body = struct.pack("<iiBBHHHiiii", 0, pos, len(name), 40, 4681, 1, 0, lseq, -1, -1, 0) + name
+        body += struct.pack("<I", (max(lseq, 30) << 4) | 0) + bytes((lseq + 1) // 2) + b"\xff" * lseq
+        return struct.pack("<i", len(body)) + body
+    recs = [rec(10 + i, 0) for i in range(1000)] + [rec(2000, 4_000_000)] + [rec(3000 + i, 0) for i in range(1000)]
+    p = tmp_path / "giant.bam"
+    p.write_bytes(_bgzf(hdr + b"".join(recs), [65536]))
+    _empty_bai(str(p) + ".bai", 1)
+    assert _sharded_vs_single(str(p), 2, monkeypatch, expect_sharded=False) == 2001
+
+
+@pytest.fixture(scope="module")
+def synth_bam(tmp_path_factory):
+    from bamsignals_amd import GRanges, write_columns_as_bam
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    names = ["c%d" % i for i in range(5)]
+    ref_len = [700_000, 30_000, 1_200_000, 90_000, 400_000]
+    cols = synth_reads(500_000, ref_len, seed=141, paired=True)
+    d = tmp_path_factory.mktemp("routebam")
+    bam = str(d / "s.bam")
+    write_columns_as_bam(bam, names, cols)
+    rg = synth_ranges(777, 1800, ref_len, seed=142, jitter=900)
+    gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"],
+                 strand=[{1: "+", -1: "-", 0: "*"}[int(s)] for s in rg["strand"]])
+    return bam, names, ref_len, cols, rg, gr
+
+
+def _oracle(cols):
+    from oracle import oracle_c
+    return oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+
+
+def _three_calls(bam, gr):
+    from bamsignals_amd import bamCount, bamCoverage, bamProfile
+    p = bamProfile(bam, gr, ss=True, shift=33, verbose=False)
+    c = bamCount(bam, gr, paired_end="midpoint", tlenFilter=(30, 700), verbose=False)
+    v = bamCoverage(bam, gr, mapqual=5, verbose=False)
+    return np.concatenate([m.T.reshape(-1) for m in p]), np.asarray(c), np.concatenate(v.as_list())
+
+
+def _want(cols, rg):
+    from oracle import oracle_c
+    orc = _oracle(cols)
+    return (oracle_c.pileup_core(orc, rg, binsize=1, ss=True, shift=33)[0],
+            oracle_c.pileup_core(orc, rg, binsize=-1, pe_mid=True, tlen_filter=(30, 700), requiredF=66)[0],
+            oracle_c.coverage_core(orc, rg, mapqual=5)[0])
+
+
+@pytest.mark.parametrize("gather", ["xgmi", "pcie"])
+@pytest.mark.parametrize("devices", ["0,0,0", "0,0,0,0,0,0,0,0"])
+def test_file_level_route_over_several_slots(synth_bam, devices, gather, monkeypatch):
+    from bamsignals_amd import _lib
+    from bamsignals_amd.wrappers import last_call_route, last_call_timing
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", devices)
+    monkeypatch.setenv("BAMSIGNALS_GATHER", gather)
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+    _lib.load().bsig_cache_clear()
+    try:
+        want = _want(cols, rg)
+        got = _three_calls(bam, gr)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        got = _three_calls(bam, gr)                          # resident on every slot
+        assert last_call_timing()["bam_was_resident"]
+        route = last_call_route()
+        assert route.startswith("%d GPU slot(s); reads: resident" % len(devices.split(",")))
+        assert ("xgmi/peer" in route) if gather == "xgmi" else route.endswith("pcie")
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        _lib.load().bsig_cache_clear()
+        _three_calls(bam, gr[list(range(5))])
+        _lib.load().bsig_cache_clear()
+        from bamsignals_amd import bamProfile
+        bamProfile(bam, gr, verbose=False)
+        assert "sharded decode, columns over peer" in last_call_route()
+    finally:
+        _lib.load().bsig_cache_clear()
+
+
+def test_rccl_route_with_a_one_rank_communicator(synth_bam, monkeypatch):
+    """BAMSIGNALS_FORCE_SHARDED=1 takes the multi-GPU route with the box's one GPU listed once: librccl is
+    loaded, ncclCommInitAll builds a communicator, the exchanges go through grouped RCCL calls."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.wrappers import last_call_route
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", "0")
+    monkeypatch.setenv("BAMSIGNALS_FORCE_SHARDED", "1")
+    monkeypatch.setenv("BAMSIGNALS_EXCHANGE", "rccl")
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    _lib.load().bsig_cache_clear()
+    try:
+        got = _three_calls(bam, gr)
+        route = last_call_route()
+        assert "xgmi/rccl" in route, route
+        for a, b in zip(got, _want(cols, rg)):
+            assert np.array_equal(a, b)
+        _lib.load().bsig_cache_clear()
+        from bamsignals_amd import bamProfile
+        bamProfile(bam, gr, verbose=False)
+        assert "columns over rccl" in last_call_route(), last_call_route()
+    finally:
+        _lib.load().bsig_cache_clear()
+
+
+def test_decode_on_second_context_after_first(synth_bam):
+    """Two contexts in one process, used one after the other for a decode and a pageable download of
+    more than 8 MiB: the staging buffers and events belong to the device they are used on."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Context, Plan, Reads, make_params
+    from bamsignals_amd.synth import tile_ranges
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    b = BamFile(bam)
+    tiles = tile_ranges(ref_len, 4000)
+    outs = []
+    for k in range(2):
+        ctx = Context(0)
+        r = Reads.from_bam(ctx, b)
+        p = Plan(ctx, r, tiles["rid"], tiles["loc"], tiles["len"], tiles["strand"], make_params(_lib.MODE_COVERAGE))
+        assert p.cells * 4 > (8 << 20)
+        outs.append(p.run_host().copy())
+        p.close(); r.close(); ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+    from oracle import oracle_c
+    assert np.array_equal(outs[0], oracle_c.coverage_core(_oracle(cols), tiles)[0])
+
+
+def test_cache_lru_rewrite_and_sidecar(synth_bam, tmp_path, monkeypatch):
+    from bamsignals_amd import _lib, bamCount, write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    from bamsignals_amd.wrappers import last_call_route, last_call_timing
+    from oracle import oracle_c
+    bam0, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", "0")
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    lib = _lib.load()
+    lib.bsig_cache_clear()
+    try:
+        # three BAMs (copies with different content), a budget that holds two of them
+        paths, wants = [], []
+        for k in range(3):
+            c = synth_reads(300_000, ref_len, seed=500 + k, paired=True)
+            p = str(tmp_path / f"b{k}.bam")
+            write_columns_as_bam(p, names, c)
+            paths.append(p)
+            wants.append(oracle_c.pileup_core(_oracle(c), rg, binsize=-1)[0])
+        from bamsignals_amd.bamio import BamFile
+        from bamsignals_amd.device import Context, Reads
+        ctx = Context(0)
+        bf = BamFile(paths[0])
+        one = Reads.from_bam(ctx, bf).info()["hbm_bytes"]
+        bf.close(); ctx.close()
+        monkeypatch.setenv("BAMSIGNALS_CACHE_GB", repr(2.5 * one / 2**30))
+        def call(k):
+            got = bamCount(paths[k], gr, verbose=False)
+            assert np.array_equal(got, wants[k]), k
+            return last_call_timing()["bam_was_resident"]
+        assert [call(0), call(1), call(0), call(1)] == [False, False, True, True]      # both stay resident
+        assert call(2) is False                                                        # evicts the least recently used: 0
+        assert call(1) is True
+        assert call(0) is False                                                        # 0 was evicted (and now evicts 2)
+        assert call(2) is False
+        # a rewritten file (same path, new content) is decoded again and gives the new counts
+        c = synth_reads(300_000, ref_len, seed=900, paired=True)
+        write_columns_as_bam(paths[1], names, c)
+        wants[1] = oracle_c.pileup_core(_oracle(c), rg, binsize=-1)[0]
+        assert call(1) is False
+        assert call(1) is True
+        # the sidecar: written by the first cold call, loaded by a "second process" (cleared cache)
+        lib.bsig_cache_clear()
+        side = tmp_path / "sidecars"
+        side.mkdir()
+        monkeypatch.setenv("BAMSIGNALS_SIDECAR_DIR", str(side))
+        assert call(0) is False and last_call_route().split("; ")[1] == "reads: decode"
+        files = os.listdir(side)
+        assert len(files) == 1 and files[0].endswith(".bsig")
+        lib.bsig_cache_clear()
+        assert call(0) is False and last_call_route().split("; ")[1] == "reads: sidecar"
+        # a sidecar made from another version of the BAM is ignored (and replaced)
+        shutil.copy(paths[2], paths[0]); shutil.copy(paths[2] + ".bai", paths[0] + ".bai")
+        wants[0] = wants[2]
+        lib.bsig_cache_clear()
+        assert call(0) is False and last_call_route().split("; ")[1] == "reads: decode"
+        lib.bsig_cache_clear()
+        assert call(0) is False and last_call_route().split("; ")[1] == "reads: sidecar"
+        # a damaged sidecar is ignored too
+        f = side / os.listdir(side)[0]
+        raw = bytearray(f.read_bytes())
+        f.write_bytes(bytes(raw[: len(raw) // 2]))
+        lib.bsig_cache_clear()
+        assert call(0) is False and last_call_route().split("; ")[1] == "reads: decode"
+    finally:
+        lib.bsig_cache_clear()
+
+
+def test_reads_save_and_load_round_trip(synth_bam, tmp_path):
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Context, Reads
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    ctx = Context(0)
+    b = BamFile(bam)
+    r = Reads.from_bam(ctx, b)
+    f = str(tmp_path / "r.bsig")
+    r.save(f, "stamp-1")
+    back = Reads.load(ctx, f, "stamp-1")
+    assert back.info() == r.info()
+    for x, y in zip(_results(ctx, back, ref_len), _results(ctx, r, ref_len)):
+        assert np.array_equal(x, y)
+    with pytest.raises(_lib.BsigError, match="another version"):
+        Reads.load(ctx, f, "stamp-2")
+    with pytest.raises(_lib.BsigError):
+        Reads.load(ctx, str(tmp_path / "absent.bsig"), "stamp-1")
+    back.close(); r.close(); b.close(); ctx.close()
