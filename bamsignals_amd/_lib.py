@@ -137,6 +137,10 @@ def load():
     lib.bsig_cache_clear.restype = None
     lib.bsig_last_call_timing.argtypes = [C.POINTER(C.c_double)]
     lib.bsig_last_call_timing.restype = None
+    lib.bsig_check_list.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.bsig_check_list.restype = C.c_int32
+    lib.bsig_fast_width.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.bsig_fast_width.restype = None
     lib.bsig_scatter_segments.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib

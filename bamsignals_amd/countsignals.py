@@ -9,13 +9,15 @@ ROWNAMES = ("sense", "antisense")
 
 
 def _check_list(signals, ss):
-    # checkList, src/CountSignals.cpp:4-16
-    for s in signals:
-        if not isinstance(s, np.ndarray) or s.dtype != np.int32:
-            return False
-        if ss and (s.ndim != 2 or s.shape[0] != 2):
-            return False
-    return True
+    """checkList (ref: src/CountSignals.cpp:4-16) through the native routine the R shim calls too:
+    per element "is an int32 array", the number of dimensions (a plain vector has no dim attribute
+    in R: 0) and the first dimension."""
+    from . import _lib
+    n = len(signals)
+    is_int = np.asarray([isinstance(s, np.ndarray) and s.dtype == np.int32 for s in signals], dtype=np.int32)
+    n_dim = np.asarray([s.ndim if isinstance(s, np.ndarray) and s.ndim > 1 else 0 for s in signals], dtype=np.int32)
+    dim0 = np.asarray([s.shape[0] if isinstance(s, np.ndarray) and s.ndim > 1 else 0 for s in signals], dtype=np.int32)
+    return bool(_lib.load().bsig_check_list(n, is_int.ctypes.data, n_dim.ctypes.data, dim0.ctypes.data, int(bool(ss))))
 
 
 class CountSignals:
@@ -36,8 +38,11 @@ class CountSignals:
         return len(self._signals)
 
     def width(self):                                                 # width() -> fastWidth, :54-56
-        div = 2 if self.ss else 1
-        return np.asarray([s.size // div for s in self._signals], dtype=np.int32)
+        from . import _lib
+        length = np.asarray([s.size for s in self._signals], dtype=np.int64)
+        out = np.empty(len(length), dtype=np.int32)
+        _lib.load().bsig_fast_width(len(length), length.ctypes.data, int(self.ss), out.ctypes.data)
+        return out
 
     def __getitem__(self, i):                                        # "[", :68-77
         if isinstance(i, (int, np.integer)):

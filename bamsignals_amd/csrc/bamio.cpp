@@ -1078,7 +1078,9 @@ int bai_load(const std::string &bai_path, BaiIndex &idx)
     if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0) return fail(BSIG_ERR_FORMAT, "%s is not a BAI index", bai_path.c_str());
     const int32_t n_ref = rdi32(d.data() + 4);
     o = 8;
-    if (n_ref < 0) return fail(BSIG_ERR_FORMAT, "malformed BAI index");
+    // every reference takes at least 8 bytes (n_bin, n_intv): a count the file cannot hold is a
+    // damaged index, not a reason to allocate gigabytes
+    if (n_ref < 0 || (size_t)n_ref > (d.size() - 8) / 8) return fail(BSIG_ERR_FORMAT, "malformed BAI index");
     idx.refs.assign((size_t)n_ref, BaiRef());
     for (int r = 0; r < n_ref; ++r) {
         if (!need(4)) return fail(BSIG_ERR_FORMAT, "truncated BAI index");
@@ -1362,6 +1364,10 @@ struct BamWriter::Impl {
     void index_push(int rid, int64_t beg, int64_t end, uint64_t v0, uint64_t v1, bool mapped)
     {
         if (rid < 0) { ++n_no_coor; return; }
+        // (a record placed on a reference without a position, POS 0 in SAM, is filed under position 0;
+        // the callers have refused coordinates a BAI cannot address)
+        if (beg < 0) beg = 0;
+        if (end <= beg) end = beg + 1;
         RefIdx &R = ridx[(size_t)rid];
         const uint32_t bin = reg2bin(beg, end);
         if (bin == R.last_bin && R.last_chunks && !R.last_chunks->empty()) R.last_chunks->back().end = v1;
@@ -1465,8 +1471,11 @@ int BamWriter::write(const BamRecord &r)
     if (r.cigar.size() > 65535) return fail(BSIG_ERR_FORMAT, "more than 65535 CIGAR operations are not supported by the writer");
     const size_t l_seq = r.seq.size();
     const size_t bs = 32 + l_name + 4 * r.cigar.size() + (l_seq + 1) / 2 + l_seq + r.aux.size();
-    b.resize(4 + bs);
     const int64_t endpos = (int64_t)r.pos + cigar_rlen(r.cigar.data(), (int)r.cigar.size(), r.flag);
+    if (r.rid >= 0 && (r.pos < -1 || endpos > (1ll << 29)))
+        return fail(BSIG_ERR_FORMAT, "position %d (end %lld) cannot be addressed by a BAI index (0 .. 2^29)", r.pos, (long long)endpos);
+    if (bs > (1u << 28)) return fail(BSIG_ERR_FORMAT, "record too large");
+    b.resize(4 + bs);
     const int32_t bs32 = (int32_t)bs;
     const uint16_t bin = (uint16_t)reg2bin(std::max(r.pos, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)r.cigar.size();
     const int32_t lseq32 = (int32_t)l_seq;
@@ -1512,6 +1521,8 @@ int BamWriter::write_core(int32_t rid, int32_t pos, uint16_t flag, uint8_t mapq,
     }
     const int32_t bs = 32 + 2 + 4 * n_cigar;
     const int64_t endpos = (int64_t)pos + cigar_rlen(cigar, n_cigar, flag);
+    if (rid >= 0 && (pos < -1 || endpos > (1ll << 29)))
+        return fail(BSIG_ERR_FORMAT, "position %d (end %lld) cannot be addressed by a BAI index (0 .. 2^29)", pos, (long long)endpos);
     const uint16_t bin = (uint16_t)reg2bin(std::max(pos, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)n_cigar;
     const int32_t zero = 0, m1 = -1;
     memcpy(b, &bs, 4); memcpy(b + 4, &rid, 4); memcpy(b + 8, &pos, 4);
@@ -1544,7 +1555,8 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
     if (n == 0) return 0;
     // anything unusual takes the record-by-record path
     bool plain = W.ubuf.empty();
-    for (int64_t i = 0; i < n && plain; ++i) plain = cigar_off[i + 1] - cigar_off[i] <= 64 && cigar_off[i + 1] >= cigar_off[i];
+    for (int64_t i = 0; i < n && plain; ++i)
+        plain = cigar_off[i + 1] - cigar_off[i] <= 64 && cigar_off[i + 1] >= cigar_off[i] && pos[i] >= -1;
     if (!plain) {
         for (int r = 0; r < n_ref; ++r)
             for (int64_t i = ref_off[r]; i < ref_off[r + 1]; ++i) {
@@ -1601,6 +1613,7 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
                 const int32_t bs = 32 + 2 + 4 * nc, rid = r, p0 = pos[i], zero = 0, m1 = -1, tl = tlen[i];
                 const uint16_t fl = flag[i];
                 const int64_t endpos = (int64_t)p0 + cigar_rlen(cg, nc, fl);
+                if (endpos > (1ll << 29)) { err.store(2); return; }
                 const uint16_t bin = (uint16_t)reg2bin(std::max(p0, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)nc;
                 memcpy(b, &bs, 4); memcpy(b + 4, &rid, 4); memcpy(b + 8, &p0, 4);
                 b[12] = 2; b[13] = mapq[i];
@@ -1627,6 +1640,7 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
             memcpy(out + 22 + clen, &isz, 4);
             csize[(size_t)k] = (uint32_t)(clen + 26);
         });
+        if (err.load() == 2) return fail(BSIG_ERR_FORMAT, "a read ends beyond 2^29: a BAI index cannot address it");
         if (err.load()) return fail(BSIG_ERR_IO, "BGZF block does not fit");
         if (tim) { const double t = now_s(); t_par += t - t_mark; t_mark = t; }
         // in file order: the bytes, then the index entries of the batch's records

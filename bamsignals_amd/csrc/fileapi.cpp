@@ -679,6 +679,23 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
     return w.close();
 }
 
+// checkList / fastWidth (ref: src/CountSignals.cpp:4-29)
+int32_t bsig_check_list(int64_t n, const int32_t *is_int, const int32_t *n_dim, const int32_t *dim0, int32_t ss)
+{
+    if (n > 0 && (!is_int || (ss && (!n_dim || !dim0)))) return 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!is_int[i]) return 0;                                   // ref: :8
+        if (ss && (n_dim[i] != 2 || dim0[i] != 2)) return 0;        // ref: :11-12
+    }
+    return 1;
+}
+
+void bsig_fast_width(int64_t n, const int64_t *length, int32_t ss, int32_t *width)
+{
+    const int64_t div = ss ? 2 : 1;                                 // ref: :21
+    for (int64_t i = 0; i < n; ++i) width[i] = (int32_t)(length[i] / div);
+}
+
 int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off, int32_t *dst,
                           const int64_t *dst_off, const int64_t *which)
 {

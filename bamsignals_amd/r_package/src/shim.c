@@ -28,15 +28,40 @@ typedef struct {
 
 static SEXP slot(SEXP obj, const char *name) { return R_do_slot(obj, Rf_install(name)); }
 
-/* expands a factor-Rle (values = integer codes with "levels", lengths) to one code per range */
+/* a logical scalar argument: TRUE or FALSE.  (Rcpp's as<bool> turns NA into TRUE, an accident of
+ * NA_LOGICAL being a non-zero int; here NA is an argument error.) */
+static int flag_arg(SEXP x, const char *name)
+{
+    const int v = Rf_asLogical(x);
+    if (v != TRUE && v != FALSE) Rf_error("'%s' must be TRUE or FALSE", name);
+    return v == TRUE;
+}
+
+/* an integer scalar argument (NA is an argument error) */
+static int int_arg(SEXP x, const char *name)
+{
+    const int v = Rf_asInteger(x);
+    if (v == NA_INTEGER) Rf_error("'%s' must be a single integer", name);
+    return v;
+}
+
+/* expands a factor-Rle (values = integer codes with "levels", lengths) to one code per range
+ * (ref: RleIter, src/bamsignals.cpp:55-89) */
 static void expand_rle(SEXP rle, R_xlen_t n, int *out, SEXP *levels_out)
 {
     SEXP values = slot(rle, "values"), lengths = slot(rle, "lengths");
-    *levels_out = Rf_getAttrib(values, R_LevelsSymbol);
+    SEXP levels = Rf_getAttrib(values, R_LevelsSymbol);
+    if (TYPEOF(values) != INTSXP || TYPEOF(lengths) != INTSXP || TYPEOF(levels) != STRSXP ||
+        XLENGTH(values) != XLENGTH(lengths))
+        Rf_error("malformed Rle in the GRanges object (seqnames and strand must be factor-Rle)");
+    *levels_out = levels;
     const int *v = INTEGER(values), *l = INTEGER(lengths);
-    R_xlen_t k = 0, nrun = XLENGTH(values);
-    for (R_xlen_t r = 0; r < nrun; ++r)
+    const R_xlen_t nrun = XLENGTH(values), n_lev = XLENGTH(levels);
+    R_xlen_t k = 0;
+    for (R_xlen_t r = 0; r < nrun; ++r) {
+        if (v[r] < 1 || v[r] > n_lev || l[r] < 0) Rf_error("malformed Rle in the GRanges object");
         for (int j = 0; j < l[r] && k < n; ++j) out[k++] = v[r] - 1;
+    }
     if (k != n) Rf_error("malformed Rle in the GRanges object");
 }
 
@@ -45,6 +70,8 @@ static void flatten(SEXP gr, flat_ranges *f)
     if (!Rf_inherits(gr, "GRanges")) Rf_error("must provide a GRanges object");   /* ref :93-94 */
     SEXP ranges = slot(gr, "ranges");
     SEXP start = slot(ranges, "start"), width = slot(ranges, "width");
+    if (TYPEOF(start) != INTSXP || TYPEOF(width) != INTSXP || XLENGTH(start) != XLENGTH(width))
+        Rf_error("malformed ranges in the GRanges object");
     f->n = XLENGTH(start);
     f->start = INTEGER(start);
     f->width = INTEGER(width);
@@ -107,12 +134,20 @@ static int32_t *tlen_vec(SEXP x, int *n, SEXP *keep)
     return INTEGER(*keep);
 }
 
+static const char *path_arg(SEXP x, const char *name)
+{
+    if (TYPEOF(x) != STRSXP || XLENGTH(x) != 1) Rf_error("'%s' must be a single string", name);
+    return CHAR(STRING_ELT(x, 0));
+}
+
 SEXP bamsignals_pileup_core(SEXP bampath, SEXP gr, SEXP tlen_filter, SEXP mapqual, SEXP binsize,
                             SEXP shift, SEXP ss, SEXP requiredF, SEXP filteredF, SEXP pe_mid, SEXP maxgap)
 {
     flat_ranges f;
     flatten(gr, &f);
-    const int bs = Rf_asInteger(binsize), strand_specific = Rf_asLogical(ss) == TRUE;
+    const int bs = int_arg(binsize, "binsize"), strand_specific = flag_arg(ss, "ss");
+    const int mid = flag_arg(pe_mid, "pe_mid");
+    const char *path = path_arg(bampath, "bampath");
     SEXP keep;
     int ntf;
     int32_t *tf = tlen_vec(tlen_filter, &ntf, &keep);
@@ -120,11 +155,11 @@ SEXP bamsignals_pileup_core(SEXP bampath, SEXP gr, SEXP tlen_filter, SEXP mapqua
     const int64_t cells = bsig_layout(f.n, f.width, bs, strand_specific, off);
     /* R_alloc'ed: released by R when the .Call returns, also on an R error (no leak on longjmp) */
     int32_t *flat = (int32_t *)R_alloc((size_t)(cells > 0 ? cells : 1), sizeof(int32_t));
-    const int rc = bsig_pileup_core(CHAR(STRING_ELT(bampath, 0)), f.n, f.seq_code, f.n_levels, f.levels,
-                                    f.start, f.width, f.strand, tf, ntf, Rf_asInteger(mapqual), bs,
-                                    Rf_asInteger(shift), strand_specific, Rf_asInteger(requiredF),
-                                    Rf_asInteger(filteredF), Rf_asLogical(pe_mid) == TRUE,
-                                    Rf_asInteger(maxgap), -1, flat, off);
+    const int rc = bsig_pileup_core(path, f.n, f.seq_code, f.n_levels, f.levels,
+                                    f.start, f.width, f.strand, tf, ntf, int_arg(mapqual, "mapqual"), bs,
+                                    int_arg(shift, "shift"), strand_specific, int_arg(requiredF, "requiredF"),
+                                    int_arg(filteredF, "filteredF"), mid,
+                                    int_arg(maxgap, "maxgap"), -1, flat, off);
     if (rc != BSIG_OK) Rf_error("%s", bsig_last_error());
     SEXP res;
     if (bs <= 0) {                                    /* bamCount: list(vector) or list(2 x n) (ref :148-169) */
@@ -145,6 +180,8 @@ SEXP bamsignals_coverage_core(SEXP bampath, SEXP gr, SEXP tlen_filter, SEXP mapq
 {
     flat_ranges f;
     flatten(gr, &f);
+    const int span = flag_arg(tspan, "tspan");
+    const char *path = path_arg(bampath, "bampath");
     SEXP keep;
     int ntf;
     int32_t *tf = tlen_vec(tlen_filter, &ntf, &keep);
@@ -152,39 +189,46 @@ SEXP bamsignals_coverage_core(SEXP bampath, SEXP gr, SEXP tlen_filter, SEXP mapq
     const int64_t cells = bsig_layout(f.n, f.width, 1, 0, off);
     /* R_alloc'ed: released by R when the .Call returns, also on an R error (no leak on longjmp) */
     int32_t *flat = (int32_t *)R_alloc((size_t)(cells > 0 ? cells : 1), sizeof(int32_t));
-    const int rc = bsig_coverage_core(CHAR(STRING_ELT(bampath, 0)), f.n, f.seq_code, f.n_levels, f.levels,
-                                      f.start, f.width, f.strand, tf, ntf, Rf_asInteger(mapqual),
-                                      Rf_asInteger(requiredF), Rf_asInteger(filteredF),
-                                      Rf_asLogical(tspan) == TRUE, Rf_asInteger(maxgap), -1, flat, off);
+    const int rc = bsig_coverage_core(path, f.n, f.seq_code, f.n_levels, f.levels,
+                                      f.start, f.width, f.strand, tf, ntf, int_arg(mapqual, "mapqual"),
+                                      int_arg(requiredF, "requiredF"), int_arg(filteredF, "filteredF"),
+                                      span, int_arg(maxgap, "maxgap"), -1, flat, off);
     if (rc != BSIG_OK) Rf_error("%s", bsig_last_error());
     SEXP res = PROTECT(wrap_signals(flat, off, f.n, 0));
     UNPROTECT(2);
     return res;
 }
 
-/* checkList (ref: src/CountSignals.cpp:4-16) */
+/* checkList (ref: src/CountSignals.cpp:4-16): what R knows about every element goes to the native
+ * check as flat arrays */
 SEXP bamsignals_checkList(SEXP l, SEXP ss)
 {
-    const int strand_specific = Rf_asLogical(ss) == TRUE;
+    const int strand_specific = flag_arg(ss, "ss");
+    if (TYPEOF(l) != VECSXP) Rf_error("'signals' must be a list");
     const R_xlen_t n = XLENGTH(l);
+    int32_t *is_int = (int32_t *)R_alloc((size_t)n + 1, sizeof(int32_t));
+    int32_t *n_dim = (int32_t *)R_alloc((size_t)n + 1, sizeof(int32_t));
+    int32_t *dim0 = (int32_t *)R_alloc((size_t)n + 1, sizeof(int32_t));
     for (R_xlen_t i = 0; i < n; ++i) {
         SEXP el = VECTOR_ELT(l, i);
-        if (TYPEOF(el) != INTSXP) return Rf_ScalarLogical(FALSE);
-        if (strand_specific) {
-            SEXP d = Rf_getAttrib(el, R_DimSymbol);
-            if (TYPEOF(d) != INTSXP || XLENGTH(d) != 2 || INTEGER(d)[0] != 2) return Rf_ScalarLogical(FALSE);
-        }
+        SEXP d = Rf_getAttrib(el, R_DimSymbol);
+        is_int[i] = TYPEOF(el) == INTSXP;
+        n_dim[i] = TYPEOF(d) == INTSXP ? (int32_t)XLENGTH(d) : 0;
+        dim0[i] = n_dim[i] > 0 ? INTEGER(d)[0] : 0;
     }
-    return Rf_ScalarLogical(TRUE);
+    return Rf_ScalarLogical(bsig_check_list(n, is_int, n_dim, dim0, strand_specific) ? TRUE : FALSE);
 }
 
 /* fastWidth (ref: src/CountSignals.cpp:19-29) */
 SEXP bamsignals_fastWidth(SEXP l, SEXP ss)
 {
-    const int div = Rf_asLogical(ss) == TRUE ? 2 : 1;
+    const int strand_specific = flag_arg(ss, "ss");
+    if (TYPEOF(l) != VECSXP) Rf_error("'signals' must be a list");
     const R_xlen_t n = XLENGTH(l);
+    int64_t *len = (int64_t *)R_alloc((size_t)n + 1, sizeof(int64_t));
+    for (R_xlen_t i = 0; i < n; ++i) len[i] = (int64_t)XLENGTH(VECTOR_ELT(l, i));
     SEXP w = PROTECT(Rf_allocVector(INTSXP, n));
-    for (R_xlen_t i = 0; i < n; ++i) INTEGER(w)[i] = (int)(XLENGTH(VECTOR_ELT(l, i)) / div);
+    bsig_fast_width(n, len, strand_specific, INTEGER(w));
     UNPROTECT(1);
     return w;
 }
@@ -192,7 +236,7 @@ SEXP bamsignals_fastWidth(SEXP l, SEXP ss)
 /* writeSamAsBamAndIndex (ref: src/bamsignals.cpp:496-534) */
 SEXP bamsignals_writeSamAsBamAndIndex(SEXP sampath, SEXP bampath)
 {
-    if (bsig_write_sam_as_bam_and_index(CHAR(STRING_ELT(sampath, 0)), CHAR(STRING_ELT(bampath, 0))) != BSIG_OK)
+    if (bsig_write_sam_as_bam_and_index(path_arg(sampath, "sampath"), path_arg(bampath, "bampath")) != BSIG_OK)
         Rf_error("%s", bsig_last_error());
     return Rf_ScalarLogical(TRUE);
 }

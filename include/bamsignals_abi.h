@@ -56,6 +56,15 @@ const char *bsig_last_error(void);
  * ------------------------------------------------------------------------------------------ */
 int64_t bsig_layout(int64_t n, const int32_t *len, int32_t binsize, int32_t ss, int64_t *off);
 
+/* checkList (ref: src/CountSignals.cpp:4-16): is a list of n signals a valid `signals` slot?  The
+ * caller reports per element whether it is an integer vector (INTSXP), how long its `dim` attribute is
+ * (0: none) and dim[0].  Valid: every element an integer vector and, if ss, a matrix (2 dims) with 2
+ * rows.  Returns 1 (valid) or 0.                                                                */
+int32_t bsig_check_list(int64_t n, const int32_t *is_int, const int32_t *n_dim, const int32_t *dim0,
+                        int32_t ss);
+/* fastWidth (ref: src/CountSignals.cpp:19-29): width[i] = length[i] / (ss ? 2 : 1)              */
+void bsig_fast_width(int64_t n, const int64_t *length, int32_t ss, int32_t *width);
+
 /* ------------------------------------------------------------------------------------------
  * Device context: one per GPU (and per host thread that drives it).
  * stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create one.

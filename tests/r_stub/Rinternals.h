@@ -1,9 +1,15 @@
 /* TEST-ONLY declarations of the handful of R C-API names r_package/src/shim.c uses, so that the
- * shim can be syntax- and type-checked with gcc in an image that has no R (tests/test_r_shim.py).
- * This is not R, it is never linked, and nothing is built against it for use: the real build is
- * `R CMD INSTALL` against the real <Rinternals.h>. */
+ * shim can be compiled in an image that has no R.  Two uses (tests/test_r_shim.py):
+ *   - a type check of shim.c with gcc -fsyntax-only -Werror;
+ *   - tests/r_stub/r_mock.c implements these names as a SMALL STAND-IN RUNTIME (tagged vectors,
+ *     attributes, S4 slots, a protect stack with an allocation-time reachability check in the
+ *     spirit of gctorture, R_alloc arenas, Rf_error as a longjmp), so that the shim's .Call routines
+ *     can be EXECUTED against the real libbamsignals_hip.so from Python.
+ * This is not R and nothing shipped is built against it: the real build is `R CMD INSTALL` against
+ * the real <Rinternals.h>. */
 #ifndef BSIG_TEST_RINTERNALS_STUB_H
 #define BSIG_TEST_RINTERNALS_STUB_H
+#include <limits.h>
 #include <stddef.h>
 typedef struct SEXPREC *SEXP;
 typedef ptrdiff_t R_xlen_t;
@@ -12,7 +18,9 @@ typedef int Rboolean;
 #define TRUE 1
 #define FALSE 0
 #endif
-enum { INTSXP = 13, STRSXP = 16, VECSXP = 19 };
+#define NA_INTEGER INT_MIN
+#define NA_LOGICAL INT_MIN
+enum { NILSXP = 0, SYMSXP = 1, CHARSXP = 9, LGLSXP = 10, INTSXP = 13, REALSXP = 14, STRSXP = 16, VECSXP = 19, S4SXP = 25 };
 extern SEXP R_NilValue, R_DimSymbol, R_DimNamesSymbol, R_LevelsSymbol;
 SEXP R_do_slot(SEXP, SEXP);
 SEXP Rf_install(const char *);
