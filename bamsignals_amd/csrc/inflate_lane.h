@@ -2,11 +2,11 @@
 // BGZF block (a BAM holds tens of thousands of independent blocks of <= 64 KiB: that, not the bits
 // inside a block, is where the parallelism is).  Written for lanes that march together:
 //
-//   * Huffman decoding: a 9-bit (literal/length) and a 6-bit (distance) first-level table answer
-//     nearly every symbol with one 16-bit lookup; longer codes fall back to the canonical walk over
-//     the code lengths (per length the NUMBER of codes, packed two per register, and the symbols
-//     sorted by (length, value): an unrolled compare chain, then one lookup).  936 bytes per lane
-//     (LDS on the device), where zlib-style two-level tables need 5.7 KB;
+//   * Huffman decoding: an 8-bit (literal/length, 16-bit entries) and a 5-bit (distance, byte
+//     entries) first-level table answer nearly every symbol with one lookup; longer codes fall back
+//     to the canonical walk over the code lengths (per length the NUMBER of codes, packed two per
+//     register, and the symbols sorted by (length, value): an unrolled compare chain, then one
+//     lookup).  964 bytes per lane (LDS on the device), where zlib-style two-level tables need 5.7 KB;
 //   * per turn of the main loop one symbol (up to six if they are literals the first-level table
 //     knows) OR a slice of a pending match: a lane that copies a 258-byte match does not hold the
 //     other lanes of its wave for 258 turns;
@@ -119,6 +119,8 @@ BSIG_HD uint32_t take(BitIn &in, int n)
 BSIG_HD int count_of(const Counts &c, int len) { return (int)((c.w[len >> 1] >> ((len & 1) * 16)) & 0xFFFFu); }
 
 // one symbol of a canonical code by the walk over the code lengths; needs 15 valid bits.  -1: no such code
+// (the published algorithm of zlib's contrib/puff/puff.c -- first code, count and index of every
+// length -- with the per-length counts packed two per register)
 template <typename Syms>
 BSIG_HD int decode_walk(BitIn &in, const Counts &c, const Syms &sym)
 {

@@ -172,3 +172,25 @@ void R_init_bamsignals(DllInfo *info) { R_registerRoutines(info, NULL, m, NULL, 
     with pytest.raises(r_mock.RViolation, match="imbalance"):
         Rb.call("bad_imbalance", Rb.int([1]), Rb.int([2]))
     assert Rb.to_py(Rb.call("good", Rb.int([1]), Rb.int([2])))[0].tolist() == [0, 0]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference checkout is only present in the build container")
+def test_graft_script_swaps_only_the_native_half(tmp_path):
+    """r_package/graft_into_reference.sh on a scratch copy of the reference: R/, man/, tests/ untouched,
+    src/ = shim.c + Makevars, Rcpp/Rhtslib gone from DESCRIPTION/NAMESPACE, and the grafted shim registers
+    the names R/RcppExports.R calls."""
+    import filecmp
+    import re
+    import shutil
+    ref = tmp_path / "bamsignals"
+    shutil.copytree("/root/reference", ref)
+    subprocess.check_call(["sh", os.path.join(ROOT, "bamsignals_amd", "r_package", "graft_into_reference.sh"), str(ref), ROOT])
+    assert sorted(os.listdir(ref / "src")) == ["Makevars", "shim.c"]
+    for sub in ("R", "man", "vignettes", "inst"):
+        cmp = filecmp.dircmp("/root/reference/" + sub, ref / sub)
+        assert not cmp.diff_files and not cmp.left_only and not cmp.right_only, sub
+    assert "Rcpp" not in (ref / "NAMESPACE").read_text() and "Rhtslib" not in (ref / "DESCRIPTION").read_text()
+    called = set(re.findall(r"\.Call\('(bamsignals_\w+)'", (ref / "R" / "RcppExports.R").read_text()))
+    registered = set(re.findall(r'\{"(bamsignals_\w+)", \(DL_FUNC\)', (ref / "src" / "shim.c").read_text()))
+    assert called == registered and len(called) == 5
+    assert {"test_methods.R", "test_CountSignals.R", "test_golden.R", "test_vignette_invariants.R"} <= set(os.listdir(ref / "tests" / "testthat"))
