@@ -134,6 +134,8 @@ def load():
     lib.bsig_write_sam_as_bam_and_index.argtypes = [C.c_char_p, C.c_char_p]
     lib.bsig_write_columns_as_bam.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Columns),
                                               C.c_int32]
+    lib.bsig_write_columns_as_bam_with_seq.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Columns),
+                                                       C.c_int32, C.c_int32, C.c_uint64]
     lib.bsig_cache_clear.restype = None
     lib.bsig_last_call_timing.argtypes = [C.POINTER(C.c_double)]
     lib.bsig_last_call_timing.restype = None

@@ -70,8 +70,10 @@ class BamFile:
         self.close()
 
 
-def write_columns_as_bam(path, ref_names, cols, level=1):
-    """Coordinate-sorted columns (ref_len, ref_off, pos, flag, mapq, tlen, cigar_off, cigar) -> BAM + BAI."""
+def write_columns_as_bam(path, ref_names, cols, level=1, l_seq=0, seed=0):
+    """Coordinate-sorted columns (ref_len, ref_off, pos, flag, mapq, tlen, cigar_off, cigar) -> BAM + BAI.
+    ``l_seq > 0``: real-shaped records (read name, ``l_seq`` random bases + qualities, an NM tag) instead
+    of bare ones, for decode benchmarks on data shaped like real BAMs."""
     lib = _lib.load()
     keep = dict(ref_len=np.ascontiguousarray(cols["ref_len"], dtype=np.int32),
                 ref_off=np.ascontiguousarray(cols["ref_off"], dtype=np.int64),
@@ -87,8 +89,12 @@ def write_columns_as_bam(path, ref_names, cols, level=1):
     for k, a in keep.items():
         setattr(c, k, a.ctypes.data)
     names = (C.c_char_p * len(ref_names))(*[str(s).encode() for s in ref_names])
-    _lib.check(lib.bsig_write_columns_as_bam(os.path.expanduser(str(path)).encode(), len(ref_names), names,
-                                             C.byref(c), int(level)))
+    if l_seq:
+        _lib.check(lib.bsig_write_columns_as_bam_with_seq(os.path.expanduser(str(path)).encode(), len(ref_names), names,
+                                                          C.byref(c), int(level), int(l_seq), int(seed)))
+    else:
+        _lib.check(lib.bsig_write_columns_as_bam(os.path.expanduser(str(path)).encode(), len(ref_names), names,
+                                                 C.byref(c), int(level)))
 
 
 def writeSamAsBamAndIndex(sampath, bampath):

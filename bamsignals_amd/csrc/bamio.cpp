@@ -1545,11 +1545,30 @@ int BamWriter::write_core(int32_t rid, int32_t pos, uint16_t flag, uint8_t mapq,
 
 // The columnar fast path for whole files: the same bytes write_core() produces record by record
 // (same block cuts, same index), with the BGZF blocks built and deflated by the worker pool.
+namespace {
+inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// 64 quality values with the histogram of clip(round(40 - |N(0, 6)|), 2, 41): mostly 36-40 with a tail,
+// about 3 bits per base like binned Illumina qualities
+const uint8_t kQualTable[64] = {40, 40, 40, 40, 40, 39, 39, 39, 39, 39, 39, 39, 39, 38, 38, 38, 38, 38, 38, 38, 37, 37,
+                                37, 37, 37, 37, 36, 36, 36, 36, 36, 36, 35, 35, 35, 35, 35, 34, 34, 34, 34, 33, 33, 33,
+                                33, 32, 32, 32, 31, 31, 31, 30, 30, 29, 29, 28, 28, 27, 26, 25, 24, 22, 19, 12};
+}  // namespace
+
 int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_t *pos, const uint16_t *flag,
                              const uint8_t *mapq, const int32_t *tlen, const int64_t *cigar_off,
-                             const uint32_t *cigar, int threads)
+                             const uint32_t *cigar, int threads, int l_seq, uint64_t seed)
 {
     Impl &W = *p_;
+    if (l_seq < 0 || l_seq > 4096) return fail(BSIG_ERR_ARG, "l_seq must be 0 .. 4096");
+    // bytes of a record with nc CIGAR operations: bare (name "*", no sequence: 52 bytes for one
+    // operation) or real-shaped (read name, l_seq bases + qualities, an NM tag: 204 bytes for 100 bp)
+    const size_t fixed = l_seq ? 4 + 32 + 10 + (size_t)(l_seq + 1) / 2 + (size_t)l_seq + 4 : 38;
     if (n_ref > W.n_ref) return fail(BSIG_ERR_FORMAT, "columns with %d references but the header has %d", n_ref, W.n_ref);
     const int64_t n = n_ref > 0 ? ref_off[n_ref] : 0;
     if (n == 0) return 0;
@@ -1557,6 +1576,7 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
     bool plain = W.ubuf.empty();
     for (int64_t i = 0; i < n && plain; ++i)
         plain = cigar_off[i + 1] - cigar_off[i] <= 64 && cigar_off[i + 1] >= cigar_off[i] && pos[i] >= -1;
+    if (!plain && l_seq) return fail(BSIG_ERR_ARG, "synthetic sequences need at most 64 CIGAR operations per read");
     if (!plain) {
         for (int r = 0; r < n_ref; ++r)
             for (int64_t i = ref_off[r]; i < ref_off[r + 1]; ++i) {
@@ -1572,7 +1592,7 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
         size_t fill = 0;
         first.push_back(0);
         for (int64_t i = 0; i < n; ++i) {
-            const size_t len = 38 + 4 * (size_t)(cigar_off[i + 1] - cigar_off[i]);
+            const size_t len = fixed + 4 * (size_t)(cigar_off[i + 1] - cigar_off[i]);
             if (fill + len > Impl::kBlockData && fill) { first.push_back(i); fill = 0; }
             fill += len;
             if (fill == Impl::kBlockData && i + 1 < n) { first.push_back(i + 1); fill = 0; }
@@ -1609,19 +1629,52 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
                 r = rid_of(i, r);
                 const int nc = (int)(cigar_off[i + 1] - cigar_off[i]);
                 const uint32_t *cg = cigar + cigar_off[i];
-                uint8_t b[4 + 32 + 2 + 4 * 64];
-                const int32_t bs = 32 + 2 + 4 * nc, rid = r, p0 = pos[i], zero = 0, m1 = -1, tl = tlen[i];
+                uint8_t b[4 + 32 + 10 + 4 * 64];
+                const int32_t bs = (int32_t)(fixed - 4) + 4 * nc, rid = r, p0 = pos[i], zero = 0, m1 = -1, tl = tlen[i];
                 const uint16_t fl = flag[i];
                 const int64_t endpos = (int64_t)p0 + cigar_rlen(cg, nc, fl);
                 if (endpos > (1ll << 29)) { err.store(2); return; }
                 const uint16_t bin = (uint16_t)reg2bin(std::max(p0, 0), std::max<int64_t>(endpos, 1)), ncig = (uint16_t)nc;
                 memcpy(b, &bs, 4); memcpy(b + 4, &rid, 4); memcpy(b + 8, &p0, 4);
-                b[12] = 2; b[13] = mapq[i];
+                b[13] = mapq[i];
                 memcpy(b + 14, &bin, 2); memcpy(b + 16, &ncig, 2); memcpy(b + 18, &fl, 2);
-                memcpy(b + 20, &zero, 4); memcpy(b + 24, &m1, 4); memcpy(b + 28, &m1, 4); memcpy(b + 32, &tl, 4);
-                b[36] = '*'; b[37] = 0;
-                if (nc) memcpy(b + 38, cg, 4 * (size_t)nc);
-                u.insert(u.end(), b, b + 4 + bs);
+                memcpy(b + 24, &m1, 4); memcpy(b + 28, &m1, 4); memcpy(b + 32, &tl, 4);
+                if (!l_seq) {
+                    b[12] = 2;
+                    memcpy(b + 20, &zero, 4);
+                    b[36] = '*'; b[37] = 0;
+                    if (nc) memcpy(b + 38, cg, 4 * (size_t)nc);
+                    u.insert(u.end(), b, b + 4 + bs);
+                    continue;
+                }
+                // real-shaped: "q" + 8 hex digits, random bases (4-bit codes of A C G T), qualities from
+                // kQualTable, NM:C -- all from a counter-based generator, so the file depends on (seed, i) only
+                b[12] = 10;
+                memcpy(b + 20, &l_seq, 4);
+                static const char hexd[] = "0123456789abcdef";
+                b[36] = 'q';
+                for (int d = 0; d < 8; ++d) b[37 + d] = (uint8_t)hexd[((uint64_t)i >> (4 * (7 - d))) & 15];
+                b[45] = 0;
+                if (nc) memcpy(b + 46, cg, 4 * (size_t)nc);
+                u.insert(u.end(), b, b + 46 + 4 * nc);
+                const size_t at = u.size();
+                u.resize(at + (size_t)(l_seq + 1) / 2 + (size_t)l_seq + 4);
+                uint8_t *sq = u.data() + at, *ql = sq + (l_seq + 1) / 2;
+                uint64_t ctr = seed ^ ((uint64_t)i * 0xD1342543DE82EF95ull);
+                for (int k = 0; k < (l_seq + 1) / 2; k += 16) {          // 16 bytes = 32 bases per draw
+                    const uint64_t rnd = splitmix64(ctr++);
+                    for (int q = 0; q < 16 && k + q < (l_seq + 1) / 2; ++q) {
+                        const unsigned two = (unsigned)(rnd >> (4 * q)) & 15u;
+                        sq[k + q] = (uint8_t)((1u << (two & 3)) << 4 | (1u << (two >> 2)));
+                    }
+                }
+                if (l_seq & 1) sq[l_seq / 2] &= 0xF0;
+                for (int k = 0; k < l_seq; k += 10) {                    // 6 bits per quality
+                    const uint64_t rnd = splitmix64(ctr++);
+                    for (int q = 0; q < 10 && k + q < l_seq; ++q) ql[k + q] = kQualTable[(rnd >> (6 * q)) & 63];
+                }
+                uint8_t *aux = ql + l_seq;
+                aux[0] = 'N'; aux[1] = 'M'; aux[2] = 'C'; aux[3] = (uint8_t)(splitmix64(ctr) % 5);
             }
             uint8_t *out = cbuf.data() + (size_t)k * kSlot;
             size_t clen = dfl->run(u.data(), u.size(), out + 18, 0x10000 - 18 - 8);
@@ -1653,7 +1706,7 @@ int BamWriter::write_columns(int32_t n_ref, const int64_t *ref_off, const int32_
             for (int64_t i = i0; i < i1; ++i) {
                 r_cur = rid_of(i, r_cur);
                 const int nc = (int)(cigar_off[i + 1] - cigar_off[i]);
-                const size_t len = 38 + 4 * (size_t)nc;
+                const size_t len = fixed + 4 * (size_t)nc;
                 if (r_cur < W.last_rid || (r_cur == W.last_rid && pos[i] < W.last_pos)) W.sorted = false;
                 W.last_rid = r_cur; W.last_pos = pos[i];
                 const int64_t endpos = (int64_t)pos[i] + cigar_rlen(cigar + cigar_off[i], nc, flag[i]);

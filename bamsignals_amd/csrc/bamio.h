@@ -162,9 +162,11 @@ public:
                    const uint32_t *cigar, int n_cigar);
     // a whole coordinate-sorted file from columns: write_core() for every read, with the BGZF blocks
     // built and deflated by the worker pool (same bytes as the record-by-record calls)
+    // l_seq > 0: real-shaped records instead of bare ones -- a read name, l_seq random bases and
+    // qualities, an NM tag (204 bytes for 100 bp) -- generated from (seed, read index)
     int write_columns(int32_t n_ref, const int64_t *ref_off, const int32_t *pos, const uint16_t *flag,
                       const uint8_t *mapq, const int32_t *tlen, const int64_t *cigar_off,
-                      const uint32_t *cigar, int threads);
+                      const uint32_t *cigar, int threads, int l_seq = 0, uint64_t seed = 0);
     int close();                              // flushes, writes EOF block and <path>.bai
 private:
     struct Impl;

@@ -648,8 +648,24 @@ int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath)
     return bsig::sam_to_bam_and_index(sampath, bampath);
 }
 
+static int write_columns_impl(const char *bampath, int32_t n_ref, const char *const *ref_names, const bsig_columns *c,
+                              int32_t level, int32_t l_seq, uint64_t seed);
+
 int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *const *ref_names,
                               const bsig_columns *c, int32_t level)
+{
+    return write_columns_impl(bampath, n_ref, ref_names, c, level, 0, 0);
+}
+
+int bsig_write_columns_as_bam_with_seq(const char *bampath, int32_t n_ref, const char *const *ref_names,
+                                       const bsig_columns *c, int32_t level, int32_t l_seq, uint64_t seed)
+{
+    if (l_seq <= 0) return fail(BSIG_ERR_ARG, "l_seq must be positive");
+    return write_columns_impl(bampath, n_ref, ref_names, c, level, l_seq, seed);
+}
+
+static int write_columns_impl(const char *bampath, int32_t n_ref, const char *const *ref_names, const bsig_columns *c,
+                              int32_t level, int32_t l_seq, uint64_t seed)
 {
     if (!bampath || !c || (n_ref > 0 && !ref_names)) return fail(BSIG_ERR_ARG, "NULL argument");
     if (c->n_ref != n_ref) return fail(BSIG_ERR_ARG, "n_ref does not match the columns");
@@ -665,7 +681,7 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
     int rc = w.open(bampath, h, level > 0 ? level : 1);
     if (rc) return rc;
     const char *how = getenv("BAMSIGNALS_WRITER");      // "serial": record by record (testing)
-    if (how && !strcmp(how, "serial")) {
+    if (how && !strcmp(how, "serial") && !l_seq) {
         for (int r = 0; r < n_ref; ++r)
             for (int64_t i = c->ref_off[r]; i < c->ref_off[r + 1]; ++i) {
                 rc = w.write_core(r, c->pos[i], c->flag[i], c->mapq[i], c->tlen[i], c->cigar + c->cigar_off[i],
@@ -673,7 +689,7 @@ int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *co
                 if (rc) return rc;
             }
     } else {
-        rc = w.write_columns(n_ref, c->ref_off, c->pos, c->flag, c->mapq, c->tlen, c->cigar_off, c->cigar, 0);
+        rc = w.write_columns(n_ref, c->ref_off, c->pos, c->flag, c->mapq, c->tlen, c->cigar_off, c->cigar, 0, l_seq, seed);
         if (rc) return rc;
     }
     return w.close();

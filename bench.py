@@ -130,6 +130,69 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def end_to_end_realistic(seed, device, oracle_c):
+    """Informational: the cold file-level call on a BAM shaped like real data -- 2e7 single-end 100-bp
+    reads on 250 Mbp WITH read names, bases, qualities and an NM tag (204-byte records, 4 GB of stream
+    that compresses about 1.9 : 1), 10k x 2 kb ranges -- under both inflate engines, next to the same
+    single-thread CPU path as above.  The bench's own BAM carries bare 52-byte records (SURVEY 8d);
+    this is what the decode stage costs on literal-heavy DEFLATE blocks."""
+    import shutil
+    import tempfile
+
+    from bamsignals_amd import GRanges, _lib
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from bamsignals_amd.wrappers import last_call_route, last_call_timing, pileup_core
+    from bamsignals_amd.device import Reads
+    ref_len, n_reads, l_seq = [250_000_000], 20_000_000, 100
+    d = tempfile.mkdtemp(prefix="bsig_bench_real_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        cols = synth_reads(n_reads, ref_len, seed=seed + 77, with_cigar=True)
+        bam = os.path.join(d, "real.bam")
+        t0 = time.perf_counter(); write_columns_as_bam(bam, ["ref1"], cols, level=1, l_seq=l_seq, seed=seed); t_write = time.perf_counter() - t0
+        rg = synth_ranges(10_000, 2000, ref_len, seed=seed + 78)
+        gr = GRanges(["ref1"] * len(rg["rid"]), rg["loc"] + 1, width=rg["len"], strand=[{1: "+", -1: "-", 0: "*"}[int(x)] for x in rg["strand"]])
+        orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+        want, _ = oracle_c.pileup_core(orc, rg, binsize=1)
+        del orc
+        out = dict(bam_bytes=os.path.getsize(bam), reads=n_reads, record_bytes=108 + l_seq - 4, write_bam_s=t_write,
+                   workload=f"bamProfile binsize=1, 10k x 2kb ranges, {n_reads:.0e} SE {l_seq}-bp reads with names, bases, qualities")
+        bases = int(rg["len"].astype(np.int64).sum())
+        old = os.environ.get("BAMSIGNALS_INFLATE")
+        for eng in ("default", "gpu", "cpu"):
+            if eng == "default":
+                os.environ.pop("BAMSIGNALS_INFLATE", None)
+            else:
+                os.environ["BAMSIGNALS_INFLATE"] = eng
+            _lib.load().bsig_cache_clear()
+            t0 = time.perf_counter(); sig = pileup_core(bam, gr, (), device=device); t_cold = time.perf_counter() - t0
+            if not np.array_equal(np.concatenate(sig), want):
+                raise SystemExit("file-level result on the real-shaped BAM differs from the oracle")
+            dd = Reads.device_decode_timing()
+            out["cold_" + eng] = dict(call_s=t_cold, Mbases_s=bases / t_cold / 1e6, stages_s=last_call_timing(),
+                                      decode_stages_s=dd, route=last_call_route())
+        if old is None:
+            os.environ.pop("BAMSIGNALS_INFLATE", None)
+        else:
+            os.environ["BAMSIGNALS_INFLATE"] = old
+        _lib.load().bsig_cache_clear()
+        b = BamFile(bam)
+        dec = b.decode(threads=1)
+        t_dec1 = b.decode_timing()["total"]
+        del dec
+        b.decode(threads=0)
+        t_decN = b.decode_timing()["total"]
+        b.close()
+        out["cpu_decode_1_thread_s"] = t_dec1
+        out["cpu_decode_all_threads_s"] = t_decN
+        out["vs_cpu_path_cold"] = (t_dec1 + 0.0) / out["cold_default"]["call_s"]
+        out["note"] = ("cold call under the cost model's engine choice and with each engine forced; vs_cpu_path_cold = "
+                       "single-thread CPU decode alone / cold call (the pileup itself is 0.05 s on one core at this size)")
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 class Workload:
     """One configuration resident on the GPU: reads, `nb` distinct range batches, their plans and
     result buffers."""
@@ -297,6 +360,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the informational end-to-end section (the workload as a BAM on disk -> host result, "
                          "next to the single-thread CPU path incl. BAM decode); it runs at N=1")
+    ap.add_argument("--no-realistic", action="store_true",
+                    help="skip the end-to-end section on a BAM with read names, bases and qualities")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary kernel-only measurement of config 2")
     ap.add_argument("--seed", type=int, default=0xBA51)
     a = ap.parse_args()
@@ -479,6 +544,13 @@ def main():
             except Exception as exc:      # e.g. no room for the BAM on local disk: the metric does not depend on it
                 res["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
         del cols, want_flat
+        if cpu is not None and not a.no_e2e and not a.no_realistic:
+            try:
+                res["end_to_end_realistic"] = end_to_end_realistic(a.seed, local, oracle_c)
+                log("end_to_end_realistic: " + ", ".join(f"{k[5:]} {v['call_s']:.3f} s" for k, v in res["end_to_end_realistic"].items()
+                                                        if k.startswith("cold_")))
+            except Exception as exc:
+                res["end_to_end_realistic"] = {"error": f"{type(exc).__name__}: {exc}"}
         if a.config != "C2" and not a.no_also and not (a.reads or a.ranges or a.width):
             w2 = Workload(a, "C2", 0, 1, local, stream)
             k2 = max(a.steps, 200)

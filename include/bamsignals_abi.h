@@ -272,6 +272,12 @@ int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath);
 /* columnar writer used for synthetic BAMs: coordinate-sorted columns -> BAM + BAI             */
 int bsig_write_columns_as_bam(const char *bampath, int32_t n_ref, const char *const *ref_names,
                               const bsig_columns *cols, int32_t level);
+/* the same with real-shaped records: a read name, l_seq random bases and qualities (about 3 bits of
+ * entropy per quality, like binned Illumina data), an NM tag -- 204 bytes per 100-bp read instead of
+ * 52, literal-heavy DEFLATE blocks that compress about 2 : 1.  For benchmarks of the decode stage on
+ * data shaped like real BAMs; the alignment columns are the caller's, the rest follows (seed, index). */
+int bsig_write_columns_as_bam_with_seq(const char *bampath, int32_t n_ref, const char *const *ref_names,
+                                       const bsig_columns *cols, int32_t level, int32_t l_seq, uint64_t seed);
 /* The file-level entry points keep, per process: one context per listed GPU, the parsed header +
  * BAI of the last 16 BAMs, and whole BAMs decoded to HBM -- least recently used first out above
  * env BAMSIGNALS_CACHE_GB (per GPU, default 96).  A file is identified by path + size + mtime of the

@@ -363,3 +363,39 @@ def test_pooled_column_writer_equals_record_by_record(tmp_path, monkeypatch, thr
         got = b.decode(threads=2)
         assert np.array_equal(got["pos"], c["pos"]) and np.array_equal(got["cigar"], c["cigar"])
         b.close()
+
+
+def test_real_shaped_synthetic_records(tmp_path):
+    """write_columns_as_bam(l_seq=100): read names, 4-bit bases, qualities and an NM tag around the caller's
+    alignment columns (204-byte records that compress about 2 : 1, for decode benchmarks on data shaped
+    like real BAMs); the columns decode back unchanged and the file depends on the seed only."""
+    import filecmp
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    cols = synth_reads(60_000, [900_000, 70_000], seed=8, paired=True)
+    a, b, c = (str(tmp_path / f"{k}.bam") for k in "abc")
+    write_columns_as_bam(a, ["x", "y"], cols, l_seq=100, seed=5)
+    write_columns_as_bam(b, ["x", "y"], cols, l_seq=100, seed=5)
+    write_columns_as_bam(c, ["x", "y"], cols, l_seq=75, seed=6)
+    assert filecmp.cmp(a, b, shallow=False) and not filecmp.cmp(a, c, shallow=False)
+    for path, l_seq in ((a, 100), (c, 75)):
+        f = BamFile(path)
+        got = f.decode(threads=2)
+        for k in ("pos", "flag", "mapq", "tlen", "cigar", "cigar_off", "ref_off"):
+            assert np.array_equal(got[k], cols[k]), k
+        f.close()
+        raw = gzip.decompress(open(path, "rb").read())
+        assert 1.5 < len(raw) / os.path.getsize(path) < 2.6
+        o = 12 + struct.unpack_from("<i", raw, 4)[0]
+        for _ in range(2):
+            o += 8 + struct.unpack_from("<i", raw, o)[0]
+        n = 0
+        while o < len(raw) and n < 500:
+            bs, rid, pos, l_name, mapq, bin_, n_cig, flag, ls = struct.unpack_from("<iiiBBHHHi", raw, o)
+            assert ls == l_seq and l_name == 10 and raw[o + 36:o + 46] == b"q%08x\x00" % n
+            sq = raw[o + 46 + 4 * n_cig:o + 46 + 4 * n_cig + (l_seq + 1) // 2]
+            ql = raw[o + 46 + 4 * n_cig + (l_seq + 1) // 2:o + 46 + 4 * n_cig + (l_seq + 1) // 2 + l_seq]
+            assert all((x >> 4) in (1, 2, 4, 8) for x in sq) and all(2 <= q <= 41 for q in ql)
+            assert raw[o + 4 + bs - 4:o + 4 + bs - 1] == b"NMC"
+            o += 4 + bs
+            n += 1
