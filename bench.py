@@ -93,6 +93,8 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         _lib.load().bsig_cache_clear()
         t0 = time.perf_counter(); sig = pileup_core(bam, gr, **call); t_cold = time.perf_counter() - t0
         stages = last_call_timing()
+        from bamsignals_amd.device import Reads
+        stages["decode_stages_s"] = Reads.device_decode_timing()
         del sig
         t0 = time.perf_counter(); sig2 = pileup_core(bam, gr, **call); t_warm = time.perf_counter() - t0
         flat = np.concatenate([np.asarray(m).T.reshape(-1) if call["ss"] else np.asarray(m) for m in sig2])

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: the cold decode of the north-star BAM (5e8 bare reads, 3 GB file, 26 GB of stream)
+three times in a row, with stage times and BSIG_DIAG_INFLATE lines."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+
+from bamsignals_amd.bamio import BamFile, write_columns_as_bam  # noqa: E402
+from bamsignals_amd.device import Context, Reads  # noqa: E402
+from bamsignals_amd.synth import synth_reads  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
+bam = "/tmp/ns_synth.bam"
+t = time.time(); cols = synth_reads(n, [250_000_000] * 10, seed=9); print("generate", round(time.time() - t, 1), flush=True)
+t = time.time(); write_columns_as_bam(bam, ["c%d" % i for i in range(10)], cols, level=1); print("write", round(time.time() - t, 1), os.path.getsize(bam), flush=True)
+del cols
+ctx = Context(0)
+b = BamFile(bam)
+os.environ["BSIG_DIAG_INFLATE"] = "1"
+for rep in range(3):
+    t = time.time(); r = Reads.from_bam(ctx, b); dt = time.time() - t
+    print("decode", rep, round(dt, 3), {k: round(v, 3) for k, v in Reads.device_decode_timing().items()}, flush=True)
+    r.close()
+for chunk in ("4096", "16384", "32768"):
+    os.environ["BAMSIGNALS_DEVICE_DECODE_CHUNK_MB"] = chunk
+    for rep in range(2):
+        t = time.time(); r = Reads.from_bam(ctx, b); dt = time.time() - t
+        print("chunk", chunk, rep, round(dt, 3), {k: round(v, 3) for k, v in Reads.device_decode_timing().items()}, flush=True)
+        r.close()
+os.remove(bam); os.remove(bam + ".bai")

@@ -1,22 +1,38 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): the default bench, the rocprofv3 kernel trace of the same
-# command, and the two PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes on gfx950).
-# Usage: scripts/profile_round.sh r01        -> gpurun_out/r01_*
+# Runs on the GPU box (through gpurun): for every BASELINE kernel the un-profiled timing, the
+# rocprofv3 kernel trace of the same command and the two PMC passes (FETCH_SIZE and WRITE_SIZE need
+# separate passes on gfx950; counters are never combined with other trace domains).  Nothing is
+# deleted: scripts/summarize_profile.py takes the newest output of every case.
+# Usage: scripts/profile_round.sh r02 [cases...]    -> gpurun_out/r02_*   (then scripts/summarize_profile.py r02)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift || true
+CASES=${*:-ns c2 c3 c4 count decode}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
-mkdir -p $OUT
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
-cd $R
-timeout 900 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-tail -c 600 $OUT/${TAG}_bench.json
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 64 --warmup 16 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $R/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1
-# the device-side decode kernels (whole file + index-driven) on the same 5e7-read BAM
-rm -rf $OUT/${TAG}_decode_trace
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_decode_trace -- python3 $R/scripts/decode_device_time.py > $OUT/${TAG}_decode_trace.log 2>&1
-ls $OUT | grep $TAG
+run_case() {   # name, program + args (python3 script ...)
+    local name=$1; shift
+    timeout 900 "$@" > "$OUT/${TAG}_${name}_plain.json" 2> "$OUT/${TAG}_${name}_plain.err" || return 1
+    echo "[$name] plain done"
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_${name}_trace" -- "$@" > "$OUT/${TAG}_${name}_trace.log" 2>&1 || return 1
+    echo "[$name] trace done"
+    timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_${name}_pmc_fetch" -- "$@" > "$OUT/${TAG}_${name}_pmc_fetch.log" 2>&1 || return 1
+    timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_${name}_pmc_write" -- "$@" > "$OUT/${TAG}_${name}_pmc_write.log" 2>&1 || return 1
+    echo "[$name] pmc done"
+}
+for c in $CASES; do
+    case $c in
+    ns)    run_case ns python3 $R/bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also || exit 1 ;;
+    c2)    run_case c2 python3 $R/bench.py --config C2 --steps 64 --warmup 16 --no-cpu-baseline --no-e2e || exit 1 ;;
+    c3)    run_case c3 python3 $R/scripts/profile_case.py C3 || exit 1 ;;
+    c4)    run_case c4 python3 $R/scripts/profile_case.py C4 || exit 1 ;;
+    count) run_case count python3 $R/scripts/profile_case.py count || exit 1 ;;
+    decode)
+        # the device-side decode kernels (whole file + index-driven) on the 5e7-read BAM
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decode_trace" -- python3 $R/scripts/decode_device_time.py > "$OUT/${TAG}_decode_trace.log" 2>&1 || exit 1
+        echo "[decode] trace done" ;;
+    esac
+done
+ls "$OUT" | grep "${TAG}_" | head -50
