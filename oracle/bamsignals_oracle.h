@@ -6,9 +6,19 @@
  * path and the timed "port" CPU baseline of bench.py.  Nothing under
  * bamsignals_amd/ may include, link or call it.
  *
- * Parity pinning: see oracle/oracle_np.py header.  The reference itself is
- * unbuildable here (Rcpp.h, htslib/sam.h, R and Rhtslib are absent from the
- * image), so there is no oracle/_ref.
+ * PARITY UNPINNED (by the evidence rule): the reference holds no literal
+ * expected outputs (its tests draw unseeded regions, tests/testthat/
+ * test_methods.R:11-20) and cannot be built or run here (Rcpp.h, htslib/sam.h,
+ * R and Rhtslib are absent from the image), so there is no oracle/_ref and no
+ * number under tests/golden/ was computed by the reference or by R.  What IS
+ * tied to reference-held data: the decode (BAM columns == the data.frame of
+ * tests/testthat/randomReads.RData, read for read) and the BAI layout; the
+ * arithmetic rests on three restatements by this project agreeing on the
+ * reference's own test grid (this file from src/bamsignals.cpp,
+ * oracle/oracle_np.py likewise in all-pairs form, oracle/r_oracle.py from the
+ * R text of tests/testthat/utils.R:178-311).  The acceptance run that would pin
+ * it needs R: bamsignals_amd/r_package/graft_into_reference.sh + the
+ * reference's own testthat suite.
  */
 #ifndef BAMSIGNALS_ORACLE_H
 #define BAMSIGNALS_ORACLE_H

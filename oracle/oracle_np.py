@@ -24,7 +24,9 @@ query window (``±ext``) always contains every read that can hit.  The faithful
 chunked form lives in ``oracle/bamsignals_oracle.c``; tests require both to
 agree.
 
-Parity pinning: this restatement is checked in ``tests/test_oracle_golden.py``
+PARITY UNPINNED by the evidence rule (no expected value was computed by the reference or by R:
+the reference holds no literal outputs and cannot run in this image; see bamsignals_oracle.h).
+What exists instead: this restatement is checked in ``tests/test_oracle_golden.py``
 against the reference's own fixtures (``inst/extdata/randomBam.bam``,
 ``tests/testthat/randomReads.RData``, ``inst/extdata/randomAnnot.Rdata``)
 through ``oracle/r_oracle.py``, an independent restatement of the reference's

@@ -539,3 +539,33 @@ def test_crc_mismatch_under_both_inflate_engines(ctx, tmp_path, monkeypatch):
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
         with pytest.raises(_lib.BsigError, match="CPU decode path"):
             Reads.from_bam(ctx, BamFile(str(p)))
+
+
+def test_inflate_engine_choice_is_never_far_from_the_better_engine(ctx, tmp_path, monkeypatch):
+    """gpu_inflate_pays() picks the inflate engine per call from the compressed size and the number of
+    blocks.  On a BAM of bare records (many blocks, few symbols each) and on a real-shaped one (names,
+    bases, qualities: literal-heavy blocks), the engine it picks must not be much slower than the one it
+    did not pick (timed here, generous margin: the point is the order of magnitude, not the last 20 %)."""
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_reads
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
+    for tag, n, l_seq in (("bare", 6_000_000, 0), ("real", 1_500_000, 100)):
+        cols = synth_reads(n, [200_000_000], seed=12)
+        path = str(tmp_path / f"{tag}.bam")
+        write_columns_as_bam(path, ["c"], cols, l_seq=l_seq, seed=3)
+        bam = BamFile(path)
+        t = {}
+        for eng in ("", "gpu", "cpu", "", "gpu", "cpu"):          # second round: warm page cache and scratch
+            if eng:
+                monkeypatch.setenv("BAMSIGNALS_INFLATE", eng)
+            else:
+                monkeypatch.delenv("BAMSIGNALS_INFLATE", raising=False)
+            r = Reads.from_bam(ctx, bam)
+            assert r.n_reads == n
+            d = Reads.device_decode_timing()
+            t[eng] = d["inflate"] + d["copy_wait"]
+            r.close()
+        assert t[""] <= 2.0 * min(t["gpu"], t["cpu"]) + 0.01, (tag, t)
+        bam.close()
