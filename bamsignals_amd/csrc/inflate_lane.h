@@ -27,7 +27,10 @@
 
 namespace bsig_inflate {
 
-constexpr int kLFast = 8, kDFast = 5;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit)
+#ifndef BSIG_LFAST
+#define BSIG_LFAST 8
+#endif
+constexpr int kLFast = BSIG_LFAST, kDFast = 5;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit)
 #ifndef BSIG_MULTI_LIT
 #define BSIG_MULTI_LIT 1
 #endif
