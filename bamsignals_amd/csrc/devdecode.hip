@@ -321,8 +321,12 @@ __global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ view, 
     if ((crc ^ 0xFFFFFFFFu) != j.crc) atomicMax(status, kErrCrc);
 }
 
+// crc_st != nullptr: the CRC kernel runs there, behind `inflated` (an event the caller owns), beside
+// whatever the caller queues on st next -- it keeps two waves per CU busy and so does the record walk;
+// its verdict lands in `crc_status`, which the caller reads once crc_st has drained.
 hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n, uint8_t *out, uint8_t *lens, int *status,
-                          const uint32_t *crc_tables, hipStream_t st)
+                          const uint32_t *crc_tables, hipStream_t st, hipStream_t crc_st = nullptr, hipEvent_t inflated = nullptr,
+                          int *crc_status = nullptr)
 {
     if (n <= 0) return hipSuccess;
     // resident lanes per CU = min(160 KB / 940 B of tables = 174, 8 waves (182 VGPRs) x LANES) in whole
@@ -336,8 +340,14 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
     case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(4), 4 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
     default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(8), 8 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
     }
-    if (crc_tables)
+    if (crc_tables && crc_st) {
+        hipError_t e = hipEventRecord(inflated, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(crc_st, inflated, 0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, crc_st, out, jobs, n, crc_tables, crc_status);
+    } else if (crc_tables) {
         hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, out, jobs, n, crc_tables, status);
+    }
     return hipGetLastError();
 }
 
@@ -728,6 +738,21 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         }
     } pf;
     if (gpu_inflate) HIP_TRY(hipStreamCreateWithFlags(&pf.cs, hipStreamNonBlocking));
+    // the CRC check of a pass runs on its own stream beside the record walk and extraction of that pass
+    struct CrcSide {
+        hipStream_t st = nullptr;
+        hipEvent_t inflated = nullptr;
+        ~CrcSide()
+        {
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+            if (inflated) (void)hipEventDestroy(inflated);
+        }
+    } crc;
+    if (gpu_inflate && d_crc_tables) {
+        HIP_TRY(hipStreamCreateWithFlags(&crc.st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&crc.inflated, hipEventDisableTiming));
+    }
+    bool crc_pending = false;
     int pass = 0;
     auto start_prefetch = [&](size_t b0, int which) {
         pf.B0 = b0;
@@ -744,13 +769,14 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     if (gpu_inflate) start_prefetch(Bbeg, 0);
 
     // a failure from here on must drain the stream before the buffers go away
-    auto decline = [&]() { pf.join(); (void)hipStreamSynchronize(st); return kNeedsCpuPath; };
+    auto decline = [&]() { pf.join(); (void)hipStreamSynchronize(st); if (crc.st) (void)hipStreamSynchronize(crc.st); return kNeedsCpuPath; };
 #define DD_TRY(expr)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
             pf.join();                                                                             \
             (void)hipStreamSynchronize(st);                                                        \
+            if (crc.st) (void)hipStreamSynchronize(crc.st);                                        \
             return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,              \
                         "HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
         }                                                                                          \
@@ -820,7 +846,9 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
                 jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
             const double t0 = now_s();
             DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
-            DD_TRY(launch_inflate(d_comp_now, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, d_crc_tables, st));
+            DD_TRY(launch_inflate(d_comp_now, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, d_crc_tables, st, crc.st,
+                                  crc.inflated, d_status + 1));
+            crc_pending = crc.st != nullptr;
             int status = 0;
             DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
             DD_TRY(hipStreamSynchronize(st));
@@ -952,6 +980,16 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         if (new_tail) DD_TRY(hipMemcpyAsync(d_data - new_tail, d_stream + o, (size_t)new_tail, hipMemcpyDeviceToDevice, st));
         // the host arrays of this chunk are reused: the copies above must have left them
         DD_TRY(hipStreamSynchronize(st));
+        if (crc_pending) {
+            // the blocks' CRCs were checked meanwhile: a mismatch sends the call down the CPU path, which
+            // reports it (nothing of this share is used then)
+            int bad = 0;
+            DD_TRY(hipStreamSynchronize(crc.st));
+            DD_TRY(hipMemcpyAsync(&bad, d_status + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            DD_TRY(hipStreamSynchronize(st));
+            if (bad) return decline();
+            crc_pending = false;
+        }
         tail = new_tail;
         first_chunk = false;
         R.t_gpu += now_s() - t0;
