@@ -312,3 +312,49 @@ def test_reads_save_and_load_round_trip(synth_bam, tmp_path):
     with pytest.raises(_lib.BsigError):
         Reads.load(ctx, str(tmp_path / "absent.bsig"), "stamp-1")
     back.close(); r.close(); b.close(); ctx.close()
+
+
+def test_concurrent_host_threads(synth_bam, tmp_path, monkeypatch):
+    """The file-level calls hold the cache lock for look-ups only: calls from several host threads -- on
+    resident BAMs side by side, cold decodes taking turns -- give the single-threaded results."""
+    import threading
+    from bamsignals_amd import _lib, bamCount, bamProfile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    from oracle import oracle_c
+    bam0, names, ref_len, cols0, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", "0")
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    _lib.load().bsig_cache_clear()
+    paths, want_p, want_c = [bam0], [], []
+    cols_all = [cols0]
+    for k in range(2):
+        c = synth_reads(200_000, ref_len, seed=700 + k, paired=True)
+        p = str(tmp_path / f"t{k}.bam")
+        write_columns_as_bam(p, names, c)
+        paths.append(p)
+        cols_all.append(c)
+    for c in cols_all:
+        want_p.append(oracle_c.pileup_core(_oracle(c), rg, binsize=1, ss=True, shift=12)[0])
+        want_c.append(oracle_c.pileup_core(_oracle(c), rg, binsize=-1)[0])
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(6):
+                k = (t + it) % len(paths)
+                if (t + it) % 2:
+                    got = np.concatenate([m.T.reshape(-1) for m in bamProfile(paths[k], gr, ss=True, shift=12, verbose=False)])
+                    assert np.array_equal(got, want_p[k]), (t, it, k)
+                else:
+                    assert np.array_equal(bamCount(paths[k], gr, verbose=False), want_c[k]), (t, it, k)
+        except Exception as exc:            # noqa: BLE001 - reported below
+            errors.append(repr(exc))
+    try:
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(5)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors
+    finally:
+        _lib.load().bsig_cache_clear()
