@@ -263,3 +263,40 @@ def test_one_process_per_rank_over_gloo(synth_bam):
     want_c, _ = oracle_c.pileup_core(orc, rg, binsize=-1, mapqual=20)
     want_v, _ = oracle_c.coverage_core(orc, rg, tspan=True, tlen_filter=(0, 1000), requiredF=66)
     assert np.array_equal(got_p, want_p) and np.array_equal(got_c, want_c) and np.array_equal(got_v, want_v)
+
+
+def test_hg38_shaped_bam_file_level_both_decode_modes(tmp_path, monkeypatch):
+    """The same genome as a BAM FILE (written by this repo's pooled writer: 24 references, bins of every
+    BAI level, hundreds of linear-index windows per reference) through the drop-in entry points: the
+    index-driven decode (BAI chunks -> islands, ref: one bam_itr_queryi per chunk of ranges,
+    src/bamsignals.cpp:252-271) and the whole-file decode, against the oracle on the generator's columns."""
+    from bamsignals_amd import GRanges, _lib, bamCount, bamCoverage, bamProfile, write_columns_as_bam
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from bamsignals_amd.wrappers import last_call_route
+    from oracle import oracle_c
+    names = ["chr%d" % (i + 1) for i in range(22)] + ["chrX", "chrY"]
+    cols = synth_reads(12_000_000, HG38, seed=91, paired=True)
+    bam = str(tmp_path / "hg38like.bam")
+    write_columns_as_bam(bam, names, cols)
+    rg = synth_ranges(3000, 1200, HG38, seed=92, jitter=600)
+    extra = dict(rid=np.asarray([23, 23, 0, 21], np.int32), loc=np.asarray([HG38[23] - 900, 0, HG38[0] - 1200, 16384 * 3 - 10], np.int32),
+                 len=np.asarray([900, 1000, 1200, 40], np.int32), strand=np.asarray([-1, 1, 0, 1], np.int32))
+    rg = {k: np.concatenate([rg[k], extra[k]]) for k in rg}
+    # level order of the GRanges differs from the BAM's
+    gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"], strand=[{1: "+", -1: "-", 0: "*"}[int(s)] for s in rg["strand"]])
+    orc = _oracle(cols)
+    want_p, _ = oracle_c.pileup_core(orc, rg, binsize=1, ss=True, shift=-20, pe_mid=True, tlen_filter=(30, 800), requiredF=66)
+    want_c, _ = oracle_c.pileup_core(orc, rg, binsize=-1)
+    want_v, _ = oracle_c.coverage_core(orc, rg, tspan=True, tlen_filter=(0, 1000), requiredF=66)
+    try:
+        for mode in ("regions", "all"):
+            monkeypatch.setenv("BAMSIGNALS_DECODE", mode)
+            _lib.load().bsig_cache_clear()
+            p = bamProfile(bam, gr, ss=True, shift=-20, paired_end="midpoint", tlenFilter=(30, 800), verbose=False)
+            assert ("index-driven" in last_call_route()) == (mode == "regions")
+            assert np.array_equal(np.concatenate([m.T.reshape(-1) for m in p]), want_p), mode
+            assert np.array_equal(bamCount(bam, gr, verbose=False), want_c), mode
+            v = bamCoverage(bam, gr, paired_end="extend", verbose=False)
+            assert np.array_equal(np.concatenate(v.as_list()), want_v), mode
+    finally:
+        _lib.load().bsig_cache_clear()
