@@ -283,8 +283,11 @@ int bsig_write_columns_as_bam_with_seq(const char *bampath, int32_t n_ref, const
  * env BAMSIGNALS_CACHE_GB (per GPU, default 96).  A file is identified by path + size + mtime of the
  * BAM and of its index: a rewritten file is decoded again.  env BAMSIGNALS_SIDECAR=1 (next to the BAM,
  * <bam>.bsig) or BAMSIGNALS_SIDECAR_DIR=<dir> additionally keeps the resident layout on disk
- * (bsig_reads_save) so that another process skips the decode.  bsig_cache_clear drops all of it
- * (not the sidecar files).                                                                      */
+ * (bsig_reads_save) so that another process skips the decode.  File-level calls may be made from
+ * several host threads at once (the cache is locked for look-ups only; cold decodes take turns).
+ * bsig_cache_clear drops all of it (not the sidecar files); entries a running call uses stay alive
+ * until that call returns, but the RCCL communicators are destroyed at once: do not call it while a
+ * multi-GPU call is in flight.                                                                   */
 void bsig_cache_clear(void);
 /* how the calling thread's last file-level call was carried out, e.g.
  * "8 GPU slot(s); reads: sharded decode, columns over rccl; result: xgmi/rccl"                  */
