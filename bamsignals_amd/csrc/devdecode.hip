@@ -45,6 +45,7 @@ using bsig::fail;
 
 // the parsed BAI of an open BAM (fileapi.cpp owns bsig_bam); internal, not part of the C ABI
 const bsig::BaiIndex *bsig_bam_index(const bsig_bam *bam);
+bool bsig_bam_csi_only(const bsig_bam *bam);
 
 namespace {
 
@@ -1624,6 +1625,8 @@ int bsig_reads_from_bam_regions(bsig_ctx *ctx, bsig_bam *bam, int64_t n_regions,
     if (!ctx || !bam || !reads) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_from_bam_regions");
     if (n_regions < 0 || (n_regions > 0 && (!rid || !beg || !end))) return fail(BSIG_ERR_ARG, "region arrays missing");
     *reads = nullptr;
+    if (bsig_bam_csi_only(bam))
+        return fail(BSIG_ERR_NOINDEX, "region queries need a .bai index (%s has a .csi index only: decode the whole file)", bsig_bam_path(bam));
     const char *mode = getenv("BAMSIGNALS_DEVICE_DECODE");
     int rc = bsig::kNeedsCpuPath;
     if (!(mode && !strcmp(mode, "0"))) {

@@ -28,6 +28,7 @@ struct bsig_bam {
     std::string path;
     bsig::BamHeader hdr;
     bsig::BaiIndex idx;
+    bool csi_only = false;      // indexed by a .csi file only: accepted, never queried (whole-file decodes)
     bsig::HostColumns cols;
 };
 
@@ -420,6 +421,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     bool whole = wanted * 3 > genome;
     if (force && !strcmp(force, "all")) whole = true;
     if (force && !strcmp(force, "regions")) whole = false;
+    if (bam->csi_only) whole = true;
 
     // ---- the reads of this call on every GPU -------------------------------------------------------
     std::shared_ptr<Resident> res;
@@ -549,6 +551,20 @@ int bsig_bam_open(const char *path, bsig_bam **out)
             alt.replace(alt.size() - 4, 4, ".bai");
             if (bsig::bai_load(alt, b->idx) == 0) rc = 0;
         }
+        if (rc) {
+            // htslib's bam_index_load (ref: src/bamsignals.cpp:207) also accepts a CSI index (references
+            // beyond 2^29 bp need one).  Its bins are not read here: a file indexed that way is always
+            // decoded whole, which needs no index at all
+            for (const std::string &cand : {b->path + ".csi", alt.size() > 4 ? alt.substr(0, alt.size() - 4) + ".csi" : std::string()}) {
+                if (cand.empty()) continue;
+                FILE *f = fopen(cand.c_str(), "rb");
+                if (!f) continue;
+                unsigned char magic[4] = {0, 0, 0, 0};
+                const bool gz = fread(magic, 1, 4, f) == 4 && magic[0] == 31 && magic[1] == 139;     // CSI files are BGZF-compressed
+                fclose(f);
+                if (gz) { b->csi_only = true; rc = 0; break; }
+            }
+        }
         if (rc) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", path);
     }
     if (rc) return rc;
@@ -561,6 +577,7 @@ void bsig_bam_close(bsig_bam *b) { delete b; }
 const char *bsig_bam_path(const bsig_bam *b) { return b ? b->path.c_str() : nullptr; }
 }  // extern "C"
 const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b) { return &b->idx; }
+bool bsig_bam_csi_only(const bsig_bam *b) { return b->csi_only; }
 extern "C" {
 
 int32_t bsig_bam_n_ref(const bsig_bam *b) { return b ? (int32_t)b->hdr.names.size() : 0; }
@@ -587,6 +604,7 @@ int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const in
         rc = bsig::bam_decode_all(b->path, threads, h, b->cols);
     } else {
         if (n_regions > 0 && (!rid || !beg || !end)) return fail(BSIG_ERR_ARG, "region arrays missing");
+        if (b->csi_only) return fail(BSIG_ERR_NOINDEX, "region queries need a .bai index (%s has a .csi index only: decode the whole file)", b->path.c_str());
         std::vector<bsig::Region> rg((size_t)n_regions);
         for (int64_t i = 0; i < n_regions; ++i) rg[(size_t)i] = bsig::Region{rid[i], beg[i], end[i]};
         rc = bsig::bam_decode_regions(b->path, b->idx, rg, threads, h, b->cols);

@@ -188,8 +188,11 @@ int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges
  * bam_name2id (ref: :26-28, :95), bam_itr_queryi / bam_itr_next (ref: :267-271).
  * ------------------------------------------------------------------------------------------ */
 typedef struct bsig_bam bsig_bam;
-/* opens <path> and loads <path>.bai; errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the reference's
- * messages (ref: src/bamsignals.cpp:204,209)                                                  */
+/* opens <path> and loads <path>.bai (or <stem>.bai); errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the
+ * reference's messages (ref: src/bamsignals.cpp:204,209).  A file that has only a CSI index
+ * (<path>.csi, which htslib's bam_index_load accepts too and references beyond 2^29 bp need) opens
+ * as well: its index is not read, whole-file decodes work, region queries return BSIG_ERR_NOINDEX,
+ * and the file-level entry points always decode it whole.                                       */
 int bsig_bam_open(const char *path, bsig_bam **bam);
 void bsig_bam_close(bsig_bam *bam);
 const char *bsig_bam_path(const bsig_bam *bam);

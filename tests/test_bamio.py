@@ -399,3 +399,24 @@ def test_real_shaped_synthetic_records(tmp_path):
             assert raw[o + 4 + bs - 4:o + 4 + bs - 1] == b"NMC"
             o += 4 + bs
             n += 1
+
+
+def test_csi_only_bam_opens_for_whole_file_decodes(tmp_path, fixture_reads):
+    """htslib's bam_index_load (ref: src/bamsignals.cpp:207) accepts a CSI index as well; here such a
+    file opens, decodes whole, and refuses region queries with a clear message (its bins are not read)."""
+    import shutil
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    p = tmp_path / "c.bam"
+    shutil.copy(BAM, p)
+    with pytest.raises(_lib.BsigError, match="BAM indexing file is not available"):
+        BamFile(str(p))
+    (tmp_path / "c.bam.csi").write_bytes(open(BAM, "rb").read()[:200])        # any BGZF-compressed file: only the magic is looked at
+    b = BamFile(str(p))
+    _cols_equal(b.decode(threads=2), fixture_reads)
+    with pytest.raises(_lib.BsigError, match="csi index only"):
+        b.decode(rid=[0], beg=[0], end=[100])
+    b.close()
+    (tmp_path / "c.bam.csi").write_bytes(b"not an index")
+    with pytest.raises(_lib.BsigError, match="BAM indexing file is not available"):
+        BamFile(str(p))
