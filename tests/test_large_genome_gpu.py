@@ -300,3 +300,31 @@ def test_hg38_shaped_bam_file_level_both_decode_modes(tmp_path, monkeypatch):
             assert np.array_equal(np.concatenate(v.as_list()), want_v), mode
     finally:
         _lib.load().bsig_cache_clear()
+
+
+def test_references_longer_than_a_bai_can_address(ctx):
+    """Two references of 1.6 and 0.9 Gbp (wheat- or axolotl-sized chromosomes, beyond the 2^29 bp a BAI
+    index reaches: such BAMs carry a CSI index and are decoded whole): positions up to 1.6e9 in the
+    int32 columns, ranges at both ends of both references."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from oracle import oracle_c
+    refs = [1_600_000_000, 900_000_000]
+    cols = synth_reads(12_000_000, refs, seed=131, paired=True, with_cigar=False)
+    rg = synth_ranges(60_000, 1500, refs, seed=132, jitter=500)
+    extra = dict(rid=np.asarray([0, 0, 1, 1], np.int32), loc=np.asarray([refs[0] - 1500, 2**30 - 700, 0, refs[1] - 800], np.int32),
+                 len=np.asarray([1500, 1500, 900, 800], np.int32), strand=np.asarray([1, -1, 0, -1], np.int32))
+    rg = {k: np.concatenate([rg[k], extra[k]]) for k in rg}
+    assert int((rg["loc"].astype(np.int64) > 2**30).sum()) > 5000
+    reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
+    orc = _oracle(cols)
+    for mode, fn, a in ((_lib.MODE_PROFILE, oracle_c.pileup_core, dict(binsize=1, ss=True, shift=40, pe_mid=True, tlen_filter=(0, 900), requiredF=66)),
+                        (_lib.MODE_PROFILE, oracle_c.pileup_core, dict(binsize=25)),
+                        (_lib.MODE_COUNT, oracle_c.pileup_core, dict(binsize=-1)),
+                        (_lib.MODE_COVERAGE, oracle_c.coverage_core, dict(tspan=True, tlen_filter=(0, 1000), requiredF=66))):
+        got = _run(ctx, reads, rg, mode, **a)
+        want, off = fn(orc, rg, **a)
+        assert got.any()
+        assert np.array_equal(got, want), (a, _per_reference_mismatch(got, want, off, rg["rid"]))
+    reads.close()
