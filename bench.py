@@ -177,6 +177,21 @@ def end_to_end_realistic(seed, device, oracle_c):
             os.environ.pop("BAMSIGNALS_INFLATE", None)
         else:
             os.environ["BAMSIGNALS_INFLATE"] = old
+        # the on-disk reads file: written by one cold call, loaded by the next "process" (cleared cache)
+        os.environ["BAMSIGNALS_SIDECAR_DIR"] = d
+        try:
+            _lib.load().bsig_cache_clear()
+            t0 = time.perf_counter(); pileup_core(bam, gr, (), device=device); t_make = time.perf_counter() - t0
+            _lib.load().bsig_cache_clear()
+            t0 = time.perf_counter(); sig = pileup_core(bam, gr, (), device=device); t_load = time.perf_counter() - t0
+            if not np.array_equal(np.concatenate(sig), want) or "sidecar" not in last_call_route():
+                raise SystemExit("the call from the reads file differs from the oracle")
+            side = [f for f in os.listdir(d) if f.endswith(".bsig")]
+            out["sidecar"] = dict(bytes=os.path.getsize(os.path.join(d, side[0])), cold_call_writing_it_s=t_make,
+                                  cold_call_loading_it_s=t_load, Mbases_s=bases / t_load / 1e6)
+            del sig
+        finally:
+            os.environ.pop("BAMSIGNALS_SIDECAR_DIR", None)
         _lib.load().bsig_cache_clear()
         b = BamFile(bam)
         dec = b.decode(threads=1)
