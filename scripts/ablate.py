@@ -50,7 +50,7 @@ def main():
                 plans[s % nb].run_device(outs[s % nb].data_ptr())
             e1.record(stream)
             torch.cuda.synchronize()
-            print(f"{name:10s} {e0.elapsed_time(e1) / 64 * 1e3:8.1f} us per step (resolve + k_profile)")
+            print(f"{name:10s} {e0.elapsed_time(e1) / 64 * 1e3:8.1f} us per step (k_profile)")
 
 
 if __name__ == "__main__":
