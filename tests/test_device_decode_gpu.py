@@ -484,11 +484,27 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
         monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu" if case % 2 else "cpu")      # both inflate engines
         dev = Reads.from_bam(ctx, bam)
+        # the same file decoded in 2-4 shares (the multi-GPU route on one GPU): either the shares are
+        # proven to tile the stream, or the call steps back to the single decode -- same reads either way
+        monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "1")
+        n_slots = int(rng.integers(2, 5))
+        from bamsignals_amd.device import Context
+        more = [Context(0) for _ in range(n_slots - 1)]
+        shares, _ = Reads.from_bam_multi([ctx] + more, bam)
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
         cpu = Reads.from_bam(ctx, bam)
         assert dev.n_reads == n_placed and dev.info() == cpu.info(), case
-        for a, b in zip(_results(ctx, dev, bam.ref_len.astype(np.int64), seed=case), _results(ctx, cpu, bam.ref_len.astype(np.int64), seed=case)):
+        want = _results(ctx, cpu, bam.ref_len.astype(np.int64), seed=case)
+        for a, b in zip(_results(ctx, dev, bam.ref_len.astype(np.int64), seed=case), want):
             assert np.array_equal(a, b), case
+        for k, sh in enumerate(shares):
+            assert sh.info() == cpu.info(), (case, k)
+        for a, b in zip(_results(shares[-1].ctx, shares[-1], bam.ref_len.astype(np.int64), seed=case), want):
+            assert np.array_equal(a, b), case
+        for sh in shares:
+            sh.close()
+        for c in more:
+            c.close()
         dev.close(); cpu.close(); bam.close()
         monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", raising=False)
         monkeypatch.delenv("BAMSIGNALS_BATCH_BLOCKS", raising=False)
