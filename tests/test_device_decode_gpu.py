@@ -438,7 +438,9 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
     from bamsignals_amd.device import Reads
     rng = np.random.default_rng(int(os.environ.get("BSIG_FUZZ_SEED", "99")))
     ops_ref = [0, 2, 3, 7, 8]
-    for case in range(int(os.environ.get("BSIG_DECODE_FUZZ_CASES", "25"))):
+    n_sharded = 0
+    n_cases = int(os.environ.get("BSIG_DECODE_FUZZ_CASES", "25"))
+    for case in range(n_cases):
         n_ref = int(rng.integers(1, 5))
         ref_len = rng.integers(500, 200_000, n_ref).astype(np.int64)
         text = b"".join(b"@SQ\tSN:r%d\tLN:%d\n" % (i, ref_len[i]) for i in range(n_ref))
@@ -490,7 +492,8 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         n_slots = int(rng.integers(2, 5))
         from bamsignals_amd.device import Context
         more = [Context(0) for _ in range(n_slots - 1)]
-        shares, _ = Reads.from_bam_multi([ctx] + more, bam)
+        shares, was_sharded = Reads.from_bam_multi([ctx] + more, bam)
+        n_sharded += bool(was_sharded)
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
         cpu = Reads.from_bam(ctx, bam)
         assert dev.n_reads == n_placed and dev.info() == cpu.info(), case
@@ -509,6 +512,8 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", raising=False)
         monkeypatch.delenv("BAMSIGNALS_BATCH_BLOCKS", raising=False)
         os.remove(path); os.remove(path + ".bai")
+    print("decoded in shares:", n_sharded, "of", n_cases)
+    assert n_sharded >= n_cases // 3          # the sharded route is really taken, not only its fall-back
 
 
 def test_damaged_deflate_data_with_the_gpu_inflate(ctx, tmp_path, monkeypatch):
