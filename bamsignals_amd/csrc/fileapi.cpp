@@ -105,12 +105,19 @@ struct Cache {
 };
 Cache g_cache;
 
-std::string file_key(const std::string &path)
+// size + mtime (ns) of a file, "" if it cannot be examined
+std::string file_stamp(const std::string &path)
 {
     struct stat st;
     if (stat(path.c_str(), &st) != 0) return std::string();
-    return path + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtime) +
-           "|" + std::to_string((long long)st.st_mtim.tv_nsec);
+    return std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtime) + "|" +
+           std::to_string((long long)st.st_mtim.tv_nsec);
+}
+
+std::string file_key(const std::string &path)
+{
+    const std::string s = file_stamp(path);
+    return s.empty() ? s : path + "|" + s;
 }
 
 int64_t cache_budget_bytes()
@@ -334,8 +341,11 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     const double t_begin = now_s();
     // ref: Bamfile ctor :200-214 opens file + index on every call; here an unchanged file (same
     // size and mtime of the BAM and of its index) reuses the parsed header and BAI
-    const std::string key = file_key(bampath);
-    const std::string bkey = key.empty() ? std::string() : key + "#" + file_key(std::string(bampath) + ".bai");
+    // (keyed by the resolved path: "a.bam" and "./a.bam" are one file, one resident copy)
+    char resolved[4096];
+    const std::string canon = realpath(bampath, resolved) ? std::string(resolved) : std::string(bampath);
+    const std::string key = file_key(canon);
+    const std::string bkey = key.empty() ? std::string() : key + "#" + file_key(canon + ".bai");
     int rc = BSIG_OK;
     std::shared_ptr<OpenBam> ob;
     if (!bkey.empty()) {
@@ -452,12 +462,15 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         double t6[6] = {0, 0, 0, 0, 0, 0};
         if (whole) {
             const std::string side = key.empty() ? std::string() : sidecar_path(bampath);
+            // (the reads file is tied to the CONTENT it was made from -- size and mtime of the BAM and of its
+            // index -- not to the spelling of the path it was reached by)
+            const std::string side_stamp = file_stamp(bampath) + "#" + file_stamp(std::string(bampath) + ".bai");
             bool loaded = false;
             if (!side.empty()) {
                 // a second process (or a call after the BAM left the cache) skips inflate and parse
                 struct stat sb;
                 if (stat(side.c_str(), &sb) == 0) {
-                    rc = for_each_slot(nd, [&](size_t k) { return bsig_reads_load(slots->ctx[k], side.c_str(), bkey.c_str(), &res->reads[k]); });
+                    rc = for_each_slot(nd, [&](size_t k) { return bsig_reads_load(slots->ctx[k], side.c_str(), side_stamp.c_str(), &res->reads[k]); });
                     loaded = rc == BSIG_OK;
                     if (!loaded) { for (bsig_reads *&r : res->reads) { if (r) bsig_reads_free(r); r = nullptr; } rc = BSIG_OK; }
                 }
@@ -484,7 +497,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                     how_decoded = nd > 1 ? "decode on the first GPU + clones" : "decode";
                 }
                 if (rc) return rc;
-                if (!side.empty()) (void)bsig_reads_save(res->reads[0], side.c_str(), bkey.c_str());   // best effort
+                if (!side.empty()) (void)bsig_reads_save(res->reads[0], side.c_str(), side_stamp.c_str());   // best effort
             }
         } else {
             // index-driven: only the blocks the BAI lists for the ranges (ref: one bam_itr_queryi per

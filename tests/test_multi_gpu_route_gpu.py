@@ -266,6 +266,10 @@ def test_cache_lru_rewrite_and_sidecar(synth_bam, tmp_path, monkeypatch):
         wants[1] = oracle_c.pileup_core(_oracle(c), rg, binsize=-1)[0]
         assert call(1) is False
         assert call(1) is True
+        # another spelling of the same path is the same file (one resident copy)
+        other = os.path.join(os.path.dirname(paths[1]), ".", os.path.basename(paths[1]))
+        got = bamCount(other, gr, verbose=False)
+        assert np.array_equal(got, wants[1]) and last_call_timing()["bam_was_resident"]
         # the sidecar: written by the first cold call, loaded by a "second process" (cleared cache)
         lib.bsig_cache_clear()
         side = tmp_path / "sidecars"
