@@ -362,3 +362,35 @@ def test_concurrent_host_threads(synth_bam, tmp_path, monkeypatch):
         assert not errors, errors
     finally:
         _lib.load().bsig_cache_clear()
+
+
+@pytest.mark.parametrize("gather", ["xgmi", "pcie"])
+def test_fewer_ranges_than_slots(synth_bam, gather, monkeypatch):
+    """No range at all, one range, and one zero-width range over four slots: empty shards everywhere."""
+    from bamsignals_amd import GRanges, _lib, bamCount, bamCoverage, bamProfile
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", "0,0,0,0")
+    monkeypatch.setenv("BAMSIGNALS_GATHER", gather)
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+    _lib.load().bsig_cache_clear()
+    try:
+        none = GRanges([], [], width=[], strand=[])
+        assert len(bamProfile(bam, none, verbose=False)) == 0
+        assert bamCount(bam, none, verbose=False).shape == (0,)
+        assert bamCount(bam, none, ss=True, verbose=False).shape == (2, 0)
+        one = gr[[5]]
+        monkeypatch.setenv("BAMSIGNALS_DEVICES", "0")
+        want_p = bamProfile(bam, one, ss=True, verbose=False)[0]
+        want_c = bamCount(bam, one, verbose=False)
+        want_v = bamCoverage(bam, one, verbose=False)[0]
+        monkeypatch.setenv("BAMSIGNALS_DEVICES", "0,0,0,0")
+        assert np.array_equal(bamProfile(bam, one, ss=True, verbose=False)[0], want_p)
+        assert np.array_equal(bamCount(bam, one, verbose=False), want_c)
+        assert np.array_equal(bamCoverage(bam, one, verbose=False)[0], want_v)
+        zero = GRanges([names[0]], [100], width=[0], strand=["-"])
+        assert bamProfile(bam, zero, verbose=False)[0].shape == (0,)
+        assert bamCoverage(bam, zero, verbose=False)[0].shape == (0,)
+        assert bamCount(bam, zero, verbose=False).tolist() == [0]
+    finally:
+        _lib.load().bsig_cache_clear()
