@@ -137,6 +137,11 @@ def load():
     lib.bsig_write_columns_as_bam_with_seq.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Columns),
                                                        C.c_int32, C.c_int32, C.c_uint64]
     lib.bsig_cache_clear.restype = None
+    lib.bsig_debug_scratch_allocs.restype = C.c_int64
+    lib.bsig_segmap_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.bsig_segmap_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bsig_segmap_free.argtypes = [C.c_void_p]
+    lib.bsig_segmap_free.restype = None
     lib.bsig_last_call_timing.argtypes = [C.POINTER(C.c_double)]
     lib.bsig_last_call_timing.restype = None
     lib.bsig_check_list.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]

@@ -1106,20 +1106,76 @@ int bai_load(const std::string &bai_path, BaiIndex &idx)
     return 0;
 }
 
+// CSI (CSIv1 spec): BGZF-compressed; magic "CSI\1", min_shift, depth, l_aux, aux[l_aux], n_ref, then per
+// reference n_bin x { bin u32, loffset u64, n_chunk i32, chunks }, optionally n_no_coor.  There is no linear
+// index: every bin carries the lowest virtual offset of a record that overlaps it (loffset).
+int csi_load(const std::string &csi_path, BaiIndex &idx)
+{
+    gzFile g = gzopen(csi_path.c_str(), "rb");          // (zlib reads the concatenated gzip members of a BGZF file)
+    if (!g) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", csi_path.c_str());
+    std::vector<uint8_t> d;
+    {
+        uint8_t buf[1 << 16];
+        int got;
+        while ((got = gzread(g, buf, sizeof buf)) > 0) {
+            d.insert(d.end(), buf, buf + got);
+            if (d.size() > (4ull << 30)) break;
+        }
+        gzclose(g);
+        if (got < 0) return fail(BSIG_ERR_FORMAT, "%s is not a CSI index (inflate failed)", csi_path.c_str());
+    }
+    size_t o = 0;
+    auto need = [&](size_t n) { return o + n <= d.size(); };
+    if (!need(16) || memcmp(d.data(), "CSI\1", 4) != 0) return fail(BSIG_ERR_FORMAT, "%s is not a CSI index", csi_path.c_str());
+    const int32_t min_shift = rdi32(d.data() + 4), depth = rdi32(d.data() + 8), l_aux = rdi32(d.data() + 12);
+    o = 16;
+    if (min_shift < 1 || min_shift > 30 || depth < 1 || depth > 9 || min_shift + 3 * depth > 44 || l_aux < 0 || !need((size_t)l_aux + 4))
+        return fail(BSIG_ERR_FORMAT, "malformed CSI index");
+    o += (size_t)l_aux;
+    const int32_t n_ref = rdi32(d.data() + o); o += 4;
+    if (n_ref < 0 || (size_t)n_ref > (d.size() - o) / 4) return fail(BSIG_ERR_FORMAT, "malformed CSI index");
+    idx = BaiIndex();
+    idx.min_shift = min_shift;
+    idx.depth = depth;
+    idx.refs.assign((size_t)n_ref, BaiRef());
+    for (int r = 0; r < n_ref; ++r) {
+        if (!need(4)) return fail(BSIG_ERR_FORMAT, "truncated CSI index");
+        const int32_t n_bin = rdi32(d.data() + o); o += 4;
+        if (n_bin < 0) return fail(BSIG_ERR_FORMAT, "malformed CSI index");
+        BaiRef &R = idx.refs[(size_t)r];
+        for (int b = 0; b < n_bin; ++b) {
+            if (!need(16)) return fail(BSIG_ERR_FORMAT, "truncated CSI index");
+            const uint32_t bin = rd32(d.data() + o);
+            const uint64_t loffset = rd64(d.data() + o + 4);
+            const int32_t n_chunk = rdi32(d.data() + o + 12); o += 16;
+            if (n_chunk < 0 || !need(16 * (size_t)n_chunk)) return fail(BSIG_ERR_FORMAT, "truncated CSI index");
+            std::vector<BaiChunk> ch((size_t)n_chunk);
+            for (int k = 0; k < n_chunk; ++k) { ch[(size_t)k].beg = rd64(d.data() + o); ch[(size_t)k].end = rd64(d.data() + o + 8); o += 16; }
+            R.bins.emplace_back(bin, std::move(ch));
+            R.loff.emplace_back(bin, loffset);
+        }
+        std::sort(R.bins.begin(), R.bins.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        std::sort(R.loff.begin(), R.loff.end());
+    }
+    idx.n_no_coor = need(8) ? rd64(d.data() + o) : 0;
+    return 0;
+}
+
 namespace {
 
-// bins overlapping [beg, end) (SAM spec 5.3, reg2bins)
-void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &out)
+// bins overlapping [beg, end) (SAM spec 5.3 reg2bins; CSIv1 spec for any min_shift / depth)
+void reg2bins(int64_t beg, int64_t end, int min_shift, int depth, std::vector<uint32_t> &out)
 {
     out.clear();
     if (beg >= end) return;
     --end;
-    out.push_back(0);
-    for (int k = 1 + (int)(beg >> 26); k <= 1 + (int)(end >> 26); ++k) out.push_back((uint32_t)k);
-    for (int k = 9 + (int)(beg >> 23); k <= 9 + (int)(end >> 23); ++k) out.push_back((uint32_t)k);
-    for (int k = 73 + (int)(beg >> 20); k <= 73 + (int)(end >> 20); ++k) out.push_back((uint32_t)k);
-    for (int k = 585 + (int)(beg >> 17); k <= 585 + (int)(end >> 17); ++k) out.push_back((uint32_t)k);
-    for (int k = 4681 + (int)(beg >> 14); k <= 4681 + (int)(end >> 14); ++k) out.push_back((uint32_t)k);
+    int s = min_shift + 3 * depth;
+    int64_t t = 0;
+    for (int l = 0; l <= depth; ++l, s -= 3) {
+        const int64_t b = t + (beg >> s), e = t + (end >> s);
+        for (int64_t k = b; k <= e; ++k) out.push_back((uint32_t)k);
+        t += 1ll << (3 * l);
+    }
 }
 
 uint32_t reg2bin(int64_t beg, int64_t end)
@@ -1143,12 +1199,29 @@ std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<R
     for (const Region &rg : regions) {
         if (rg.rid < 0 || rg.rid >= (int)idx.refs.size()) continue;
         const BaiRef &R = idx.refs[(size_t)rg.rid];
-        const int64_t beg = std::max<int64_t>(rg.beg, 0), end = std::min<int64_t>(rg.end, 1ll << 29);
+        const int ms = idx.min_shift, depth = idx.depth;
+        const int64_t n_leaf = 1ll << (3 * depth);                       // leaf bins (windows of 2^min_shift bp)
+        const int64_t t_leaf = (n_leaf - 1) / 7;                          // number of the first leaf bin
+        const int64_t beg = std::max<int64_t>(rg.beg, 0), end = std::min<int64_t>(rg.end, 1ll << (ms + 3 * depth));
         if (beg >= end) continue;
         uint64_t min_off = 0;
         if (!R.linear.empty()) {
             const size_t w = (size_t)(beg >> 14);
             min_off = w < R.linear.size() ? R.linear[w] : R.linear.back();
+        } else if (!R.loff.empty()) {
+            // CSI (htslib's hts_itr_query): the loffset of the leaf bin that holds `beg`, or of the nearest
+            // bin to its left on its level, climbing to the parent where a level has none
+            int64_t bin = t_leaf + (beg >> ms);
+            uint64_t found = 0;
+            bool have = false;
+            while (true) {
+                auto it = std::lower_bound(R.loff.begin(), R.loff.end(), std::make_pair((uint32_t)bin, (uint64_t)0));
+                if (it != R.loff.end() && it->first == (uint32_t)bin) { found = it->second; have = true; break; }
+                if (bin == 0) break;
+                const int64_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
+                bin = bin > first ? bin - 1 : parent;
+            }
+            min_off = have ? found : 0;
         }
         // Upper bound.  htslib's iterator stops at the first record with pos >= end; the chunk lists of
         // the coarse bins (reads that straddle a finer bin's border) run on to the end of their bin,
@@ -1157,9 +1230,9 @@ std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<R
         // that read's virtual offset, which is a record boundary.
         uint64_t max_off = ~0ull;
         {
-            const int64_t w_end = (end - 1) >> 14;
-            for (int64_t w = w_end + 1; w <= w_end + 64 && w < (1 << 15); ++w) {
-                const uint32_t leaf = 4681u + (uint32_t)w;
+            const int64_t w_end = (end - 1) >> ms;
+            for (int64_t w = w_end + 1; w <= w_end + 64 && w < n_leaf; ++w) {
+                const uint32_t leaf = (uint32_t)(t_leaf + w);
                 auto it = std::lower_bound(R.bins.begin(), R.bins.end(), leaf, [](const auto &x, uint32_t v) { return x.first < v; });
                 if (it == R.bins.end() || it->first != leaf || it->second.empty()) continue;
                 uint64_t first = ~0ull;
@@ -1168,7 +1241,7 @@ std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<R
                 break;
             }
         }
-        reg2bins(beg, end, bins);
+        reg2bins(beg, end, ms, depth, bins);
         for (uint32_t b : bins) {
             auto it = std::lower_bound(R.bins.begin(), R.bins.end(), b, [](const auto &x, uint32_t v) { return x.first < v; });
             if (it == R.bins.end() || it->first != b) continue;

@@ -65,11 +65,15 @@ struct HostColumns {
 struct BaiChunk { uint64_t beg, end; };
 struct BaiRef {
     std::vector<std::pair<uint32_t, std::vector<BaiChunk>>> bins;   // sorted by bin number
-    std::vector<uint64_t> linear;                                    // 16 kbp windows
+    std::vector<uint64_t> linear;                                    // BAI: 16 kbp windows
+    std::vector<std::pair<uint32_t, uint64_t>> loff;                 // CSI: per-bin loffset, sorted by bin number
 };
+// A BAI (min_shift 14, depth 5: SAM spec 5.2) or a CSI index (any min_shift / depth: CSIv1 spec; htslib's
+// bam_index_load, ref: src/bamsignals.cpp:207, accepts both -- references beyond 2^29 bp need a CSI).
 struct BaiIndex {
     std::vector<BaiRef> refs;
     uint64_t n_no_coor = 0;
+    int min_shift = 14, depth = 5;
 };
 
 struct Region { int32_t rid; int64_t beg, end; };   // 0-based half-open
@@ -136,6 +140,8 @@ int bam_read_header(const std::string &path, BamHeader &hdr);
 // column extraction, total
 extern thread_local double g_decode_timing[6];
 int bai_load(const std::string &bai_path, BaiIndex &idx);
+// BSIG_ERR_NOINDEX if absent, BSIG_ERR_FORMAT if the file does not inflate to a CSIv1 index
+int csi_load(const std::string &csi_path, BaiIndex &idx);
 
 // One alignment for the writer
 struct BamRecord {

@@ -10,25 +10,48 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "runtime_internal.h"
 
 namespace bsig {
 
-struct Exchange;     // one per ordered list of devices, kept for the life of the process (or until exchange_close_all)
+struct Exchange;     // one per ordered list of devices; lives while the registry or a call refers to it
+
+// A call's hold on an exchange, from exchange_open() until the slots' streams have been synchronised:
+//   * the exchange's lock -- RCCL does not allow two threads to interleave group calls on one
+//     communicator, and the file-level calls may come from several host threads at once;
+//   * a reference that keeps the communicators alive: bsig_cache_clear() only drops the registry's
+//     reference, the communicators go when the last call using them has returned;
+//   * this call's streams (one per slot), so that nothing call-specific lives in the shared object.
+struct ExchangeUse {
+    std::shared_ptr<Exchange> ex;
+    std::unique_lock<std::mutex> lock;
+    std::vector<hipStream_t> streams;
+    const char *transport = "";     // "rccl", "peer", or "peer (after an RCCL error)" once a collective fell back
+    ~ExchangeUse() { release(); }
+    void release() { if (lock.owns_lock()) lock.unlock(); ex.reset(); }
+};
 
 // ctxs: one context per slot (its device and the stream the exchange is queued on).  Never fails for
-// lack of RCCL: it then uses peer copies.  *transport receives "rccl" or "peer".
-int exchange_open(const std::vector<bsig_ctx *> &ctxs, Exchange **ex, const char **transport);
+// lack of RCCL: it then uses peer copies (unless env BAMSIGNALS_EXCHANGE=rccl demands RCCL).  A fresh
+// communicator set is checked: every communicator must report ctxs.size() ranks and its own slot as rank.
+int exchange_open(const std::vector<bsig_ctx *> &ctxs, ExchangeUse &use);
 // Every slot k holds a buffer bufs[k] of identical layout; share g (len[g] bytes at off[g]) is valid on
 // slot g.  Afterwards every slot holds every share.  Queued on the slots' streams; the shares must be
 // complete (streams synchronised) before the call, and the caller synchronises the streams afterwards.
-int exchange_allgather(Exchange *ex, const std::vector<uint8_t *> &bufs, const std::vector<size_t> &off,
+// An RCCL failure while the group is being built abandons RCCL for this exchange (for good) and the
+// call is carried out with peer copies instead; use.transport says so.
+int exchange_allgather(ExchangeUse &use, const std::vector<uint8_t *> &bufs, const std::vector<size_t> &off,
                        const std::vector<size_t> &len);
-// src[k] (len[k] bytes on slot k) -> dst_root + off[k] on slot 0.  Same synchronisation rules.
-int exchange_gather(Exchange *ex, const std::vector<const uint8_t *> &src, const std::vector<size_t> &len,
+// src[k] (len[k] bytes on slot k) -> dst_root + off[k] on slot 0.  Same rules.
+int exchange_gather(ExchangeUse &use, const std::vector<const uint8_t *> &src, const std::vector<size_t> &len,
                     uint8_t *dst_root, const std::vector<size_t> &off);
+// can a kernel on slot 0's GPU read the other slots' device memory in place (same device, or peer access on)?
+bool exchange_root_reads_peers(ExchangeUse &use);
+// drops the registry's references (communicators in use by a running call live until it returns)
 void exchange_close_all();
 
 // Segment k of src (src_off[k] .. src_off[k+1]) goes to dst at dst_off[which[k]]: bsig_scatter_segments

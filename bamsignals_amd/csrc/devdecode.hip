@@ -45,7 +45,6 @@ using bsig::fail;
 
 // the parsed BAI of an open BAM (fileapi.cpp owns bsig_bam); internal, not part of the C ABI
 const bsig::BaiIndex *bsig_bam_index(const bsig_bam *bam);
-bool bsig_bam_csi_only(const bsig_bam *bam);
 
 namespace {
 
@@ -1060,6 +1059,148 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
 }
 
 
+namespace {
+// The second half of every sharded decode: share g of the reads sits in pieces on GPU g.  The reads must
+// stay in coordinate order across the shares; then every GPU puts its pieces at their global offset in
+// full-length columns, the other shares arrive over xGMI (collect.h), and every GPU lays the reads out.
+// Returns BSIG_OK, kNeedsCpuPath (order broken across shares) or an error.  T[3] += exchange, T[5] = layouts.
+int join_shares(const std::vector<bsig_ctx *> &ctxs, std::vector<ShareOut> &S, const BamHeader &hdr,
+                std::vector<bsig_reads *> &out, const char **transport, double *T)
+{
+    const size_t n = ctxs.size();
+    std::vector<int> rcs(n, BSIG_OK);
+    std::vector<std::string> msgs(n);
+    auto run_all = [&](const std::function<int(size_t)> &body) {
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < n; ++g) {
+            auto one = [&, g] {
+                rcs[g] = body(g);
+                if (rcs[g]) msgs[g] = g_last_error;
+            };
+            try { th.emplace_back(one); } catch (const std::system_error &) { one(); }
+        }
+        for (auto &t : th) t.join();
+        for (size_t g = 0; g < n; ++g)
+            if (rcs[g] < 0) return fail(rcs[g], "%s", msgs[g].c_str());
+        for (size_t g = 0; g < n; ++g)
+            if (rcs[g]) return rcs[g];
+        return (int)BSIG_OK;
+    };
+    int rc = BSIG_OK;
+    int32_t prid = -1, ppos = -1;
+    int64_t n_reads = 0;
+    std::vector<int64_t> base(n + 1, 0);
+    for (size_t g = 0; g < n; ++g) {
+        if (S[g].n_reads) {
+            if (S[g].first_rid < prid || (S[g].first_rid == prid && S[g].first_pos < ppos)) return kNeedsCpuPath;
+            prid = S[g].last_rid; ppos = S[g].last_pos;
+        }
+        base[g] = n_reads;
+        n_reads += S[g].n_reads;
+    }
+    base[n] = n_reads;
+    const double t_x = now_s();
+
+    // ---- first read of every reference (share-local indices -> global) ----------------------------
+    const int32_t n_ref = (int32_t)hdr.names.size();
+    std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
+    {
+        std::vector<long long> rf((size_t)n_ref + 1);
+        std::vector<long long> first((size_t)n_ref + 1, -1);
+        for (size_t g = 0; g < n; ++g) {
+            if (!S[g].d_ref_first) continue;               // a share without any block
+            HIP_TRY(hipSetDevice(ctxs[g]->device));
+            HIP_TRY(hipMemcpyAsync(rf.data(), S[g].d_ref_first, rf.size() * sizeof(long long), hipMemcpyDeviceToHost, ctxs[g]->stream));
+            HIP_TRY(hipStreamSynchronize(ctxs[g]->stream));
+            // a share marks every reference up to its first read's as starting at its index 0: the
+            // earliest share that knows a reference is the one that holds its first read
+            for (int32_t q = 0; q <= n_ref; ++q)
+                if (first[(size_t)q] < 0 && rf[(size_t)q] >= 0) first[(size_t)q] = base[g] + rf[(size_t)q];
+        }
+        ref_off[(size_t)n_ref] = n_reads;
+        for (int32_t r = n_ref - 1; r >= 0; --r) ref_off[(size_t)r] = first[(size_t)r] >= 0 ? first[(size_t)r] : ref_off[(size_t)r + 1];
+        ref_off[0] = 0;
+    }
+
+    // ---- full columns on every GPU: own pieces in place, the other shares over xGMI ---------------
+    std::vector<Piece> whole(n);
+    if (n_reads > 0) {
+        rc = run_all([&](size_t k) -> int {
+            HIP_TRY(hipSetDevice(ctxs[k]->device));
+            hipStream_t st = ctxs[k]->stream;
+            if (!S[k].tmp) S[k].tmp.reset(new ScratchPool(ctxs[k]->device, st));
+            HIP_TRY(whole[k].alloc(*S[k].tmp, n_reads));
+            int64_t at = base[k];
+            for (auto &pp : S[k].pieces) {
+                const Piece &pc = *pp;
+                HIP_TRY(hipMemcpyAsync(whole[k].pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(whole[k].mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st));
+                at += pc.n;
+            }
+            HIP_TRY(hipStreamSynchronize(st));
+            return BSIG_OK;
+        });
+        if (rc) return rc;
+        // (the use holds the exchange's lock until the slots' streams have been synchronised below)
+        ExchangeUse use;
+        rc = exchange_open(ctxs, use);
+        if (rc) return rc;
+        std::vector<uint8_t *> bufs(n);
+        std::vector<size_t> off(n), len(n);
+        auto gather_col = [&](size_t elt, const std::function<uint8_t *(Piece &)> &col) {
+            for (size_t g = 0; g < n; ++g) {
+                bufs[g] = col(whole[g]);
+                off[g] = (size_t)base[g] * elt;
+                len[g] = (size_t)S[g].n_reads * elt;
+            }
+            return exchange_allgather(use, bufs, off, len);
+        };
+        rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.pos; });
+        if (!rc) rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.end; });
+        if (!rc) rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.tlen; });
+        if (!rc) rc = gather_col(2, [](Piece &p) { return (uint8_t *)p.flag; });
+        if (!rc) rc = gather_col(1, [](Piece &p) { return (uint8_t *)p.mapq; });
+        for (size_t k = 0; k < n; ++k) {
+            (void)hipSetDevice(ctxs[k]->device);
+            const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
+            if (e != hipSuccess && !rc) rc = fail(BSIG_ERR_DEVICE, "exchanging the decoded columns failed on GPU %d: %s", ctxs[k]->device, hipGetErrorString(e));
+        }
+        if (transport) *transport = use.transport;
+        use.release();
+        if (rc) return rc;
+    } else if (transport) {
+        *transport = "none";
+    }
+    T[3] += now_s() - t_x;
+
+    // ---- every GPU lays the reads out ---------------------------------------------------------------
+    const double t_lay = now_s();
+    std::vector<bsig_reads *> made(n, nullptr);
+    rc = run_all([&](size_t k) -> int {
+        bsig_reads *R = new bsig_reads;
+        R->ctx = ctxs[k];
+        const int r = n_reads > 0 ? layout_from_device(ctxs[k], R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), whole[k].pos,
+                                                       whole[k].end, whole[k].flag, whole[k].mapq, whole[k].tlen)
+                                  : layout_from_device(ctxs[k], R, 0, n_ref, hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr,
+                                                       nullptr, nullptr);
+        if (r) { delete R; return r; }
+        made[k] = R;
+        return BSIG_OK;
+    });
+    if (rc) {
+        for (bsig_reads *R : made) delete R;
+        return rc;
+    }
+    out = made;
+    T[5] = now_s() - t_lay;
+    return BSIG_OK;
+}
+
+}  // namespace
+
 // Whole BAM -> resident reads on EVERY listed GPU (the single-process multi-GPU route): GPU g
 // inflates and parses share g of the BGZF blocks (the reference's wall time is this stage,
 // bam_itr_next, ref: src/bamsignals.cpp:271), the column shares are all-gathered over xGMI
@@ -1116,155 +1257,42 @@ int reads_from_bam_sharded(const std::vector<bsig_ctx *> &ctxs, const std::strin
     };
     rc = run_all([&](size_t g) { return decode_share(ctxs[g], F.f, F.hdr, F.uoff, cut[g], cut[g + 1], thr_each, F.gpu_inflate, S[g]); });
     if (rc) return rc;
-    // the shares' chains must tile the stream, and the reads must stay in coordinate order across them
-    int32_t prid = -1, ppos = -1;
-    int64_t n_reads = 0;
-    std::vector<int64_t> base(n + 1, 0);
-    for (size_t g = 0; g < n; ++g) {
-        if (g && S[g - 1].chain_end != S[g].chain_first) return kNeedsCpuPath;
-        if (S[g].n_reads) {
-            if (S[g].first_rid < prid || (S[g].first_rid == prid && S[g].first_pos < ppos)) return kNeedsCpuPath;
-            prid = S[g].last_rid; ppos = S[g].last_pos;
-        }
-        base[g] = n_reads;
-        n_reads += S[g].n_reads;
-    }
-    base[n] = n_reads;
+    // the shares' chains must tile the stream
+    for (size_t g = 1; g < n; ++g)
+        if (S[g - 1].chain_end != S[g].chain_first) return kNeedsCpuPath;
     for (size_t g = 0; g < n; ++g) { T[1] = std::max(T[1], S[g].t_inflate); T[2] = std::max(T[2], S[g].t_wait); T[3] = std::max(T[3], S[g].t_gpu); }
-    const double t_x = now_s();
-
-    // ---- first read of every reference (share-local indices -> global) ----------------------------
-    const int32_t n_ref = (int32_t)F.hdr.names.size();
-    std::vector<int64_t> ref_off((size_t)n_ref + 1, n_reads);
-    {
-        std::vector<long long> rf((size_t)n_ref + 1);
-        std::vector<long long> first((size_t)n_ref + 1, -1);
-        for (size_t g = 0; g < n; ++g) {
-            HIP_TRY(hipSetDevice(ctxs[g]->device));
-            HIP_TRY(hipMemcpyAsync(rf.data(), S[g].d_ref_first, rf.size() * sizeof(long long), hipMemcpyDeviceToHost, ctxs[g]->stream));
-            HIP_TRY(hipStreamSynchronize(ctxs[g]->stream));
-            // a share marks every reference up to its first read's as starting at its index 0: the
-            // earliest share that knows a reference is the one that holds its first read
-            for (int32_t q = 0; q <= n_ref; ++q)
-                if (first[(size_t)q] < 0 && rf[(size_t)q] >= 0) first[(size_t)q] = base[g] + rf[(size_t)q];
-        }
-        ref_off[(size_t)n_ref] = n_reads;
-        for (int32_t r = n_ref - 1; r >= 0; --r) ref_off[(size_t)r] = first[(size_t)r] >= 0 ? first[(size_t)r] : ref_off[(size_t)r + 1];
-        ref_off[0] = 0;
-    }
-
-    // ---- full columns on every GPU: own pieces in place, the other shares over xGMI ---------------
-    std::vector<Piece> whole(n);
-    if (n_reads > 0) {
-        rc = run_all([&](size_t k) -> int {
-            HIP_TRY(hipSetDevice(ctxs[k]->device));
-            hipStream_t st = ctxs[k]->stream;
-            HIP_TRY(whole[k].alloc(*S[k].tmp, n_reads));
-            int64_t at = base[k];
-            for (auto &pp : S[k].pieces) {
-                const Piece &pc = *pp;
-                HIP_TRY(hipMemcpyAsync(whole[k].pos + at, pc.pos, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(whole[k].end + at, pc.end, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(whole[k].tlen + at, pc.tlen, (size_t)pc.n * 4, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(whole[k].flag + at, pc.flag, (size_t)pc.n * 2, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(whole[k].mapq + at, pc.mapq, (size_t)pc.n, hipMemcpyDeviceToDevice, st));
-                at += pc.n;
-            }
-            HIP_TRY(hipStreamSynchronize(st));
-            return BSIG_OK;
-        });
-        if (rc) return rc;
-        Exchange *ex = nullptr;
-        rc = exchange_open(ctxs, &ex, transport);
-        if (rc) return rc;
-        std::vector<uint8_t *> bufs(n);
-        std::vector<size_t> off(n), len(n);
-        auto gather_col = [&](size_t elt, const std::function<uint8_t *(Piece &)> &col) {
-            for (size_t g = 0; g < n; ++g) {
-                bufs[g] = col(whole[g]);
-                off[g] = (size_t)base[g] * elt;
-                len[g] = (size_t)S[g].n_reads * elt;
-            }
-            return exchange_allgather(ex, bufs, off, len);
-        };
-        rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.pos; });
-        if (!rc) rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.end; });
-        if (!rc) rc = gather_col(4, [](Piece &p) { return (uint8_t *)p.tlen; });
-        if (!rc) rc = gather_col(2, [](Piece &p) { return (uint8_t *)p.flag; });
-        if (!rc) rc = gather_col(1, [](Piece &p) { return (uint8_t *)p.mapq; });
-        for (size_t k = 0; k < n; ++k) {
-            (void)hipSetDevice(ctxs[k]->device);
-            const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
-            if (e != hipSuccess && !rc) rc = fail(BSIG_ERR_DEVICE, "exchanging the decoded columns failed on GPU %d: %s", ctxs[k]->device, hipGetErrorString(e));
-        }
-        if (rc) return rc;
-    } else if (transport) {
-        *transport = "none";
-    }
-    T[3] += now_s() - t_x;
-
-    // ---- every GPU lays the reads out ---------------------------------------------------------------
-    const double t_lay = now_s();
-    std::vector<bsig_reads *> made(n, nullptr);
-    rc = run_all([&](size_t k) -> int {
-        bsig_reads *R = new bsig_reads;
-        R->ctx = ctxs[k];
-        const int r = n_reads > 0 ? layout_from_device(ctxs[k], R, n_reads, n_ref, F.hdr.lens.data(), ref_off.data(), whole[k].pos,
-                                                       whole[k].end, whole[k].flag, whole[k].mapq, whole[k].tlen)
-                                  : layout_from_device(ctxs[k], R, 0, n_ref, F.hdr.lens.data(), ref_off.data(), nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr);
-        if (r) { delete R; return r; }
-        made[k] = R;
-        return BSIG_OK;
-    });
-    if (rc) {
-        for (bsig_reads *R : made) delete R;
-        return rc;
-    }
-    out = made;
-    T[5] = now_s() - t_lay;
+    rc = join_shares(ctxs, S, F.hdr, out, transport, T);
+    if (rc) return rc;
     T[4] = now_s() - t_begin;
     return BSIG_OK;
 }
 
 
-// The records the index lists for `regions` -> bsig_reads on ctx's device (what the reference gets
-// from one bam_itr_queryi per chunk of ranges, ref: src/bamsignals.cpp:252-271).  The merged BAI
-// chunks are independent islands of the file: each starts at a record boundary the index vouches
-// for.  Their blocks are inflated into one view, island behind island, and walked / extracted by
-// the same kernels as the whole file; the host check runs per island.  A superset of the
-// overlapping records, each at most once, in file order -- exactly what the CPU region decode
-// (bamio.cpp: bam_decode_regions) returns.
-int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiIndex &idx,
-                              const std::vector<Region> &regions, int threads, bsig_reads **out)
+namespace {
+
+// One merged BAI chunk: an independent island of the file that starts and ends at record boundaries the
+// index vouches for.
+struct Island {
+    std::vector<BgzfBlock> blocks;
+    uint64_t bytes = 0;            // uncompressed bytes of its blocks
+    uint32_t ub = 0;               // the chain starts at this offset of the first block
+    uint64_t end = 0;              // ... and ends at this offset from the start of the first block
+    bool bad = false;
+};
+
+// the islands of `regions` (a serial header walk per island, islands in parallel); kNeedsCpuPath if one is odd
+int build_islands(const std::string &path, const BaiIndex &idx, const std::vector<Region> &regions, int threads, BgzfFile &f,
+                  std::vector<Island> &isl, uint64_t &total)
 {
-    double *T = g_dev_decode_timing;
-    for (int k = 0; k < 6; ++k) T[k] = 0;
-    const double t_begin = now_s();
-    *out = nullptr;
-    BamHeader hdr;
-    int rc = bam_read_header(path, hdr);
-    if (rc) return kNeedsCpuPath;
-    const int32_t n_ref = (int32_t)hdr.names.size();
     const std::vector<BaiChunk> chunks = bai_region_chunks(idx, regions);
-    BgzfFile f;
-    rc = f.map(path);
+    int rc = f.map(path);
     if (rc) return rc;
     {
         std::vector<std::pair<uint64_t, uint64_t>> spans;
         for (const BaiChunk &c : chunks) spans.emplace_back(c.beg >> 16, (c.end >> 16) + 0x10000);
         f.populate(spans);
     }
-
-    // ---- the blocks of every island (a serial header walk per island, islands in parallel) -------
-    struct Island {
-        std::vector<BgzfBlock> blocks;
-        uint64_t bytes = 0;            // uncompressed bytes of its blocks
-        uint32_t ub = 0;               // the chain starts at this offset of the first block
-        uint64_t end = 0;              // ... and ends at this offset from the start of the first block
-        bool bad = false;
-    };
-    std::vector<Island> isl(chunks.size());
+    isl.assign(chunks.size(), Island());
     pool_for((int64_t)chunks.size(), threads, [&](int64_t i) {
         Island &I = isl[(size_t)i];
         const BaiChunk &c = chunks[(size_t)i];
@@ -1291,24 +1319,32 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         if (I.blocks.empty()) { I.end = 0; I.ub = 0; return; }
         if (I.ub > I.blocks[0].isize || I.ub > I.end) I.bad = true;
     });
-    uint64_t total = 0;
+    total = 0;
     for (const Island &I : isl) {
         if (I.bad) return kNeedsCpuPath;                        // the CPU path names the problem
         total += I.bytes;
     }
-    T[0] = now_s() - t_begin;
 
+    return BSIG_OK;
+}
+
+// Decodes islands [i0, i1) on ctx's device into pieces (share-local read numbering): their blocks are inflated
+// into one view, island behind island, walked and extracted by the same kernels as the whole file; the
+// host check runs per island.  BSIG_OK, kNeedsCpuPath or an error.
+int decode_islands(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const std::vector<Island> &isl, size_t i0, size_t i1,
+                   int threads, bool gpu_inflate, ShareOut &R)
+{
+    int rc = BSIG_OK;
+    auto bail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); return code; };
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    ScratchPool tmp(ctx->device, st);
-    std::vector<std::unique_ptr<Piece>> pieces;
-    auto bail = [&](int code) { (void)hipStreamSynchronize(st); return code; };
-    if (total == 0 || n_ref == 0) {
-        double tj = 0, tl = 0;
-        rc = finish_reads(ctx, st, tmp, pieces, 0, hdr, nullptr, tj, tl, out);
-        T[4] = now_s() - t_begin;
-        return rc;
-    }
+    R.tmp.reset(new ScratchPool(ctx->device, st));
+    ScratchPool &tmp = *R.tmp;
+    std::vector<std::unique_ptr<Piece>> &pieces = R.pieces;
+    const int32_t n_ref = (int32_t)hdr.names.size();
+    uint64_t total = 0;
+    for (size_t i = i0; i < i1; ++i) total += isl[i].bytes;
+    if (total == 0 || n_ref == 0) return BSIG_OK;          // nothing to decode: no pieces, no reads
 
     const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
     size_t batch_bytes = 32u << 20;
@@ -1320,11 +1356,11 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     std::vector<std::pair<size_t, size_t>> groups;
     uint64_t max_group = 0;
     size_t max_seg = 0;
-    for (size_t i = 0; i < isl.size();) {
+    for (size_t i = i0; i < i1;) {
         size_t j = i;
         uint64_t bytes = 0;
         size_t segs = 0;
-        while (j < isl.size() && (j == i || bytes + isl[j].bytes <= chunk_cap)) { bytes += isl[j].bytes; segs += isl[j].blocks.size() + 2; ++j; }
+        while (j < i1 && (j == i || bytes + isl[j].bytes <= chunk_cap)) { bytes += isl[j].bytes; segs += isl[j].blocks.size() + 2; ++j; }
         if (bytes > (64ull << 30)) return kNeedsCpuPath;                    // one island beyond any sensible chunk
         groups.emplace_back(i, j);
         max_group = std::max(max_group, bytes);
@@ -1334,7 +1370,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
 
     uint8_t *d_view = nullptr;
     int32_t *d_ref_len = nullptr;
-    long long *d_ref_first = nullptr;
+    long long *&d_ref_first = R.d_ref_first;
     uint64_t *d_seg_start = nullptr, *d_seg_hard = nullptr;
     uint16_t *d_off16 = nullptr;
     SegSummary *d_sum = nullptr;
@@ -1360,14 +1396,13 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     DR_TRY(tmp.alloc(&d_seg_prev, max_seg));
     if (n_ref) DR_TRY(hipMemcpyAsync(d_ref_len, hdr.lens.data(), (size_t)n_ref * sizeof(int32_t), hipMemcpyHostToDevice, st));
     DR_TRY(hipMemsetAsync(d_ref_first, 0xFF, ((size_t)n_ref + 1) * sizeof(long long), st));
-    const char *eng = getenv("BAMSIGNALS_INFLATE");
     size_t n_island_blocks = 0;
     uint64_t comp_total = 0;
-    for (const Island &I : isl) {
-        n_island_blocks += I.blocks.size();
-        for (const BgzfBlock &b : I.blocks) comp_total += b.dlen;
+    for (size_t i = i0; i < i1; ++i) {
+        n_island_blocks += isl[i].blocks.size();
+        for (const BgzfBlock &b : isl[i].blocks) comp_total += b.dlen;
     }
-    const bool gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_island_blocks, comp_total, threads);
+    (void)n_island_blocks; (void)comp_total;
     uint8_t *d_comp = nullptr, *d_lens = nullptr;
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
@@ -1394,11 +1429,12 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
     if (rc) return bail(rc);
     auto decline = [&]() { return bail(kNeedsCpuPath); };
 
-    int64_t n_reads = 0;
+    int64_t &n_reads = R.n_reads;
+    n_reads = 0;
     int32_t last_rid = -1, last_pos = -1;
     int half = 0;
     bool used[2] = {false, false};
-    double t_inflate = 0, t_wait = 0, t_gpu = 0;
+    double &t_inflate = R.t_inflate, &t_wait = R.t_wait, &t_gpu = R.t_gpu;
     std::vector<BgzfBlock> list;
     std::vector<uint64_t> seg_start, seg_hard, isl_first_seg, isl_a, isl_b, isl_v0;
     std::vector<SegSummary> sum;
@@ -1522,6 +1558,7 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
                 if (g.first != o || g.flags) return decline();
                 if (g.n_placed) {
                     if (g.first_rid < last_rid || (g.first_rid == last_rid && g.first_pos < last_pos)) return decline();
+                    if (R.first_rid < 0) { R.first_rid = g.first_rid; R.first_pos = g.first_pos; }
                     seg_n[s] = g.n_placed;
                     seg_base[s] = n_chunk;
                     seg_prev[s] = last_rid;
@@ -1548,16 +1585,126 @@ int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiI
         DR_TRY(hipStreamSynchronize(st));
         t_gpu += now_s() - t0;
     }
-    T[1] = t_inflate;
-    T[2] = t_wait;
-
 #undef DR_TRY
+    R.last_rid = last_rid; R.last_pos = last_pos;
+    return BSIG_OK;
+}
+
+// which inflate engine an index-driven decode uses (env BAMSIGNALS_INFLATE=gpu|cpu, else the cost model)
+bool islands_gpu_inflate(const std::vector<Island> &isl, int threads)
+{
+    size_t n_blocks = 0;
+    uint64_t comp_total = 0;
+    for (const Island &I : isl) {
+        n_blocks += I.blocks.size();
+        for (const BgzfBlock &b : I.blocks) comp_total += b.dlen;
+    }
+    const char *eng = getenv("BAMSIGNALS_INFLATE");
+    return eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_blocks, comp_total, threads);
+}
+
+}  // namespace
+
+// The records the index lists for `regions` -> bsig_reads on ctx's device (what the reference gets
+// from one bam_itr_queryi per chunk of ranges, ref: src/bamsignals.cpp:252-271).  The merged BAI
+// chunks are independent islands of the file: each starts at a record boundary the index vouches
+// for.  A superset of the overlapping records, each at most once, in file order -- exactly what the CPU
+// region decode (bamio.cpp: bam_decode_regions) returns.
+int reads_from_regions_device(bsig_ctx *ctx, const std::string &path, const BaiIndex &idx,
+                              const std::vector<Region> &regions, int threads, bsig_reads **out)
+{
+    double *T = g_dev_decode_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
+    *out = nullptr;
+    BamHeader hdr;
+    int rc = bam_read_header(path, hdr);
+    if (rc) return kNeedsCpuPath;
+    BgzfFile f;
+    std::vector<Island> isl;
+    uint64_t total = 0;
+    rc = build_islands(path, idx, regions, threads, f, isl, total);
+    if (rc) return rc;
+    T[0] = now_s() - t_begin;
+    ShareOut S;
+    rc = decode_islands(ctx, f, hdr, isl, 0, isl.size(), threads, islands_gpu_inflate(isl, threads), S);
+    if (rc) return rc;
+    T[1] = S.t_inflate;
+    T[2] = S.t_wait;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!S.tmp) S.tmp.reset(new ScratchPool(ctx->device, ctx->stream));
     // ---- join the pieces, first read of every reference, resident layout ---------------------------
     double t_join = 0, t_layout = 0;
-    rc = finish_reads(ctx, st, tmp, pieces, n_reads, hdr, d_ref_first, t_join, t_layout, out);
+    rc = finish_reads(ctx, ctx->stream, *S.tmp, S.pieces, S.n_reads, hdr, S.d_ref_first, t_join, t_layout, out);
     if (rc) return rc;
-    T[3] = t_gpu + t_join;
+    T[3] = S.t_gpu + t_join;
     T[5] = t_layout;
+    T[4] = now_s() - t_begin;
+    return BSIG_OK;
+}
+
+// The same with several GPUs (the single-process multi-GPU route): the islands are independent by
+// construction, so GPU g decodes a contiguous run of them (equal uncompressed bytes), and the shares are
+// joined exactly like the shares of a whole file (join_shares: order check, column all-gather over xGMI,
+// one layout per GPU).  BSIG_OK, kNeedsCpuPath (too little work to share, or a share declined) or an error.
+int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::string &path, const BaiIndex &idx, int64_t n_regions,
+                               const int32_t *rid, const int64_t *beg, const int64_t *end, int threads,
+                               std::vector<bsig_reads *> &out, const char **transport)
+{
+    double *T = g_dev_decode_timing;
+    for (int k = 0; k < 6; ++k) T[k] = 0;
+    const double t_begin = now_s();
+    const size_t n = ctxs.size();
+    out.assign(n, nullptr);
+    if (n == 0) return fail(BSIG_ERR_ARG, "no GPU given");
+    BamHeader hdr;
+    int rc = bam_read_header(path, hdr);
+    if (rc) return kNeedsCpuPath;
+    std::vector<Region> regions((size_t)std::max<int64_t>(n_regions, 0));
+    for (int64_t i = 0; i < n_regions; ++i) regions[(size_t)i] = Region{rid[i], beg[i], end[i]};
+    BgzfFile f;
+    std::vector<Island> isl;
+    uint64_t total = 0;
+    rc = build_islands(path, idx, regions, threads, f, isl, total);
+    if (rc) return rc;
+    size_t min_islands = 2;                                 // per share: fewer islands than that are not worth a GPU
+    if (const char *e = getenv("BAMSIGNALS_SHARD_MIN_ISLANDS")) min_islands = (size_t)std::max(1l, atol(e));
+    if (isl.size() < min_islands * n || total == 0) return kNeedsCpuPath;
+    std::vector<size_t> cut(n + 1, isl.size());
+    cut[0] = 0;
+    {
+        uint64_t acc = 0;
+        size_t g = 1;
+        for (size_t i = 0; i < isl.size() && g < n; ++i) {
+            acc += isl[i].bytes;
+            while (g < n && acc >= total / n * g) { cut[g] = std::min(std::max(i + 1, cut[g - 1] + 1), isl.size() - (n - g)); ++g; }
+        }
+        for (size_t q = 1; q < n; ++q) cut[q] = std::min(std::max(cut[q], cut[q - 1] + 1), isl.size() - (n - q));
+    }
+    T[0] = now_s() - t_begin;
+    const bool gpu_inflate = islands_gpu_inflate(isl, threads);
+    std::vector<ShareOut> S(n);
+    std::vector<int> rcs(n, BSIG_OK);
+    std::vector<std::string> msgs(n);
+    const int thr_each = std::max(1, decode_threads(threads) / (int)n);
+    {
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < n; ++g) {
+            auto one = [&, g] {
+                rcs[g] = decode_islands(ctxs[g], f, hdr, isl, cut[g], cut[g + 1], thr_each, gpu_inflate, S[g]);
+                if (rcs[g]) msgs[g] = g_last_error;
+            };
+            try { th.emplace_back(one); } catch (const std::system_error &) { one(); }
+        }
+        for (auto &t : th) t.join();
+        for (size_t g = 0; g < n; ++g)
+            if (rcs[g] < 0) return fail(rcs[g], "%s", msgs[g].c_str());
+        for (size_t g = 0; g < n; ++g)
+            if (rcs[g]) return rcs[g];
+    }
+    for (size_t g = 0; g < n; ++g) { T[1] = std::max(T[1], S[g].t_inflate); T[2] = std::max(T[2], S[g].t_wait); T[3] = std::max(T[3], S[g].t_gpu); }
+    rc = join_shares(ctxs, S, hdr, out, transport, T);
+    if (rc) return rc;
     T[4] = now_s() - t_begin;
     return BSIG_OK;
 }
@@ -1625,8 +1772,6 @@ int bsig_reads_from_bam_regions(bsig_ctx *ctx, bsig_bam *bam, int64_t n_regions,
     if (!ctx || !bam || !reads) return fail(BSIG_ERR_ARG, "NULL argument to bsig_reads_from_bam_regions");
     if (n_regions < 0 || (n_regions > 0 && (!rid || !beg || !end))) return fail(BSIG_ERR_ARG, "region arrays missing");
     *reads = nullptr;
-    if (bsig_bam_csi_only(bam))
-        return fail(BSIG_ERR_NOINDEX, "region queries need a .bai index (%s has a .csi index only: decode the whole file)", bsig_bam_path(bam));
     const char *mode = getenv("BAMSIGNALS_DEVICE_DECODE");
     int rc = bsig::kNeedsCpuPath;
     if (!(mode && !strcmp(mode, "0"))) {

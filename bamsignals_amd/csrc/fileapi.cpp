@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -28,9 +29,11 @@ struct bsig_bam {
     std::string path;
     bsig::BamHeader hdr;
     bsig::BaiIndex idx;
-    bool csi_only = false;      // indexed by a .csi file only: accepted, never queried (whole-file decodes)
+    bool from_csi = false;      // the index was read from a .csi file (htslib's bam_index_load accepts both, ref: :207)
     bsig::HostColumns cols;
 };
+
+const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b);
 
 namespace {
 
@@ -39,7 +42,7 @@ namespace {
 // resident in HBM
 thread_local double g_call_timing[6] = {0, 0, 0, 0, 0, 0};
 // how the calling thread's last file-level call was carried out (bsig_last_call_route)
-thread_local char g_call_route[160] = "";
+thread_local char g_call_route[320] = "";
 inline double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -73,10 +76,48 @@ void fill_columns(const bsig_bam *b, bsig_columns *c)
 // launch: calls from several host threads on resident BAMs run side by side (cold decodes take
 // turns, they use the whole GPU anyway); an entry in use is kept alive by its shared_ptr.
 // ---------------------------------------------------------------------------------------------
+// Buffers the multi-GPU result path keeps between calls (so that a call on a resident BAM does no
+// hipMalloc / hipFree / hipHostMalloc: config 5 moved 8 GB of allocations per call through the driver)
+struct SlotScratch {
+    int32_t *d_shard = nullptr;   size_t shard_cap = 0;      // this slot's result shard (device, int32 cells)
+    int32_t *h_shard = nullptr;   size_t h_cap = 0;          // ... page-locked host copy ("pcie" gather)
+};
+struct RootScratch {
+    int32_t *d_gather = nullptr;  size_t gather_cap = 0;     // RCCL receive buffer: the shards behind each other
+    int32_t *d_final = nullptr;   size_t final_cap = 0;      // the result in the caller's range order
+    int64_t *d_tab[3] = {nullptr, nullptr, nullptr};         // segment offsets, segment -> range, range offsets
+    size_t tab_cap[3] = {0, 0, 0};
+};
+struct Slots {
+    std::vector<int> devices;
+    std::vector<bsig_ctx *> ctx;
+    std::mutex run_mu;                   // one multi-GPU run at a time per device list (they share the scratch)
+    std::vector<SlotScratch> scratch;
+    RootScratch root;
+    std::atomic<int64_t> scratch_allocs{0};   // device / pinned allocations made for the scratch (tests: stays flat)
+    ~Slots()
+    {
+        for (size_t k = 0; k < scratch.size(); ++k) {
+            (void)hipSetDevice(devices[k]);
+            if (scratch[k].d_shard) (void)hipFree(scratch[k].d_shard);
+            if (scratch[k].h_shard) (void)hipHostFree(scratch[k].h_shard);
+        }
+        if (!devices.empty()) (void)hipSetDevice(devices[0]);
+        if (root.d_gather) (void)hipFree(root.d_gather);
+        if (root.d_final) (void)hipFree(root.d_final);
+        for (int64_t *t : root.d_tab) if (t) (void)hipFree(t);
+        for (bsig_ctx *c : ctx) if (c) bsig_ctx_destroy(c);
+    }
+};
 struct Resident {
-    std::string key;
+    std::string key;                     // file key + '@' + device list
+    std::shared_ptr<Slots> slots;        // the contexts the reads live on stay alive as long as the reads
     std::vector<bsig_reads *> reads;     // one per slot
     int64_t bytes = 0;                   // per GPU
+    // index-driven decodes: the (rid, beg, end) intervals the reads were decoded for, merged and sorted; a
+    // later query whose regions all lie inside them can use these reads as they are
+    std::vector<int32_t> cov_rid;
+    std::vector<int64_t> cov_beg, cov_end;
     ~Resident() { for (bsig_reads *r : reads) if (r) bsig_reads_free(r); }
 };
 struct OpenBam {
@@ -84,23 +125,21 @@ struct OpenBam {
     bsig_bam *bam = nullptr;
     ~OpenBam() { if (bam) bsig_bam_close(bam); }
 };
-struct Slots {
-    std::vector<int> devices;
-    std::vector<bsig_ctx *> ctx;
-    ~Slots() { for (bsig_ctx *c : ctx) if (c) bsig_ctx_destroy(c); }
-};
 
 struct Cache {
     std::mutex mu;                                       // guards everything below
     std::mutex decode_mu;                                // cold decodes take turns
-    std::shared_ptr<Slots> slots;
+    std::vector<std::shared_ptr<Slots>> slot_sets;       // one per device list seen (an R session alternating
+                                                         // between device= arguments keeps both sets resident)
     std::list<std::shared_ptr<OpenBam>> bams;            // most recently used first
-    std::list<std::shared_ptr<Resident>> resident;       // most recently used first
+    std::list<std::shared_ptr<Resident>> resident;       // whole files, most recently used first
+    std::list<std::shared_ptr<Resident>> regional;       // index-driven decodes, most recently used first (few)
     void clear()
     {
         resident.clear();
+        regional.clear();
         bams.clear();
-        slots.reset();
+        slot_sets.clear();
     }
 };
 Cache g_cache;
@@ -193,34 +232,65 @@ int for_each_slot(size_t n, const std::function<int(size_t)> &body)
     return BSIG_OK;
 }
 
+// grows a cached buffer of the multi-GPU result path (never shrinks; freed with the Slots)
+template <typename T>
+int grow_dev(Slots &sl, int device, T **p, size_t *cap, size_t want)
+{
+    if (*p && *cap >= want) return BSIG_OK;
+    HIP_TRY(hipSetDevice(device));
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const size_t n = std::max<size_t>(want + want / 8, 1024);          // head-room: a slightly larger call fits too
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    sl.scratch_allocs.fetch_add(1);
+    return BSIG_OK;
+}
+int grow_pinned(Slots &sl, int device, int32_t **p, size_t *cap, size_t want)
+{
+    if (*p && *cap >= want) return BSIG_OK;
+    HIP_TRY(hipSetDevice(device));
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    const size_t n = std::max<size_t>(want + want / 8, 1024);
+    HIP_TRY(hipHostMalloc((void **)p, n * sizeof(int32_t), hipHostMallocDefault));
+    *cap = n;
+    sl.scratch_allocs.fetch_add(1);
+    return BSIG_OK;
+}
+
 // ---- several GPUs: ranges are independent (each owns its output, ref: src/bamsignals.cpp:164,181,186)
 // The (rid, loc)-sorted ranges (ref: :222-226,246) are dealt round-robin to the GPUs; every GPU plans
-// and runs its shard on its own stream, driven by its own host thread.  The shards then
-//   "xgmi" (default): travel to the first GPU over xGMI (RCCL grouped send/recv, or peer copies:
-//           collect.h), are put into the caller's range order there by one kernel, and leave for the
-//           host in ONE copy (no host-side reassembly);
-//   "pcie": are pulled over each GPU's own PCIe link into page-locked buffers and put in place by host
-//           threads (bsig_scatter_segments).
-int run_on_slots(const Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, const int32_t *rid, const int32_t *loc,
+// and runs its shard on its own stream, driven by its own host thread, into a shard buffer the slot
+// keeps between calls.  The shards then reach the caller by one of
+//   "xgmi/rccl"   (default where RCCL runs): RCCL grouped send/recv into a receive buffer on the first GPU
+//                 (collect.h), put into the caller's range order there by k_place_segments, ONE download;
+//   "xgmi/direct" (default without RCCL where the first GPU can read its peers; env BAMSIGNALS_GATHER=direct):
+//                 k_place_segments on the first GPU reads every peer's shard buffer in place over xGMI --
+//                 one pass, no receive buffer -- then ONE download;
+//   "xgmi/peer":  as rccl with hipMemcpyPeerAsync (no RCCL, no peer mapping);
+//   "pcie"        (env BAMSIGNALS_GATHER=pcie): every shard over its own GPU's PCIe link into a page-locked
+//                 buffer, put in place by host threads (bsig_scatter_segments).
+// All device and page-locked buffers are kept in the Slots: a call on a resident BAM allocates nothing here.
+int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, const int32_t *rid, const int32_t *loc,
                  const int32_t *width, const int32_t *strand, const bsig_params &prm, int32_t *out, const int64_t *off,
-                 const char **gather_name)
+                 std::string &gather_name)
 {
+    std::lock_guard<std::mutex> run_lock(sl.run_mu);
+    const double t0 = now_s();
     const size_t nd = sl.ctx.size();
-    std::vector<int64_t> order((size_t)n);
-    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-        if (rid[a] != rid[b]) return rid[a] < rid[b];
-        return loc[a] < loc[b];
-    });
+    if (sl.scratch.size() != nd) sl.scratch.resize(nd);
+    std::vector<int64_t> order;
+    bsig::sort_ranges(n, rid, loc, order);
     struct Shard {
         std::vector<int64_t> which;
         std::vector<int32_t> rid, loc, len, strand;
         bsig_plan *plan = nullptr;
-        int32_t *host = nullptr;
-        int32_t *dev = nullptr;
         int64_t cells = 0;
     };
     std::vector<Shard> sh(nd);
+    for (size_t k = 0; k < nd; ++k) {
+        const size_t cap = (size_t)n / nd + 1;
+        sh[k].which.reserve(cap); sh[k].rid.reserve(cap); sh[k].loc.reserve(cap); sh[k].len.reserve(cap); sh[k].strand.reserve(cap);
+    }
     for (int64_t k = 0; k < n; ++k) {
         Shard &S = sh[(size_t)(k % (int64_t)nd)];
         const int64_t i = order[(size_t)k];
@@ -229,100 +299,184 @@ int run_on_slots(const Slots &sl, const std::vector<bsig_reads *> &reads, int64_
         S.len.push_back(width[i]); S.strand.push_back(strand[i]);
     }
     const bool pcie = env_is("BAMSIGNALS_GATHER", "pcie");
-    *gather_name = pcie ? "pcie" : "xgmi";
-    std::vector<void *> dev_tmp;                       // device buffers of the xgmi route (first GPU)
+    gather_name = pcie ? "pcie" : "xgmi";
     auto cleanup = [&]() {
-        for (size_t k = 0; k < nd; ++k) {
-            Shard &S = sh[k];
-            if (S.plan) bsig_plan_free(S.plan);
-            if (S.host) bsig_host_free(S.host);
-            if (S.dev) { (void)hipSetDevice(sl.devices[k]); (void)hipFree(S.dev); }
-        }
-        if (!dev_tmp.empty()) (void)hipSetDevice(sl.devices[0]);
-        for (void *p : dev_tmp) (void)hipFree(p);
+        for (Shard &S : sh)
+            if (S.plan) { bsig_plan_free(S.plan); S.plan = nullptr; }
     };
     // plan + launch, one host thread per GPU
     int rc = for_each_slot(nd, [&](size_t k) -> int {
         Shard &S = sh[k];
+        SlotScratch &X = sl.scratch[k];
         int r = bsig_plan_create(sl.ctx[k], reads[k], (int64_t)S.which.size(), S.rid.data(), S.loc.data(), S.len.data(),
                                  S.strand.data(), &prm, &S.plan);
         if (r) return r;
         S.cells = bsig_plan_cells(S.plan);
-        if (pcie) {
-            r = bsig_host_alloc(S.cells * (int64_t)sizeof(int32_t), (void **)&S.host);
-            if (r) return r;
-            r = bsig_plan_run_host_async(S.plan, S.host);
-        } else {
-            HIP_TRY(hipSetDevice(sl.devices[k]));
-            HIP_TRY(hipMalloc((void **)&S.dev, (size_t)std::max<int64_t>(S.cells, 4) * sizeof(int32_t)));
-            r = bsig_plan_run(S.plan, S.dev);
+        // every segment must fit its destination: the caller's offsets are only trusted after this check
+        const int64_t *po = bsig_plan_offsets(S.plan);
+        for (size_t j = 0; j < S.which.size(); ++j) {
+            const int64_t w = S.which[j];
+            if (po[j + 1] - po[j] != off[w + 1] - off[w])
+                return fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters");
         }
+        r = grow_dev(sl, sl.devices[k], &X.d_shard, &X.shard_cap, (size_t)std::max<int64_t>(S.cells, 4));
         if (r) return r;
+        r = bsig_plan_run(S.plan, X.d_shard);
+        if (r) return r;
+        if (pcie && S.cells) {
+            r = grow_pinned(sl, sl.devices[k], &X.h_shard, &X.h_cap, (size_t)S.cells);
+            if (r) return r;
+            HIP_TRY(hipMemcpyAsync(X.h_shard, X.d_shard, (size_t)S.cells * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   (hipStream_t)bsig_ctx_stream(sl.ctx[k])));
+        }
         return bsig_ctx_sync(sl.ctx[k]);
     });
     if (rc) { cleanup(); return rc; }
+    const double t1 = now_s();
+    int64_t cells = 0;
+    for (size_t k = 0; k < nd; ++k) cells += sh[k].cells;
+    const int64_t total = off[n];
+    if (cells != total) { cleanup(); return fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters"); }
+    char times[96];
     if (pcie) {
         for (size_t k = 0; k < nd && rc == BSIG_OK; ++k)
-            rc = bsig_scatter_segments((int64_t)sh[k].which.size(), sh[k].host, bsig_plan_offsets(sh[k].plan), out, off,
+            rc = bsig_scatter_segments((int64_t)sh[k].which.size(), sl.scratch[k].h_shard, bsig_plan_offsets(sh[k].plan), out, off,
                                        sh[k].which.data());
         cleanup();
+        snprintf(times, sizeof times, " (plan+run+d2h %.3f s, host scatter %.3f s)", t1 - t0, now_s() - t1);
+        gather_name += times;
         return rc;
     }
-    // ---- xgmi: gather on the first GPU, reassemble there, one download ------------------------------
-    const int64_t total = off[n];
-    std::vector<size_t> goff(nd), glen(nd);
-    std::vector<const uint8_t *> src(nd);
-    std::vector<int64_t> seg_off, seg_which;           // all shards' segments behind each other
-    seg_off.reserve((size_t)n + 1);
-    seg_which.reserve((size_t)n);
-    int64_t cells = 0;
-    for (size_t k = 0; k < nd; ++k) {
-        goff[k] = (size_t)cells * sizeof(int32_t);
-        glen[k] = (size_t)sh[k].cells * sizeof(int32_t);
-        src[k] = (const uint8_t *)sh[k].dev;
-        const int64_t *po = bsig_plan_offsets(sh[k].plan);
-        for (size_t j = 0; j < sh[k].which.size(); ++j) {
-            seg_off.push_back(cells + po[j]);
-            seg_which.push_back(sh[k].which[j]);
-        }
-        cells += sh[k].cells;
-    }
-    seg_off.push_back(cells);
-    if (cells != total) { cleanup(); return fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters"); }
     if (total == 0) { cleanup(); return BSIG_OK; }
+    // ---- xgmi: the shards meet on the first GPU, in the caller's range order, and leave in one download ----
+    double t2 = t1, t3 = t1;
     auto body = [&]() -> int {
-        HIP_TRY(hipSetDevice(sl.devices[0]));
+        RootScratch &G = sl.root;
+        const int dev0 = sl.devices[0];
         hipStream_t st = (hipStream_t)bsig_ctx_stream(sl.ctx[0]);
-        int32_t *d_gather = nullptr, *d_final = nullptr;
-        int64_t *d_seg_off = nullptr, *d_which = nullptr, *d_dst_off = nullptr;
-        auto dalloc = [&](void **p, size_t bytes) { const hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16)); if (e == hipSuccess) dev_tmp.push_back(*p); return e; };
-        HIP_TRY(dalloc((void **)&d_gather, (size_t)total * sizeof(int32_t)));
-        HIP_TRY(dalloc((void **)&d_final, (size_t)total * sizeof(int32_t)));
-        HIP_TRY(dalloc((void **)&d_seg_off, seg_off.size() * sizeof(int64_t)));
-        HIP_TRY(dalloc((void **)&d_which, std::max<size_t>(seg_which.size(), 1) * sizeof(int64_t)));
-        HIP_TRY(dalloc((void **)&d_dst_off, (size_t)(n + 1) * sizeof(int64_t)));
-        HIP_TRY(hipMemcpyAsync(d_seg_off, seg_off.data(), seg_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_which, seg_which.data(), seg_which.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_dst_off, off, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        bsig::Exchange *ex = nullptr;
-        const char *transport = nullptr;
-        int r = bsig::exchange_open(sl.ctx, &ex, &transport);
-        if (r) return r;
-        *gather_name = !strcmp(transport, "rccl") ? "xgmi/rccl" : "xgmi/peer";
-        r = bsig::exchange_gather(ex, src, glen, (uint8_t *)d_gather, goff);
-        if (r) return r;
-        for (size_t k = 1; k < nd; ++k) {              // the senders' streams (RCCL queues the sends there)
-            r = bsig_ctx_sync(sl.ctx[k]);
-            if (r) return r;
+        // tables: per shard its local segment offsets (n_k + 1 entries) and segment -> range; the ranges' offsets
+        std::vector<int64_t> seg_off, seg_which;
+        seg_off.reserve((size_t)n + nd);
+        seg_which.reserve((size_t)n);
+        std::vector<size_t> seg_base(nd), which_base(nd);
+        for (size_t k = 0; k < nd; ++k) {
+            seg_base[k] = seg_off.size();
+            which_base[k] = seg_which.size();
+            const int64_t *po = bsig_plan_offsets(sh[k].plan);
+            seg_off.insert(seg_off.end(), po, po + sh[k].which.size() + 1);
+            seg_which.insert(seg_which.end(), sh[k].which.begin(), sh[k].which.end());
         }
-        HIP_TRY(hipSetDevice(sl.devices[0]));
-        HIP_TRY(bsig::launch_place_segments((int64_t)seg_which.size(), d_gather, d_seg_off, d_final, d_dst_off, d_which, st));
-        return bsig::download_to_host(sl.ctx[0], d_final, out, (size_t)total * sizeof(int32_t));
+        int r = grow_dev(sl, dev0, &G.d_final, &G.final_cap, (size_t)total);
+        if (!r) r = grow_dev(sl, dev0, &G.d_tab[0], &G.tab_cap[0], seg_off.size());
+        if (!r) r = grow_dev(sl, dev0, &G.d_tab[1], &G.tab_cap[1], std::max<size_t>(seg_which.size(), 1));
+        if (!r) r = grow_dev(sl, dev0, &G.d_tab[2], &G.tab_cap[2], (size_t)n + 1);
+        if (r) return r;
+        HIP_TRY(hipSetDevice(dev0));
+        HIP_TRY(hipMemcpyAsync(G.d_tab[0], seg_off.data(), seg_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(G.d_tab[1], seg_which.data(), seg_which.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(G.d_tab[2], off, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        bsig::ExchangeUse use;            // holds the exchange's lock until the streams are synchronised below
+        r = bsig::exchange_open(sl.ctx, use);
+        if (r) return r;
+        // (env BAMSIGNALS_GATHER=direct: in-place reads even where RCCL runs; =copy: a receive buffer even where
+        // in-place reads are possible -- both exist so that an 8-GPU node can time all three)
+        const bool want_direct = env_is("BAMSIGNALS_GATHER", "direct"), want_copy = env_is("BAMSIGNALS_GATHER", "copy");
+        const bool rccl = !strcmp(use.transport, "rccl") && !want_direct;
+        const bool direct = !rccl && !want_copy && bsig::exchange_root_reads_peers(use);
+        std::vector<const int32_t *> from(nd);          // where the place kernel finds shard k
+        if (direct) {
+            for (size_t k = 0; k < nd; ++k) from[k] = sl.scratch[k].d_shard;
+            gather_name = "xgmi/direct";
+        } else {
+            r = grow_dev(sl, dev0, &G.d_gather, &G.gather_cap, (size_t)total);
+            if (r) return r;
+            std::vector<size_t> goff(nd), glen(nd);
+            std::vector<const uint8_t *> src(nd);
+            int64_t at = 0;
+            for (size_t k = 0; k < nd; ++k) {
+                goff[k] = (size_t)at * sizeof(int32_t);
+                glen[k] = (size_t)sh[k].cells * sizeof(int32_t);
+                src[k] = (const uint8_t *)sl.scratch[k].d_shard;
+                from[k] = G.d_gather + at;
+                at += sh[k].cells;
+            }
+            // (the first GPU's own shard is read in place: no copy into the receive buffer)
+            from[0] = sl.scratch[0].d_shard;
+            glen[0] = 0;
+            r = bsig::exchange_gather(use, src, glen, (uint8_t *)G.d_gather, goff);
+            if (r) return r;
+            gather_name = std::string("xgmi/") + use.transport;
+            for (size_t k = 1; k < nd; ++k) {              // the senders' streams (RCCL queues the sends there)
+                r = bsig_ctx_sync(sl.ctx[k]);
+                if (r) return r;
+            }
+        }
+        HIP_TRY(hipSetDevice(dev0));
+        for (size_t k = 0; k < nd; ++k)
+            HIP_TRY(bsig::launch_place_segments((int64_t)sh[k].which.size(), from[k], G.d_tab[0] + seg_base[k], G.d_final, G.d_tab[2],
+                                                G.d_tab[1] + which_base[k], st));
+        HIP_TRY(hipStreamSynchronize(st));
+        use.release();
+        t2 = now_s();
+        r = bsig::download_to_host(sl.ctx[0], G.d_final, out, (size_t)total * sizeof(int32_t));
+        t3 = now_s();
+        return r;
     };
     rc = body();
     if (rc) for (size_t k = 0; k < nd; ++k) (void)bsig_ctx_sync(sl.ctx[k]);
     cleanup();
+    snprintf(times, sizeof times, " (plan+run %.3f s, gather+place %.3f s, download %.3f s)", t1 - t0, t2 - t1, t3 - t2);
+    gather_name += times;
     return rc;
+}
+
+// size + mtime of every index file a BAM may be opened with (<bam>.bai, <stem>.bai, <bam>.csi, <stem>.csi;
+// bsig_bam_open tries them in this order): whichever one is used, replacing, adding or removing it
+// changes the stamp, so cached headers, resident reads and reads files are never tied to a stale index
+std::string index_stamps(const std::string &bam)
+{
+    std::string stem = bam;
+    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".bam") == 0) stem.erase(stem.size() - 4);
+    std::string out;
+    for (const std::string &cand : {bam + ".bai", stem + ".bai", bam + ".csi", stem + ".csi"}) out += file_stamp(cand) + ";";
+    return out;
+}
+
+// An index-driven decode remembers the intervals it was made for (merged, sorted by reference and start).
+void set_coverage(Resident &R, int64_t n, const int32_t *rid, const int64_t *beg, const int64_t *end)
+{
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return rid[a] != rid[b] ? rid[a] < rid[b] : beg[a] < beg[b]; });
+    R.cov_rid.clear(); R.cov_beg.clear(); R.cov_end.clear();
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t i = order[(size_t)k];
+        if (end[i] <= beg[i]) continue;
+        if (!R.cov_rid.empty() && R.cov_rid.back() == rid[i] && beg[i] <= R.cov_end.back()) {
+            R.cov_end.back() = std::max(R.cov_end.back(), end[i]);
+        } else {
+            R.cov_rid.push_back(rid[i]); R.cov_beg.push_back(beg[i]); R.cov_end.push_back(end[i]);
+        }
+    }
+}
+// ... and serves a later query whose every region lies inside one of them: the BAI query of the earlier
+// call returned every record overlapping its intervals, hence every record overlapping a sub-interval
+bool regions_covered(const Resident &R, int64_t n, const int32_t *rid, const int64_t *beg, const int64_t *end)
+{
+    const size_t m = R.cov_rid.size();
+    for (int64_t i = 0; i < n; ++i) {
+        if (end[i] <= beg[i]) continue;
+        // last interval with (rid, beg) <= (rid[i], beg[i])
+        size_t lo = 0, hi = m;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (R.cov_rid[mid] < rid[i] || (R.cov_rid[mid] == rid[i] && R.cov_beg[mid] <= beg[i])) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0) return false;
+        const size_t k = lo - 1;
+        if (R.cov_rid[k] != rid[i] || R.cov_end[k] < end[i]) return false;
+    }
+    return true;
 }
 
 // the common body of pileup_core / coverage_core
@@ -345,7 +499,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     char resolved[4096];
     const std::string canon = realpath(bampath, resolved) ? std::string(resolved) : std::string(bampath);
     const std::string key = file_key(canon);
-    const std::string bkey = key.empty() ? std::string() : key + "#" + file_key(canon + ".bai");
+    const std::string bkey = key.empty() ? std::string() : key + "#" + index_stamps(canon);
     int rc = BSIG_OK;
     std::shared_ptr<OpenBam> ob;
     if (!bkey.empty()) {
@@ -396,14 +550,17 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                                                  : std::llabs((long long)prm.shift) + (mid ? prm.tlen_filter[1] : 0);
     if (ext < 0) return fail(BSIG_ERR_EXT, "negative 'ext' values don't make sense");             // ref: :243
 
-    // the GPUs of this call (a changed list drops everything that lives on the old one)
+    // the GPUs of this call: every device list seen keeps its own contexts, scratch and resident BAMs (a
+    // session that alternates between two device= arguments keeps both copies; the LRU budget bounds them)
     const std::vector<int> devs = pick_devices(device);
+    std::string dev_tag = "@";
+    for (int d : devs) dev_tag += std::to_string(d) + ",";
     std::shared_ptr<Slots> slots;
     {
         std::lock_guard<std::mutex> lock(g_cache.mu);
-        if (!g_cache.slots || g_cache.slots->devices != devs) {
-            g_cache.resident.clear();
-            g_cache.slots.reset();
+        for (auto &sp : g_cache.slot_sets)
+            if (sp->devices == devs) slots = sp;
+        if (!slots) {
             auto fresh = std::make_shared<Slots>();
             fresh->devices = devs;
             for (int d : devs) {
@@ -412,9 +569,9 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                 if (rc) return rc;
                 fresh->ctx.push_back(c);
             }
-            g_cache.slots = fresh;
+            g_cache.slot_sets.push_back(fresh);
+            slots = fresh;
         }
-        slots = g_cache.slots;
     }
     const size_t nd = devs.size();
     const bool many = nd > 1 || env_is("BAMSIGNALS_FORCE_SHARDED", "1");     // (=1: the multi-GPU route on one GPU, testing)
@@ -431,28 +588,59 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     bool whole = wanted * 3 > genome;
     if (force && !strcmp(force, "all")) whole = true;
     if (force && !strcmp(force, "regions")) whole = false;
-    if (bam->csi_only) whole = true;
+
+    // the regions an index-driven decode would ask the BAI for (ref: :252-267): range +- ext
+    std::vector<int64_t> qbeg, qend;
+    if (!whole) {
+        qbeg.resize((size_t)n); qend.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            qbeg[(size_t)i] = (int64_t)loc[(size_t)i] - ext;
+            qend[(size_t)i] = (int64_t)loc[(size_t)i] + width[i] + ext;
+        }
+    }
 
     // ---- the reads of this call on every GPU -------------------------------------------------------
+    const std::string rkey = bkey + dev_tag;
     std::shared_ptr<Resident> res;
     std::string how_decoded = "resident";
-    if (!key.empty()) {
+    // a whole file resident on these GPUs serves every query; failing that, an earlier index-driven decode
+    // whose regions contain this call's (repeated bamCount / bamProfile on the same few ranges)
+    auto lookup = [&]() {
+        if (key.empty()) return;
         std::lock_guard<std::mutex> lock(g_cache.mu);
         for (auto it = g_cache.resident.begin(); it != g_cache.resident.end(); ++it)
-            if ((*it)->key == bkey) {
+            if ((*it)->key == rkey) {
                 res = *it;
                 g_cache.resident.erase(it);
                 g_cache.resident.push_front(res);
-                break;
+                how_decoded = "resident";
+                return;
             }
-    }
+        if (whole) return;
+        for (auto it = g_cache.regional.begin(); it != g_cache.regional.end(); ++it)
+            if ((*it)->key == rkey && regions_covered(**it, n, rid.data(), qbeg.data(), qend.data())) {
+                res = *it;
+                g_cache.regional.erase(it);
+                g_cache.regional.push_front(res);
+                how_decoded = "resident (index-driven decode of an earlier call)";
+                return;
+            }
+    };
+    lookup();
+    std::string side_to_write, side_stamp;
     if (res) {
         T[5] = 1;
     } else {
-        std::lock_guard<std::mutex> dlock(g_cache.decode_mu);
+        std::unique_lock<std::mutex> dlock(g_cache.decode_mu);
+        // another thread may have decoded this very file while this one waited for its turn
+        lookup();
+        if (res) {
+            T[5] = 1;
+        } else {
         const double t_dec = now_s();
         res = std::make_shared<Resident>();
-        res->key = bkey;
+        res->key = rkey;
+        res->slots = slots;
         res->reads.assign(nd, nullptr);
         auto clone_rest = [&]() -> int {
             return for_each_slot(nd, [&](size_t k) -> int {
@@ -463,8 +651,8 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         if (whole) {
             const std::string side = key.empty() ? std::string() : sidecar_path(bampath);
             // (the reads file is tied to the CONTENT it was made from -- size and mtime of the BAM and of its
-            // index -- not to the spelling of the path it was reached by)
-            const std::string side_stamp = file_stamp(bampath) + "#" + file_stamp(std::string(bampath) + ".bai");
+            // index files -- not to the spelling of the path it was reached by)
+            side_stamp = file_stamp(bampath) + "#" + index_stamps(bampath);
             bool loaded = false;
             if (!side.empty()) {
                 // a second process (or a call after the BAM left the cache) skips inflate and parse
@@ -497,29 +685,40 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                     how_decoded = nd > 1 ? "decode on the first GPU + clones" : "decode";
                 }
                 if (rc) return rc;
-                if (!side.empty()) (void)bsig_reads_save(res->reads[0], side.c_str(), side_stamp.c_str());   // best effort
+                side_to_write = side;          // written after the decode lock is released (best effort)
             }
         } else {
             // index-driven: only the blocks the BAI lists for the ranges (ref: one bam_itr_queryi per
-            // chunk of ranges, :252-267), parsed on the first GPU like the whole file; not cached
-            std::vector<int64_t> beg((size_t)n), end((size_t)n);
-            for (int64_t i = 0; i < n; ++i) {
-                beg[(size_t)i] = (int64_t)loc[(size_t)i] - ext;
-                end[(size_t)i] = (int64_t)loc[(size_t)i] + width[i] + ext;
-            }
-            rc = bsig_reads_from_bam_regions(slots->ctx[0], bam, n, rid.data(), beg.data(), end.data(), 0, &res->reads[0]);
-            bsig_device_decode_timing(t6);
-            if (rc == BSIG_OK) rc = clone_rest();
-            if (rc) return rc;
+            // chunk of ranges, :252-267), parsed on the GPU like the whole file.  With several GPUs the
+            // islands are dealt to them and the column shares all-gathered (devdecode.hip).
+            rc = bsig::kNeedsCpuPath;
             how_decoded = "index-driven decode";
+            if (many && !env_is("BAMSIGNALS_DEVICE_DECODE", "0") && !env_is("BAMSIGNALS_SHARDED_DECODE", "0")) {
+                const char *transport = "";
+                rc = bsig::reads_from_regions_sharded(slots->ctx, bampath, *bsig_bam_index(bam), n, rid.data(), qbeg.data(), qend.data(),
+                                                      0, res->reads, &transport);
+                if (rc == BSIG_OK) how_decoded = std::string("index-driven decode, sharded, columns over ") + transport;
+                bsig_device_decode_timing(t6);
+            }
+            if (rc == bsig::kNeedsCpuPath) {
+                rc = bsig_reads_from_bam_regions(slots->ctx[0], bam, n, rid.data(), qbeg.data(), qend.data(), 0, &res->reads[0]);
+                bsig_device_decode_timing(t6);
+                if (rc == BSIG_OK) rc = clone_rest();
+            }
+            if (rc) return rc;
+            set_coverage(*res, n, rid.data(), qbeg.data(), qend.data());
         }
         T[2] = t6[5];
         T[1] = now_s() - t_dec - T[2];
-        if (whole && !key.empty()) {
+        if (!key.empty()) {
             bsig_reads_info inf;
             if (bsig_reads_get_info(res->reads[0], &inf) == BSIG_OK) res->bytes = inf.hbm_bytes;
             std::lock_guard<std::mutex> lock(g_cache.mu);
-            if (g_cache.slots == slots) {                  // (the GPU list may have changed meanwhile)
+            bool still = false;                            // (bsig_cache_clear may have run meanwhile)
+            for (auto &sp : g_cache.slot_sets) still = still || sp == slots;
+            if (still && whole) {
+                for (auto it = g_cache.resident.begin(); it != g_cache.resident.end();)
+                    it = (*it)->key == rkey ? g_cache.resident.erase(it) : std::next(it);
                 g_cache.resident.push_front(res);
                 const int64_t budget = cache_budget_bytes();
                 int64_t held = 0;
@@ -528,18 +727,27 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
                     if (held > budget && it != g_cache.resident.begin()) it = g_cache.resident.erase(it);
                     else ++it;
                 }
+            } else if (still) {
+                // index-driven decodes are small by construction (less than a third of the genome): keep the
+                // last few (env BAMSIGNALS_REGION_CACHE, default 8; 0 = the reference's behaviour, none)
+                size_t keep = 8;
+                if (const char *e = getenv("BAMSIGNALS_REGION_CACHE")) keep = (size_t)std::max(0, atoi(e));
+                if (keep) g_cache.regional.push_front(res);
+                while (g_cache.regional.size() > keep) g_cache.regional.pop_back();
             }
         }
+        }
     }
+    if (!side_to_write.empty()) (void)bsig_reads_save(res->reads[0], side_to_write.c_str(), side_stamp.c_str());
 
     const double t_run = now_s();
-    const char *gather = "";
+    std::string gather;
     if (!many) rc = bsig_pileup_columns(slots->ctx[0], res->reads[0], n, rid.data(), loc.data(), width, strand, &prm, out, off);
-    else rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, &gather);
+    else rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, gather);
     T[3] = now_s() - t_run;
     T[4] = now_s() - t_begin;
     snprintf(g_call_route, sizeof g_call_route, "%zu GPU slot(s); reads: %s; result: %s", nd, how_decoded.c_str(),
-             many ? gather : "download");
+             many ? gather.c_str() : "download");
     return rc;
 }
 
@@ -565,17 +773,12 @@ int bsig_bam_open(const char *path, bsig_bam **out)
             if (bsig::bai_load(alt, b->idx) == 0) rc = 0;
         }
         if (rc) {
-            // htslib's bam_index_load (ref: src/bamsignals.cpp:207) also accepts a CSI index (references
-            // beyond 2^29 bp need one).  Its bins are not read here: a file indexed that way is always
-            // decoded whole, which needs no index at all
+            // htslib's bam_index_load (ref: src/bamsignals.cpp:207) also accepts a CSI index (references beyond
+            // 2^29 bp need one): <bam>.csi, then <stem>.csi.  A file of that name that does not inflate to a
+            // CSIv1 index is not an index: the reference's "not available" error stands
             for (const std::string &cand : {b->path + ".csi", alt.size() > 4 ? alt.substr(0, alt.size() - 4) + ".csi" : std::string()}) {
                 if (cand.empty()) continue;
-                FILE *f = fopen(cand.c_str(), "rb");
-                if (!f) continue;
-                unsigned char magic[4] = {0, 0, 0, 0};
-                const bool gz = fread(magic, 1, 4, f) == 4 && magic[0] == 31 && magic[1] == 139;     // CSI files are BGZF-compressed
-                fclose(f);
-                if (gz) { b->csi_only = true; rc = 0; break; }
+                if (bsig::csi_load(cand, b->idx) == 0) { b->from_csi = true; rc = 0; break; }
             }
         }
         if (rc) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", path);
@@ -590,7 +793,6 @@ void bsig_bam_close(bsig_bam *b) { delete b; }
 const char *bsig_bam_path(const bsig_bam *b) { return b ? b->path.c_str() : nullptr; }
 }  // extern "C"
 const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b) { return &b->idx; }
-bool bsig_bam_csi_only(const bsig_bam *b) { return b->csi_only; }
 extern "C" {
 
 int32_t bsig_bam_n_ref(const bsig_bam *b) { return b ? (int32_t)b->hdr.names.size() : 0; }
@@ -617,7 +819,6 @@ int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const in
         rc = bsig::bam_decode_all(b->path, threads, h, b->cols);
     } else {
         if (n_regions > 0 && (!rid || !beg || !end)) return fail(BSIG_ERR_ARG, "region arrays missing");
-        if (b->csi_only) return fail(BSIG_ERR_NOINDEX, "region queries need a .bai index (%s has a .csi index only: decode the whole file)", b->path.c_str());
         std::vector<bsig::Region> rg((size_t)n_regions);
         for (int64_t i = 0; i < n_regions; ++i) rg[(size_t)i] = bsig::Region{rid[i], beg[i], end[i]};
         rc = bsig::bam_decode_regions(b->path, b->idx, rg, threads, h, b->cols);
@@ -780,14 +981,89 @@ int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off,
     return BSIG_OK;
 }
 
+struct bsig_segmap {
+    bsig_ctx *ctx = nullptr;
+    int64_t n = 0;
+    int64_t *d_src_off = nullptr, *d_dst_off = nullptr, *d_which = nullptr;
+};
+
+int bsig_segmap_create(bsig_ctx *ctx, int64_t n, const int64_t *src_off, int64_t n_dst, const int64_t *dst_off,
+                       const int64_t *which, bsig_segmap **out)
+{
+    if (!ctx || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_segmap_create");
+    *out = nullptr;
+    if (n < 0 || n_dst < 0 || (n > 0 && (!src_off || !dst_off || !which))) return fail(BSIG_ERR_ARG, "segment tables missing");
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t len = src_off[k + 1] - src_off[k];
+        const int64_t i = which[k];
+        if (len < 0 || src_off[k] < 0 || i < 0 || i >= n_dst) return fail(BSIG_ERR_ARG, "bad segment %lld", (long long)k);
+        if (dst_off[i] < 0 || len != dst_off[i + 1] - dst_off[i]) return fail(BSIG_ERR_ARG, "segment %lld does not fit its destination", (long long)k);
+    }
+    std::unique_ptr<bsig_segmap> M(new bsig_segmap);
+    M->ctx = ctx;
+    M->n = n;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMalloc((void **)&M->d_src_off, (size_t)(n + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&M->d_dst_off, (size_t)(n_dst + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&M->d_which, (size_t)std::max<int64_t>(n, 1) * sizeof(int64_t));
+    const int64_t zero = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(M->d_src_off, n ? src_off : &zero, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(M->d_dst_off, dst_off ? dst_off : &zero, (size_t)(n_dst + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(M->d_which, which, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        bsig_segmap_free(M.release());
+        return fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "segment map upload failed: %s", hipGetErrorString(e));
+    }
+    *out = M.release();
+    return BSIG_OK;
+}
+
+int bsig_segmap_run(bsig_segmap *M, const int32_t *src_dev, int32_t *dst_dev)
+{
+    if (!M) return fail(BSIG_ERR_ARG, "segment map is NULL");
+    if (M->n == 0) return BSIG_OK;
+    if (!src_dev || !dst_dev) return fail(BSIG_ERR_ARG, "NULL device buffer");
+    HIP_TRY(hipSetDevice(M->ctx->device));
+    HIP_TRY(bsig::launch_place_segments(M->n, src_dev, M->d_src_off, dst_dev, M->d_dst_off, M->d_which, M->ctx->stream));
+    return BSIG_OK;
+}
+
+void bsig_segmap_free(bsig_segmap *M)
+{
+    if (!M) return;
+    (void)hipSetDevice(M->ctx->device);
+    if (M->d_src_off) (void)hipFree(M->d_src_off);
+    if (M->d_dst_off) (void)hipFree(M->d_dst_off);
+    if (M->d_which) (void)hipFree(M->d_which);
+    delete M;
+}
+
 void bsig_cache_clear(void)
 {
+    // everything is moved out under the lock and released outside it (freeing HBM takes a while); what a
+    // running call holds -- its contexts, scratch, resident reads, communicators -- lives until it returns
+    Cache old;
     {
         std::lock_guard<std::mutex> lock(g_cache.mu);
-        g_cache.clear();
+        old.resident.swap(g_cache.resident);
+        old.regional.swap(g_cache.regional);
+        old.bams.swap(g_cache.bams);
+        old.slot_sets.swap(g_cache.slot_sets);
     }
+    old.clear();
     bsig::exchange_close_all();
     bsig::release_decode_scratch();
+}
+
+int64_t bsig_debug_scratch_allocs(void)
+{
+    // allocations made so far for the multi-GPU result path's cached buffers (tests: flat across resident calls)
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    int64_t n = 0;
+    for (auto &sp : g_cache.slot_sets) n += sp->scratch_allocs.load();
+    return n;
 }
 
 const char *bsig_last_call_route(void) { return g_call_route; }

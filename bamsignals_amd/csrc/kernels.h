@@ -38,6 +38,10 @@ hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, cons
                           const uint16_t *flag, const uint8_t *mapq, const int32_t *tlen,
                           const uint64_t *chunk_base, const ScatterPtrs &S, hipStream_t st);
 hipError_t launch_build_idx(int64_t n, const uint32_t *gb, uint64_t n_buckets, uint32_t *idx, hipStream_t st);
+// 64-bit order-independent checksum of n_words 32-bit words, ADDED into *acc (device)
+hipError_t launch_checksum(const void *words, uint64_t n_words, uint64_t salt, unsigned long long *acc, hipStream_t st);
+// *bad (device) = 1 unless idx[0..n_buckets] is non-decreasing, <= n_reads, and ends at n_reads
+hipError_t launch_check_idx(const uint32_t *idx, uint64_t n_buckets, uint32_t n_reads, int *bad, hipStream_t st);
 hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
                          int64_t n_items, unsigned long long *acc, hipStream_t st);
 

@@ -13,6 +13,9 @@
 //   k_visits    counts read visits for the roofline figure
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "bsig_types.h"
 #include "kernels.h"
@@ -194,11 +197,10 @@ __global__ void k_count_heavy(const uint2 *__restrict__ windows, int64_t n_items
 // ONE memory round trip for its reads: the first kPre0 passes (kPre0 * 4 * NT reads) of class 0,
 // where nearly all reads live, and the first pass of class 1.  Longer windows and the two
 // long-span classes continue in plain loops.
-template <int NT, typename F>
+template <int NT, int kPre0 = 4, typename F>
 __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
                                               const uint2 (&win)[BSIG_MAX_CLASSES], int tid, F &&one)
 {
-    constexpr int kPre0 = 4;
     int4 p0[kPre0], t0[kPre0], p1, e1, t1 = make_int4(0, 0, 0, 0);
     uint4 f0[kPre0], f1;
     const uint32_t jb0 = (win[0].x & ~3u) + 4u * tid;
@@ -538,6 +540,80 @@ __global__ __launch_bounds__(NT) void k_count(const BsigWorkItem *__restrict__ i
     }
 }
 
+// bamCount, several consecutive tiles per wave.  A count tile moves one dword out and has no LDS image,
+// so nothing but the dependent chain item -> index -> reads fills a wave's lifetime.  Here lane t of
+// the wave fetches the work item of tile t of its group and looks up that tile's windows (T chains
+// side by side instead of one behind the other); the tiles are then streamed one after the other
+// with the windows broadcast from their lane, and lane t stores tile t's counters at the end.
+template <int T, int PRE>
+__global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
+                                                       int32_t *__restrict__ out,
+                                                       const uint2 *__restrict__ windows,
+                                                       const BsigReadsDev R, const BsigKParams P)
+{
+    __shared__ uint32_t stage[T][12];      // per tile: 4 windows, first base, bases, flags
+    const int lane = threadIdx.x;
+    const uint32_t n_groups = (n_tiles + T - 1) / T;
+    const uint32_t first = tile_of_block(blockIdx.x, n_groups) * T;
+    const uint32_t n_here = n_tiles - first < (uint32_t)T ? n_tiles - first : (uint32_t)T;      // uniform
+    const bool have = (uint32_t)lane < n_here;
+    int64_t out_off = 0;
+    bool atomic = false;
+    if (have) {
+        const BsigWorkItem w = items[first + lane];
+        uint2 win[BSIG_MAX_CLASSES];
+        load_windows(R, P, BSIG_MODE_COUNT, w, items, nullptr, win, first + lane);
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { stage[lane][2 * c] = win[c].x; stage[lane][2 * c + 1] = win[c].y; }
+        stage[lane][8] = (uint32_t)(w.loc + w.c0);
+        stage[lane][9] = (uint32_t)w.nc;
+        stage[lane][10] = w.units_strand;
+        out_off = w.out_off;
+        atomic = (w.units_strand & BSIG_ITEM_ATOMIC) != 0u;
+    }
+    (void)windows;
+    block_sync<kWave>();
+    int my_sense = 0, my_anti = 0;
+#pragma unroll 1
+    for (int t = 0; t < (int)n_here; ++t) {
+        uint2 wn[BSIG_MAX_CLASSES];
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c)
+            wn[c] = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][2 * c]),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][2 * c + 1]));
+        const int glo = __builtin_amdgcn_readfirstlane((int)stage[t][8]);
+        const int gn = __builtin_amdgcn_readfirstlane((int)stage[t][9]);
+        const bool neg_range = ((uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][10]) & BSIG_ITEM_NEG) != 0u;
+        int c_sense = 0, c_anti = 0;
+        auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
+            if (!valid || read_rejected(P, fm, tl)) return;
+            const bool neg = (fm & 0x10u) != 0u;
+            const int a = tl < 0 ? -tl : tl;
+            const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
+            const int p5 = neg ? e - offset : p + offset;
+            if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
+            if (neg != neg_range) ++c_anti; else ++c_sense;
+        };
+        for_each_read<kWave, PRE>(R, P, wn, lane, one);
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            c_sense += __shfl_xor(c_sense, d);
+            c_anti += __shfl_xor(c_anti, d);
+        }
+        if (lane == t) { my_sense = c_sense; my_anti = c_anti; }
+    }
+    if (have) {
+        int32_t *o = out + out_off;
+        if (P.ss) {
+            if (atomic) { if (my_sense) atomicAdd(o, my_sense); if (my_anti) atomicAdd(o + 1, my_anti); }
+            else        { o[0] = my_sense; o[1] = my_anti; }
+        } else {
+            if (atomic) { if (my_sense + my_anti) atomicAdd(o, my_sense + my_anti); }
+            else        { o[0] = my_sense + my_anti; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // bamCoverage: +1/-1 difference array in LDS, workgroup prefix scan, coalesced store
 // ------------------------------------------------------------------------------------------
@@ -796,6 +872,35 @@ __global__ void k_build_idx(int64_t n, const uint32_t *__restrict__ gb, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------
+// integrity of a resident layout that came from a reads file (bsig_reads_load)
+// ------------------------------------------------------------------------------------------
+// Order-independent 64-bit checksum of a run of 32-bit words: sum of mix(word, position).  Computed on the
+// device where the data lies anyway (save: before the download; load: after the upload), so a reads file
+// that rotted on disk is caught at HBM speed instead of a host CRC pass over 12 B per read.
+__global__ __launch_bounds__(256) void k_checksum(const uint32_t *__restrict__ w, uint64_t n, uint64_t salt,
+                                                  unsigned long long *__restrict__ acc)
+{
+    unsigned long long h = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long x = ((unsigned long long)w[i] << 32 | (uint32_t)(i * 0x9E3779B1ull)) ^ (i + salt) * 0xD6E8FEB86659FD93ull;
+        x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 29;
+        h += x;
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) h += __shfl_xor(h, d);
+    if ((threadIdx.x & (kWave - 1)) == 0 && h) atomicAdd(acc, h);
+}
+
+// a bucket index the pileup kernels may follow blindly: non-decreasing, ending at the class's read count
+__global__ void k_check_idx(const uint32_t *__restrict__ idx, uint64_t n_buckets, uint32_t n_reads, int *__restrict__ bad)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    const uint32_t v = idx[b];
+    if (v > n_reads || (b < n_buckets && v > idx[b + 1]) || (b == n_buckets && v != n_reads)) *bad = 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // read visits of a plan, for the roofline's algorithmic bytes:
 //   acc[c], c = 0..3 = reads of span class c whose pos lies in the exact candidate window of
 //                      their tile (SURVEY 8d's V, per class because class 0 reads are 4 B shorter)
@@ -848,6 +953,9 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
                               uint2 *windows, bool resolve_first, int32_t *out, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
+    // count family: consecutive tiles per wave (BAMSIGNALS_COUNT_TILES=1|2|4|8, tuning)
+    static const int count_tiles = [] { const char *e = getenv("BAMSIGNALS_COUNT_TILES"); return e ? atoi(e) : 4; }();
+    static const int count_pre = [] { const char *e = getenv("BAMSIGNALS_COUNT_PRE"); return e ? atoi(e) : 3; }();
     if (windows && resolve_first)
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
                            R, P, mode, items, n_items, windows);
@@ -864,6 +972,16 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
     } else if (mode == BSIG_MODE_COVERAGE) {
         const size_t lds = (size_t)((tile_cells + 8 + 7) / 8) * 16 + (size_t)(NT / 64) * sizeof(int32_t);   // signed 16-bit cells
         hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
+    } else if (NT == kWave && !windows && count_tiles > 1) {
+        // several consecutive tiles per wave (the slices of heavy tiles, which come with fixed windows, and
+        // the wider workgroups keep the one-tile kernel)
+        const int T = count_tiles >= 8 ? 8 : count_tiles >= 4 ? 4 : 2;
+        const dim3 g2((unsigned)((n_items + T - 1) / T));
+#define BSIG_CM(T_, PRE_) hipLaunchKernelGGL((k_count_multi<T_, PRE_>), g2, dim3(kWave), 0, st, items, (uint32_t)n_items, out, windows, R, P)
+        if (count_pre <= 2)      { if (T == 8) BSIG_CM(8, 2); else if (T == 4) BSIG_CM(4, 2); else BSIG_CM(2, 2); }
+        else if (count_pre == 3) { if (T == 8) BSIG_CM(8, 3); else if (T == 4) BSIG_CM(4, 3); else BSIG_CM(2, 3); }
+        else                     { if (T == 8) BSIG_CM(8, 4); else if (T == 4) BSIG_CM(4, 4); else BSIG_CM(2, 4); }
+#undef BSIG_CM
     } else {
         hipLaunchKernelGGL((k_count<NT>), grid, block, 0, st, items, (uint32_t)n_items, out, windows, R, P);
     }
@@ -941,6 +1059,20 @@ hipError_t launch_build_idx(int64_t n, const uint32_t *gb, uint64_t n_buckets, u
     const uint64_t total = n_buckets + 1;
     hipLaunchKernelGGL(k_build_idx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        n, gb, n_buckets, idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_checksum(const void *words, uint64_t n_words, uint64_t salt, unsigned long long *acc, hipStream_t st)
+{
+    if (n_words == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_words + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_checksum, dim3(blocks), dim3(256), 0, st, (const uint32_t *)words, n_words, salt, acc);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_idx(const uint32_t *idx, uint64_t n_buckets, uint32_t n_reads, int *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_idx, dim3((unsigned)((n_buckets + 1 + 255) / 256)), dim3(256), 0, st, idx, n_buckets, n_reads, bad);
     return hipGetLastError();
 }
 

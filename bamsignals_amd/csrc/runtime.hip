@@ -67,6 +67,10 @@ struct bsig_plan {
     BsigWorkItem *heavy_items = nullptr;
     void *heavy_windows = nullptr;
     int64_t n_heavy_slices = 0, n_heavy_tiles = 0;
+    // count family only: some cells are reached by global atomic adds (sub-intervals of a range wider than
+    // one workgroup's share, wide bins) or by no work item at all (zero-width ranges), so the result must
+    // be zeroed in front of the launch.  Ranges of one tile store their counters themselves.
+    bool needs_zero = false;
     bool have_stats = false;
     bsig_plan_stats stats{};
 };
@@ -548,9 +552,41 @@ struct SidecarHeader {
     uint32_t stamp_len, n_classes;
     uint64_t file_bytes;
     SidecarClass cls[BSIG_MAX_CLASSES];
+    uint64_t checksum;              // of every column and index as it lay in HBM when the file was written
 };
-constexpr uint32_t kSidecarVersion = 1;
+constexpr uint32_t kSidecarVersion = 2;
 inline uint64_t pad64(uint64_t v) { return (v + 63) & ~(uint64_t)63; }
+}  // namespace
+
+namespace {
+// checksum of the class columns and indexes of a resident layout, computed where they lie (kernels.hip)
+int layout_checksum(const bsig_reads *R, uint64_t *out)
+{
+    hipStream_t st = R->ctx->stream;
+    HIP_TRY(hipSetDevice(R->ctx->device));
+    unsigned long long *d_acc = nullptr, acc = 0;
+    HIP_TRY(hipMalloc((void **)&d_acc, sizeof acc));
+    hipError_t e = hipMemsetAsync(d_acc, 0, sizeof acc, st);
+    uint64_t salt = 1;
+    for (int c = 0; c < BSIG_MAX_CLASSES && e == hipSuccess; ++c) {
+        const BsigClassCols &C = R->dev.cls[c];
+        if (!C.n) continue;
+        const uint64_t cap = R->col_cap[c];
+        for (const void *col : {(const void *)C.pos, (const void *)C.end, (const void *)C.fm, (const void *)C.tlen}) {
+            if (col && e == hipSuccess) e = bsig::launch_checksum(col, cap, salt, d_acc, st);
+            salt += 0x100000001ull;
+        }
+        // (the index's spare last entry is never written: not part of the sum)
+        if (e == hipSuccess) e = bsig::launch_checksum(C.idx, R->idx_entries[c] - 1, salt, d_acc, st);
+        salt += 0x100000001ull;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_acc);
+    if (e != hipSuccess) return fail(BSIG_ERR_DEVICE, "layout checksum failed: %s", hipGetErrorString(e));
+    *out = (uint64_t)acc;
+    return BSIG_OK;
+}
 }  // namespace
 
 int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp)
@@ -573,6 +609,10 @@ int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp
         bytes += (c ? 4 : 3) * pad64(H.cls[c].col_cap * 4) + pad64(H.cls[c].idx_entries * 4);
     }
     H.file_bytes = bytes;
+    {
+        const int crc_rc = layout_checksum(reads, &H.checksum);
+        if (crc_rc) return crc_rc;
+    }
     const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
     FILE *fp = fopen(tmp.c_str(), "wb");
     if (!fp) return fail(BSIG_ERR_IO, "cannot write %s", tmp.c_str());
@@ -688,15 +728,40 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
     R->ref_units.assign((const uint32_t *)p_un, (const uint32_t *)p_un + H.n_ref);
     R->info = bsig_reads_info{};
     R->info.n_reads = H.n_reads;
+    // The file's numbers steer device-side indexing (bucket numbers, read windows), so nothing is taken on
+    // trust: the unit tables must be the ones layout_from_device derives from the reference lengths, every
+    // class's shapes must follow from its read count and bucket shift, the counts must add up -- and below
+    // the indexes are checked on the device and the checksum of what reached HBM must match the header's.
+    uint64_t total_units = 0;
+    for (uint32_t r = 0; r < H.n_ref; ++r) {
+        if (R->ref_len[r] < 0) return fail(BSIG_ERR_FORMAT, "%s is damaged (reference lengths)", path);
+        const uint64_t u = ((uint64_t)R->ref_len[r] >> BSIG_REF_UNIT_SHIFT) + 1;
+        if (R->ref_unit0[r] != total_units || R->ref_units[r] != u || total_units + u >= (1ull << 31))
+            return fail(BSIG_ERR_FORMAT, "%s is damaged (reference units)", path);
+        total_units += u;
+    }
+    const uint64_t total_bp = total_units << BSIG_REF_UNIT_SHIFT;
+    {
+        int64_t sum = 0;
+        uint32_t live = 0;
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+            if (H.cls[c].n < 0 || H.cls[c].n > H.n_reads) return fail(BSIG_ERR_FORMAT, "%s is damaged (class counts)", path);
+            sum += H.cls[c].n;
+            live += H.cls[c].n > 0;
+        }
+        if (H.n_reads < 0 || sum != H.n_reads || live != H.n_classes || (H.n_reads > 0 && H.n_ref == 0))
+            return fail(BSIG_ERR_FORMAT, "%s is damaged (class counts)", path);
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         BsigClassCols &C = R->dev.cls[c];
         C = BsigClassCols{};
         const SidecarClass &K = H.cls[c];
         if (K.n <= 0) continue;
-        if (K.col_cap < (uint64_t)K.n || K.col_cap > (1ull << 33) || K.idx_entries < 2 || K.idx_entries > (1ull << 33) ||
-            K.kshift < 0 || K.kshift > 62)
-            return fail(BSIG_ERR_FORMAT, "%s is damaged", path);
+        if ((uint64_t)K.n >= (1ull << 32) - 8 || K.col_cap != ((uint64_t)K.n + 3) / 4 * 4 + 4 || K.kshift < 4 ||
+            K.kshift > BSIG_REF_UNIT_SHIFT || (total_bp >> K.kshift) >= (1ull << 32) || K.idx_entries != (total_bp >> K.kshift) + 2 ||
+            K.maxspan < 1)
+            return fail(BSIG_ERR_FORMAT, "%s is damaged (shape of span class %d)", path, c);
         auto load = [&](uint64_t count, const void **dst) -> int {
             const uint8_t *src = take(count * 4);
             if (!src) return fail(BSIG_ERR_FORMAT, "%s is truncated", path);
@@ -720,6 +785,25 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
         R->info.n_classes += 1;
     }
     R->info.hbm_bytes = R->pool.bytes;
+    // what arrived in HBM: indexes the kernels can follow blindly, and the bytes the writer had
+    {
+        int *d_bad = nullptr, bad = 0;
+        HIP_TRY(hipMalloc((void **)&d_bad, sizeof(int)));
+        hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream);
+        for (int c = 0; c < BSIG_MAX_CLASSES && e == hipSuccess; ++c) {
+            const BsigClassCols &C = R->dev.cls[c];
+            if (C.n) e = bsig::launch_check_idx(C.idx, R->idx_entries[c] - 2, (uint32_t)C.n, d_bad, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_bad);
+        if (e != hipSuccess) return fail(BSIG_ERR_DEVICE, "checking %s failed: %s", path, hipGetErrorString(e));
+        if (bad) return fail(BSIG_ERR_FORMAT, "%s is damaged (bucket index)", path);
+        uint64_t sum = 0;
+        const int rc = layout_checksum(R.get(), &sum);
+        if (rc) return rc;
+        if (sum != H.checksum) return fail(BSIG_ERR_FORMAT, "%s is damaged (checksum)", path);
+    }
     *out = R.release();
     return BSIG_OK;
 }
@@ -808,37 +892,8 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
 
     // tiles in genomic order (ref: std::sort by (rid, loc), src/bamsignals.cpp:222-226,246):
     // neighbouring workgroups then stream neighbouring reads
-    std::vector<int64_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    {
-        bool sorted = true;
-        for (int64_t i = 1; i < n && sorted; ++i)
-            sorted = rid[i - 1] < rid[i] || (rid[i - 1] == rid[i] && loc[i - 1] <= loc[i]);
-        if (!sorted) {
-            // sort (key, index) pairs: one contiguous array instead of a comparator chasing three
-            std::vector<std::pair<uint64_t, int64_t>> keyed(n);
-            for (int64_t i = 0; i < n; ++i)
-                keyed[i] = {(uint64_t)(uint32_t)rid[i] << 32 | (uint32_t)(loc[i] ^ INT32_MIN), i};
-            if (n < 4096) {
-                std::sort(keyed.begin(), keyed.end());    // index as tie-break = stable
-            } else {
-                // LSD radix sort, 16 bits per pass; passes whose digit is constant are skipped
-                std::vector<std::pair<uint64_t, int64_t>> tmp2(n);
-                std::vector<uint32_t> hist(65536);
-                for (int pass = 0; pass < 4; ++pass) {
-                    const int sh = 16 * pass;
-                    std::fill(hist.begin(), hist.end(), 0u);
-                    for (int64_t i = 0; i < n; ++i) ++hist[(keyed[i].first >> sh) & 0xFFFF];
-                    if (hist[(keyed[0].first >> sh) & 0xFFFF] == (uint32_t)n) continue;
-                    uint32_t acc = 0;
-                    for (uint32_t &h : hist) { const uint32_t c = h; h = acc; acc += c; }
-                    for (int64_t i = 0; i < n; ++i) tmp2[hist[(keyed[i].first >> sh) & 0xFFFF]++] = keyed[i];
-                    keyed.swap(tmp2);
-                }
-            }
-            for (int64_t i = 0; i < n; ++i) order[i] = keyed[i].second;
-        }
-    }
+    std::vector<int64_t> order;
+    bsig::sort_ranges(n, rid, loc, order);
     std::vector<BsigWorkItem> items;
     items.reserve(n);
     const int64_t mult = K.ss ? 2 : 1;
@@ -849,7 +904,10 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     P->kernel_mode = wide_bins ? BSIG_MODE_COUNT : mode;
     for (int64_t k = 0; k < n; ++k) {
         const int64_t i = order[k];
-        if (len[i] <= 0) continue;
+        if (len[i] <= 0) {
+            if (P->off[i + 1] > P->off[i]) P->needs_zero = true;      // bamCount of a zero-width range: 0
+            continue;
+        }
         BsigWorkItem w{};
         w.loc = loc[i]; w.len = len[i];
         w.ref_unit0 = reads->ref_unit0[rid[i]];
@@ -865,6 +923,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
                     w.nc = (int32_t)std::min<int64_t>(count_split, g1 - a);
                     w.out_off = P->off[i] + c * mult;
                     w.units_strand |= BSIG_ITEM_ATOMIC;
+                    P->needs_zero = true;
                     items.push_back(w);
                 }
             }
@@ -874,7 +933,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
                 w.c0 = (int32_t)a;
                 w.nc = (int32_t)std::min<int64_t>(count_split, len[i] - a);
                 w.out_off = P->off[i];
-                if (split) w.units_strand |= BSIG_ITEM_ATOMIC;
+                if (split) { w.units_strand |= BSIG_ITEM_ATOMIC; P->needs_zero = true; }
                 items.push_back(w);
             }
         } else {
@@ -977,7 +1036,8 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (((uintptr_t)out_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device output buffer must be 16-byte aligned");
     HIP_TRY(hipSetDevice(p->ctx->device));      // the caller's thread may have another GPU current
     hipStream_t st = p->ctx->stream;
-    if (p->kernel_mode == BSIG_MODE_COUNT)
+    // (heavy tiles need no fill: their main item stores 0 and only the slices add)
+    if (p->kernel_mode == BSIG_MODE_COUNT && p->needs_zero)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
     HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
                                 p->tile_cells, nullptr, false, out_dev, st));

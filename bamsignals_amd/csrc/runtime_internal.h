@@ -65,6 +65,7 @@ struct bsig_reads {
 };
 
 namespace bsig {
+struct BaiIndex;
 // Builds the resident HBM layout of R (span classes + bucket indexes, bsig_types.h) from device
 // columns of n reads in BAM order; ref_off is a host array of n_ref + 1 entries.  The input
 // columns are only read.
@@ -79,6 +80,11 @@ constexpr int kNeedsCpuPath = 1;
 // column shares are all-gathered over xGMI (devdecode.hip).  BSIG_OK, kNeedsCpuPath or an error.
 int reads_from_bam_sharded(const std::vector<bsig_ctx *> &ctxs, const std::string &path, int threads,
                            std::vector<bsig_reads *> &out, const char **transport);
+// Index-driven decode with several GPUs: the merged BAI islands of the regions [beg, end) are dealt to the
+// GPUs in contiguous runs, the column shares all-gathered (devdecode.hip).  BSIG_OK, kNeedsCpuPath or an error.
+int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::string &path, const BaiIndex &idx, int64_t n_regions,
+                               const int32_t *rid, const int64_t *beg, const int64_t *end, int threads,
+                               std::vector<bsig_reads *> &out, const char **transport);
 // a device buffer to (pageable or page-locked) host memory, staged through page-locked halves where
 // that is faster (runtime.hip)
 int download_to_host(bsig_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes);

@@ -297,6 +297,36 @@ class Plan:
         self.close()
 
 
+class SegmentMap:
+    """Device-side reassembly of sharded results: segment k of a source buffer goes to the destination at
+    ``dst_off[which[k]]`` (bsig_segmap_*; the host-side twin is bsig_scatter_segments).  The tables are
+    uploaded once; ``run`` is one asynchronous kernel launch on the context's stream."""
+
+    def __init__(self, ctx, src_off, dst_off, which):
+        self._lib = _lib.load()
+        self.ctx = ctx
+        src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.int64)
+        which = np.ascontiguousarray(which, dtype=np.int64)
+        if len(src_off) != len(which) + 1:
+            raise ValueError("src_off must have one more entry than which")
+        h = C.c_void_p()
+        _lib.check(self._lib.bsig_segmap_create(ctx._h, len(which), _ptr(src_off), len(dst_off) - 1, _ptr(dst_off), _ptr(which),
+                                                C.byref(h)))
+        self._h = h
+
+    def run(self, src_ptr, dst_ptr):
+        _lib.check(self._lib.bsig_segmap_run(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bsig_segmap_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 def layout(length, binsize, ss):
     """Flat offsets of the result (allocateList's shapes, ref: src/bamsignals.cpp:139-192)."""
     lib = _lib.load()

@@ -2,14 +2,14 @@
 same argument names, defaults, normalisation, warnings, errors and return shapes, over the C ABI.
 
 R is not available in the build image, so this Python module is the host side that can be run
-and tested here; the R files with the identical logic are in bamsignals_amd/r_package/.
+and tested here.  Under R nothing of this is needed: the reference's own ``R/`` files stay as they
+are and only ``src/`` is swapped (bamsignals_amd/r_package/graft_into_reference.sh, INTEGRATION.md).
 ``paired.end`` is spelled ``paired_end``.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
-import random
 import sys
 import warnings
 
@@ -55,18 +55,10 @@ def tlenFilter(tlenFilter, paired_end):  # noqa: N802,N803 - reference names
     return (int(tf[0]), int(tf[1]))
 
 
-_SENTENCES = (
-    "tHaT'S tHa fAStEsT pIlE-uP bAm iN tHe SoUth!!!",
-    "yOu cAn'T pIlE-Up FaStEr!!!",
-    "I'M gOnNa cHaSe'em and PiLe'em aLl up!!!",
-    "fOr brOoMmHiLdA!!!",
-    "tHe lEgEnD said, hE cOuLd PiLe uP fAsTeR thAn LiGht",
-    "I gEt gOoSeBuMPs wHen I seE yOu pilEuPpiNg...",
-)
-
-
 def _print_sentence(path):
-    print(f"Processing {path}: {random.choice(_SENTENCES)}", file=sys.stderr)
+    """The reference prints a progress line per call when ``verbose`` (R/wrappers.R:175-184); only its
+    presence matters, so the text here is a plain one."""
+    print(f"Processing {path}", file=sys.stderr)
 
 
 # GPU the file-level calls run on when the caller passes no ``device``: -1 = the library's own choice

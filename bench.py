@@ -15,9 +15,20 @@ At N = 1 the same run also reports
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): ranges are independent units,
 so they are sharded round-robin over the ranks with NO data-path collective; every rank holds
-the reads (weak scaling: each rank gets `--ranges` ranges).  After the timed region the per-rank
-results are gathered to rank 0 over RCCL once (the north star's final reassembly step); its time
-is reported separately in "gather" and is not part of `value`.
+the reads (weak scaling: each rank gets `--ranges` ranges) -- that is `value`.  The reads are
+generated ONCE per node (local rank 0 -> .npy files in /dev/shm, the other ranks map them), so the
+N-rank run costs one generation and one copy of the columns in host memory, not N.
+
+Because a weak-scaling number without a collective is linear by construction, a run with N > 1 also
+carries (informational, never `value`):
+  * "strong": BASELINE config 5 at FIXED total size -- 1M x 1 kb ranges over 1e9 reads on 24
+    references, 1M/N sorted ranges per rank -- with the whole north-star step in the timed region:
+    kernel on the rank's shard + RCCL gather of the shards to rank 0 + reassembly into the caller's
+    range order in rank 0's HBM (bsig_segmap_run); next to the same 1M ranges run by rank 0's GPU
+    alone, and checked cell by cell against that result and on a sample against the oracle;
+  * "in_process": the route an R session uses -- ONE process driving all N GPUs through the
+    file-level call (BAMSIGNALS_DEVICES=0..N-1) on the same data written as a BAM: cold call
+    (sharded decode + column all-gather) and warm calls under each gather route.
 
 Prints ONE JSON line on rank 0.
 """
@@ -210,11 +221,78 @@ def end_to_end_realistic(seed, device, oracle_c):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def host_ram_available():
+    try:
+        import psutil
+        return int(psutil.virtual_memory().available)
+    except Exception:
+        return None
+
+
+class SharedReads:
+    """The synthetic read columns of one configuration, generated once per node: local rank 0 runs the
+    generator and writes the columns as .npy files (to /dev/shm when it has room, else TMPDIR), the other
+    ranks map them read-only after a barrier.  N ranks then cost one generation (26 s for 5e8 reads, 49 s for
+    1e9) and ONE copy of the columns in host memory (15 B per read) instead of N of each."""
+
+    KEYS = ("ref_len", "ref_off", "pos", "flag", "mapq", "tlen", "end")
+
+    def __init__(self, tag, n_reads, ref_len, seed, paired, rank, world, barrier):
+        import shutil
+
+        from bamsignals_amd.synth import synth_reads
+        self.dir = None
+        self.leader = rank == 0
+        t0 = time.time()
+        need_gen = int(n_reads) * 48            # generator temporaries (int64 positions, sort buffers) + columns
+        need_shm = int(n_reads) * 16
+        if world == 1:
+            self.cols = synth_reads(n_reads, ref_len, seed=seed, paired=paired, with_cigar=False)
+            self.t_gen = time.time() - t0
+            return
+        root = None
+        for cand in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):
+            try:
+                if shutil.disk_usage(cand).free > need_shm * 1.2:
+                    root = cand
+                    break
+            except OSError:
+                pass
+        self.dir = os.path.join(root or "/tmp", f"bsig_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}")
+        if self.leader:
+            avail = host_ram_available()
+            if root is None or (avail is not None and avail < need_gen + (need_shm if root == "/dev/shm" else 0)):
+                raise SystemExit(f"bench.py: not enough host memory / scratch space for {n_reads} synthetic reads "
+                                 f"(available RAM {avail}, need about {need_gen + need_shm} bytes)")
+            shutil.rmtree(self.dir, ignore_errors=True)
+            os.makedirs(self.dir)
+            self.cols = synth_reads(n_reads, ref_len, seed=seed, paired=paired, with_cigar=False)
+            for k in self.KEYS:
+                np.save(os.path.join(self.dir, k + ".npy"), self.cols[k])
+            log(f"{tag}: generated {n_reads} reads once for {world} ranks in {time.time() - t0:.1f} s -> {self.dir}")
+        barrier()
+        if not self.leader:
+            self.cols = {k: np.load(os.path.join(self.dir, k + ".npy"), mmap_mode="r") for k in self.KEYS}
+        self.t_gen = time.time() - t0
+
+    def release(self, barrier):
+        """After every rank has uploaded: the files go (the leader keeps its in-memory columns)."""
+        import shutil
+        if self.dir is None:
+            return
+        if not self.leader:
+            self.cols = None
+        barrier()
+        if self.leader:
+            shutil.rmtree(self.dir, ignore_errors=True)
+        self.dir = None
+
+
 class Workload:
     """One configuration resident on the GPU: reads, `nb` distinct range batches, their plans and
     result buffers."""
 
-    def __init__(self, a, name, rank, world, local, stream, n_reads=0, n_ranges=0, width=0, nb=0):
+    def __init__(self, a, name, rank, world, local, stream, n_reads=0, n_ranges=0, width=0, nb=0, cols=None, t_gen=0.0):
         import torch
 
         from bamsignals_amd import _lib
@@ -230,7 +308,7 @@ class Workload:
         # config 2; a batch of the larger configurations (>= 1 GB per step) exceeds it by itself
         nb = nb or (8 if self.n_reads <= 100_000_000 else 2)
         t0 = time.time()
-        self.cols = synth_reads(self.n_reads, cfg["ref_len"], seed=a.seed, paired=cfg["paired"], with_cigar=False)
+        self.cols = cols if cols is not None else synth_reads(self.n_reads, cfg["ref_len"], seed=a.seed, paired=cfg["paired"], with_cigar=False)
         self.batches = []
         for b in range(nb):
             all_rg = synth_ranges(self.n_ranges * world, self.width, cfg["ref_len"], seed=a.seed + 1 + 7919 * b)
@@ -238,8 +316,9 @@ class Workload:
             mine = order[rank::world]                                 # round-robin shard of sorted ranges
             self.batches.append({k: v[mine] for k, v in all_rg.items()})
         self.nb = nb
-        self.t_gen = time.time() - t0
-        log(f"{name}: generated {self.n_reads} reads, {nb} x {len(self.batches[0]['rid'])} ranges in {self.t_gen:.1f} s")
+        self.t_gen = time.time() - t0 + t_gen
+        if rank == 0:
+            log(f"{name}: {self.n_reads} reads, {nb} x {len(self.batches[0]['rid'])} ranges ready in {self.t_gen:.1f} s")
         cols = self.cols
         with torch.cuda.stream(stream):
             self.ctx = Context(local, stream=stream.cuda_stream)
@@ -350,6 +429,184 @@ def committed_traffic(a, name, cfg):
     return None, None
 
 
+def strong_block(a, rank, world, stream, ctx, reads, cols, use_dist, dist, cdev, barrier, backend, n_ranges_total, steps):
+    """BASELINE config 5 at FIXED total size over `world` GPUs, the whole north-star step timed:
+       kernel on this rank's shard of the (rid, loc)-sorted ranges (ref: src/bamsignals.cpp:222-226,246)
+       -> gather of the shards to rank 0 (RCCL over xGMI: grouped send/recv, the peers send straight to the root)
+       -> reassembly into the caller's range order in rank 0's HBM (bsig_segmap_run; each range owns its
+          output, ref: :164,181,186).
+    Next to it the same ranges run by rank 0's GPU alone (the 1-GPU time the speed-up is quoted against);
+    the assembled result must equal that result cell by cell, and a sample is checked against the oracle."""
+    import torch
+
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, SegmentMap, layout, make_params
+    from bamsignals_amd.synth import synth_ranges
+    cfg = CONFIGS["C5"]
+    width = cfg["width"]
+    prm = make_params(_lib.MODE_PROFILE, **cfg["args"])
+    rg = synth_ranges(n_ranges_total, width, cfg["ref_len"], seed=a.seed + 555)        # the caller's (unsorted) order
+    order = np.lexsort((rg["loc"], rg["rid"]))
+    shards = [order[r::world] for r in range(world)]
+    off_all = layout(rg["len"], 1, False)
+    loffs = [layout(rg["len"][sh], 1, False) for sh in shards]
+    sizes = [int(o[-1]) for o in loffs]
+    pad = max(max(sizes), 4)
+    mine = shards[rank]
+    out = {}
+    with torch.cuda.stream(stream):
+        plan = Plan(ctx, reads, rg["rid"][mine], rg["loc"][mine], rg["len"][mine], rg["strand"][mine], prm)
+        assert plan.cells == sizes[rank]
+        shard = torch.zeros(pad, dtype=torch.int32, device="cuda")
+        bufs = maps = final = None
+        if rank == 0:
+            bufs = [torch.empty(pad, dtype=torch.int32, device=cdev) for _ in range(world)]
+            final = torch.zeros(max(int(off_all[-1]), 4), dtype=torch.int32, device="cuda")
+            maps = [SegmentMap(ctx, loffs[r], off_all, shards[r]) for r in range(world)]
+        dev_bufs = bufs
+
+        def step():
+            nonlocal dev_bufs
+            plan.run_device(shard.data_ptr())
+            if use_dist:
+                if backend == "nccl":
+                    dist.gather(shard, bufs, dst=0)
+                else:                           # gloo (testing the code path on a box with fewer GPUs): via host memory
+                    torch.cuda.synchronize()
+                    dist.gather(shard.cpu(), bufs, dst=0)
+                    if rank == 0:
+                        dev_bufs = [b.cuda() for b in bufs]
+            else:
+                dev_bufs = [shard]
+            if rank == 0:
+                for r in range(world):
+                    maps[r].run(dev_bufs[r].data_ptr(), final.data_ptr())
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)] if rank == 0 and backend == "nccl" else None
+        t0 = time.perf_counter()
+        for q in range(steps):
+            if ev:
+                ev[q][0].record(stream)
+                plan.run_device(shard.data_ptr())
+                ev[q][1].record(stream)
+                if use_dist:
+                    dist.gather(shard, bufs, dst=0)
+                else:
+                    dev_bufs = [shard]
+                ev[q][2].record(stream)
+                for r in range(world):
+                    maps[r].run(dev_bufs[r].data_ptr(), final.data_ptr())
+                ev[q][3].record(stream)
+            else:
+                step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier(); torch.cuda.synchronize()
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        bases = int(rg["len"].astype(np.int64).sum())
+        if rank == 0:
+            out = dict(workload=f"C5 strong: bamProfile binsize=1, {n_ranges_total} x {width} bp ranges in total over {world} GPU(s), "
+                                f"{reads.n_reads} SE reads, {len(cfg['ref_len'])} refs",
+                       n_gpus=world, ranges_total=n_ranges_total, ranges_per_gpu=len(mine), reads=int(reads.n_reads), steps=steps,
+                       timed_region="kernel on the rank's shard + gather of the shards to rank 0 + reassembly in rank 0's HBM",
+                       backend=backend, ms_per_step=elapsed / steps * 1e3, value=bases * steps / elapsed / 1e6, unit="Mbases/s",
+                       gather_bytes=int(sum(sizes[1:]) * 4))
+            if ev:
+                ph = np.asarray([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in ev]).mean(axis=0)
+                out["phases_ms_rank0"] = dict(kernel=float(ph[0]), gather=float(ph[1]), place=float(ph[2]))
+                if ph[1] > 0:
+                    out["gather_GBps"] = out["gather_bytes"] / (ph[1] * 1e-3) / 1e9
+            # the same ranges on rank 0's GPU alone
+            plan1 = Plan(ctx, reads, rg["rid"], rg["loc"], rg["len"], rg["strand"], prm)
+            ref = torch.zeros(max(plan1.cells, 4), dtype=torch.int32, device="cuda")
+            for _ in range(2):
+                plan1.run_device(ref.data_ptr())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(steps):
+                plan1.run_device(ref.data_ptr())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            one = e0.elapsed_time(e1) / steps
+            st1 = plan1.stats()
+            out["one_gpu_ms"] = one
+            out["one_gpu_frac_of_hbm_peak"] = st1["algorithmic_bytes"] / (one * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            out["speedup_vs_1gpu"] = one / out["ms_per_step"]
+            out["efficiency_vs_1gpu"] = one / out["ms_per_step"] / world
+            if not torch.equal(final[:plan1.cells], ref[:plan1.cells]):
+                raise SystemExit("strong block: the result assembled from the ranks' shards differs from the 1-GPU result")
+            out["checked"] = f"assembled result identical to the 1-GPU result ({plan1.cells} cells)"
+            out["_final_host"] = ref[:plan1.cells].cpu().numpy()
+            plan1.close()
+            for m in maps:
+                m.close()
+        plan.close()
+    out_rg = rg if rank == 0 else None
+    return out, out_rg
+
+
+def in_process_block(a, world, ngpu, cols, cfg, rg, want_flat):
+    """ONE process, N GPU slots, the file-level call (what an R session with BAMSIGNALS_DEVICES=0..N-1 does):
+    the strong block's reads written to local disk as a BAM, cold call (every GPU inflates and parses its
+    share, column all-gather over xGMI, one layout per GPU) and warm calls under each gather route."""
+    import shutil
+    import tempfile
+
+    from bamsignals_amd import GRanges, _lib
+    from bamsignals_amd.bamio import write_columns_as_bam
+    from bamsignals_amd.synth import add_cigar
+    from bamsignals_amd.wrappers import last_call_route, last_call_timing, pileup_core
+    d = tempfile.mkdtemp(prefix="bsig_bench_inproc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    keep = {k: os.environ.get(k) for k in ("BAMSIGNALS_DEVICES", "BAMSIGNALS_DECODE", "BAMSIGNALS_GATHER")}
+    try:
+        if "cigar" not in cols:
+            add_cigar(cols)
+        names = ["ref%d" % (i + 1) for i in range(len(cfg["ref_len"]))]
+        bam = os.path.join(d, "c5.bam")
+        t0 = time.perf_counter(); write_columns_as_bam(bam, names, cols, level=1); t_write = time.perf_counter() - t0
+        cols.pop("cigar"); cols.pop("cigar_off")
+        gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"],
+                     strand=[{1: "+", -1: "-", 0: "*"}[int(x)] for x in rg["strand"]])
+        devices = ",".join(str(r % ngpu) for r in range(world))
+        os.environ["BAMSIGNALS_DEVICES"] = devices
+        os.environ["BAMSIGNALS_DECODE"] = "all"
+        out = dict(devices=devices, bam_bytes=os.path.getsize(bam), write_bam_s=t_write, ranges=len(rg["rid"]),
+                   note="pileup_core(bampath, GRanges) from ONE process over all listed GPU slots; results in host memory "
+                        "(PCIe-inclusive); every call checked against the strong block's 1-GPU result")
+        bases = int(rg["len"].astype(np.int64).sum())
+        first = True
+        for gather in ("xgmi", "direct", "pcie"):
+            os.environ["BAMSIGNALS_GATHER"] = gather
+            runs = []
+            if first:
+                _lib.load().bsig_cache_clear()
+            for rep in (("cold", "warm", "warm") if first else ("warm", "warm")):
+                t0 = time.perf_counter(); sig = pileup_core(bam, gr, (), device=-1); dt = time.perf_counter() - t0
+                flat = np.concatenate(sig)
+                if not np.array_equal(flat, want_flat):
+                    raise SystemExit(f"in-process call ({gather}, {rep}) differs from the 1-GPU result")
+                del sig, flat
+                runs.append(dict(kind=rep, call_s=dt, Mbases_s=bases / dt / 1e6, stages_s=last_call_timing(), route=last_call_route()))
+            out[gather] = runs
+            first = False
+        _lib.load().bsig_cache_clear()
+        return out
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -381,7 +638,19 @@ def main():
                     help="skip the end-to-end section on a BAM with read names, bases and qualities")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary kernel-only measurement of config 2")
     ap.add_argument("--seed", type=int, default=0xBA51)
+    ap.add_argument("--strong", action="store_true", help="run the strong-scaling block (config 5 at fixed total size) "
+                    "even with one rank; with N > 1 it always runs unless --no-strong")
+    ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--strong-reads", type=int, default=0, help="reads of the strong block's data set (default: config 5's 1e9; "
+                    "with --config C5 the block reuses the main workload's reads)")
+    ap.add_argument("--strong-ranges", type=int, default=1_000_000, help="TOTAL ranges of the strong block")
+    ap.add_argument("--strong-steps", type=int, default=20)
+    ap.add_argument("--no-in-process", action="store_true", help="skip the single-process multi-GPU file-level block (N > 1)")
+    ap.add_argument("--in-process-slots", type=int, default=0, help="run the in-process block with this many GPU slots even "
+                    "with one rank (slots beyond the box's GPUs reuse them: testing)")
+    ap.add_argument("--budget-s", type=float, default=420.0, help="optional blocks are skipped once the run is older than this")
     a = ap.parse_args()
+    t_program = time.time()
 
     import torch
     import torch.distributed as dist
@@ -415,13 +684,33 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    # long host-side waits (one rank generating reads, rank 0 running the in-process block) go through a
+    # gloo group: an RCCL barrier would park a spinning kernel on every waiting GPU
+    host_group = dist.new_group(backend="gloo") if use_dist and a.backend == "nccl" else None
+
     def barrier():
         if use_dist:
             dist.barrier()
 
+    def host_barrier():
+        if use_dist:
+            dist.barrier(group=host_group) if host_group is not None else dist.barrier()
+
+    def all_agree(flag):
+        # rank 0 decides (time budget): every rank takes the same branch
+        if not use_dist:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.broadcast(t, src=0, group=host_group) if host_group is not None else dist.broadcast(t, src=0)
+        return bool(t.item())
+
     cfg = CONFIGS[a.config]
     stream = torch.cuda.Stream()
-    w = Workload(a, a.config, rank, world, local, stream, a.reads, a.ranges, a.width, a.batches)
+    shared = SharedReads(a.config, a.reads or cfg["reads"], cfg["ref_len"], a.seed, cfg["paired"], rank, world, host_barrier)
+    w = Workload(a, a.config, rank, world, local, stream, a.reads, a.ranges, a.width, a.batches, cols=shared.cols, t_gen=shared.t_gen)
+    shared.release(host_barrier)
+    if rank != 0:
+        w.cols = None                    # (only rank 0 checks against the oracle: the mapped columns can go)
     elapsed, kernel_ms = w.timed(a.steps, a.warmup, stream, barrier)
     nb, plan, rg = w.nb, w.plans[0], w.batches[0]
 
@@ -544,12 +833,83 @@ def main():
             "parity_checked": parity,
             "pipelined_two_streams": pipelined,
             "gather": gather,
+            "strong": None,
+            "in_process": None,
             "setup_s": {"generate": w.t_gen, "upload_and_layout": w.t_upload, "plan": w.t_plan},
             "reads_in_hbm": w.reads.info(),
         }
 
+    # ---- N > 1: config 5 at fixed total size with the collective in the timed region; the in-process route ------
+    want_strong = (world > 1 or a.strong) and not a.no_strong
+    want_inproc = (world > 1 and not a.no_in_process) or a.in_process_slots > 0
+    if want_strong or want_inproc:
+        go = all_agree(time.time() - t_program < a.budget_s)
+        if not go:
+            if rank == 0:
+                res["strong"] = res["in_process"] = {"skipped": f"time budget ({a.budget_s:.0f} s) used up before the block"}
+        else:
+            c5 = CONFIGS["C5"]
+            if a.config == "C5":
+                reads5, cols5, ctx5, own5 = w.reads, w.cols, w.ctx, False
+            else:
+                # the main workload leaves HBM and host memory first
+                w.close(); w.cols = None
+                torch.cuda.empty_cache()
+                from bamsignals_amd.device import Context, Reads
+                sh5 = SharedReads("C5", a.strong_reads or c5["reads"], c5["ref_len"], a.seed + 5, False, rank, world, host_barrier)
+                cols5 = sh5.cols
+                with torch.cuda.stream(stream):
+                    ctx5 = Context(local, stream=stream.cuda_stream)
+                    reads5 = Reads(ctx5, cols5["ref_len"], cols5["ref_off"], cols5["pos"], cols5["flag"], cols5["mapq"], cols5["tlen"],
+                                   end=cols5["end"])
+                sh5.release(host_barrier)
+                own5 = True
+            strong = rg5 = None
+            if want_strong or want_inproc:
+                strong, rg5 = strong_block(a, rank, world, stream, ctx5, reads5, cols5, use_dist, dist, cdev, barrier, a.backend,
+                                           a.strong_ranges, a.strong_steps)
+            want5 = strong.pop("_final_host", None) if rank == 0 else None
+            if rank == 0:
+                # a seeded sample of the 1-GPU result against the oracle (all references; the checker imported above)
+                _oc = oracle_c
+                orc5 = _oc.OracleReads(cols5["ref_off"], cols5["pos"], cols5["end"], cols5["flag"], cols5["mapq"], cols5["tlen"])
+                pick = np.sort(np.random.default_rng(a.seed + 9).choice(len(rg5["rid"]), size=min(2000, len(rg5["rid"])), replace=False))
+                sub = {k: v[pick] for k, v in rg5.items()}
+                wv, wo = _oc.pileup_core(orc5, sub, **c5["args"])
+                from bamsignals_amd.device import layout as _layout
+                off5 = _layout(rg5["len"], 1, False)
+                for j, i in enumerate(pick):
+                    if not np.array_equal(want5[off5[i]:off5[i + 1]], wv[wo[j]:wo[j + 1]]):
+                        raise SystemExit(f"strong block: range {i} differs from the oracle")
+                del orc5
+                strong["checked"] += f"; {len(pick)} ranges on {len(np.unique(sub['rid']))} references identical to the oracle"
+                res["strong"] = strong if want_strong else None
+                log(f"strong: {strong['ms_per_step']:.3f} ms per step on {world} GPU(s), 1 GPU {strong['one_gpu_ms']:.3f} ms")
+            # everything this process holds on the GPUs goes before ONE process drives them all
+            if own5:
+                reads5.close(); ctx5.close()
+            elif a.config == "C5":
+                w.close()
+            torch.cuda.empty_cache()
+            host_barrier()
+            if want_inproc and all_agree(time.time() - t_program < a.budget_s + 60):
+                if rank == 0:
+                    try:
+                        slots = a.in_process_slots or world
+                        res["in_process"] = in_process_block(a, slots, ngpu, cols5, c5, rg5, want5)
+                        log("in_process: " + "; ".join(f"{g} " + "/".join(f"{r['call_s']:.3f}" for r in res["in_process"][g])
+                                                        for g in ("xgmi", "direct", "pcie")))
+                    except SystemExit:
+                        raise
+                    except Exception as exc:
+                        res["in_process"] = {"error": f"{type(exc).__name__}: {exc}"}
+                host_barrier()
+            elif want_inproc and rank == 0:
+                res["in_process"] = {"skipped": "time budget used up before the block"}
+            del cols5
+
     # ---- N = 1 extras: the same workload from a BAM file, and config 2's small launch ---------------
-    if rank == 0 and world == 1 and not use_dist:
+    if rank == 0 and world == 1 and not use_dist and not (want_strong or want_inproc):
         cols = w.cols
         want_flat = got[:plan.cells]
         w.close()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BSIG_ABI_VERSION 2
+#define BSIG_ABI_VERSION 3
 
 enum {
     BSIG_OK = 0,
@@ -119,8 +119,11 @@ int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **read
 /* The resident layout as a file (the decoded-column "sidecar" of a BAM): a later process loads it and
  * skips BGZF inflate and record parsing (the reference pays both on every call, ref:
  * src/bamsignals.cpp:449,479 + :271).  `stamp` ties the file to what it was made from (the
- * file-level calls use path + size + mtime of the BAM and of its index); bsig_reads_load fails with
- * BSIG_ERR_FORMAT when the stamp differs or the file is damaged, BSIG_ERR_IO when it is absent.   */
+ * file-level calls use size + mtime of the BAM and of every index file next to it); bsig_reads_load fails
+ * with BSIG_ERR_FORMAT when the stamp differs or the file is damaged, BSIG_ERR_IO when it is absent.
+ * Nothing in the file is trusted: the shapes must follow from the counts, the bucket indexes are
+ * checked on the device (non-decreasing, within the read count) and a checksum of what reached HBM
+ * must equal the one the writer took of its resident layout.                                      */
 int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp);
 int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_reads **reads);
 
@@ -188,11 +191,10 @@ int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges
  * bam_name2id (ref: :26-28, :95), bam_itr_queryi / bam_itr_next (ref: :267-271).
  * ------------------------------------------------------------------------------------------ */
 typedef struct bsig_bam bsig_bam;
-/* opens <path> and loads <path>.bai (or <stem>.bai); errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the
- * reference's messages (ref: src/bamsignals.cpp:204,209).  A file that has only a CSI index
- * (<path>.csi, which htslib's bam_index_load accepts too and references beyond 2^29 bp need) opens
- * as well: its index is not read, whole-file decodes work, region queries return BSIG_ERR_NOINDEX,
- * and the file-level entry points always decode it whole.                                       */
+/* opens <path> and loads <path>.bai, <stem>.bai, <path>.csi or <stem>.csi (the first that exists, as
+ * htslib's bam_index_load does, ref: src/bamsignals.cpp:207; a CSI index may have any min_shift / depth --
+ * references beyond 2^29 bp need one); errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the reference's messages
+ * (ref: src/bamsignals.cpp:204,209).                                                             */
 int bsig_bam_open(const char *path, bsig_bam **bam);
 void bsig_bam_close(bsig_bam *bam);
 const char *bsig_bam_path(const bsig_bam *bam);
@@ -249,9 +251,13 @@ void bsig_device_decode_timing(double *t6);
  * else GPU 0.  With several GPUs every GPU inflates and parses its share of the BGZF blocks and the
  * column shares are all-gathered over xGMI; the (rid, loc)-sorted ranges are dealt round-robin to the
  * GPUs (one host thread and stream each); the result shards are gathered on the first GPU over xGMI
- * (RCCL grouped send/recv; env BAMSIGNALS_EXCHANGE=peer: peer copies), put into range order there and
+ * (RCCL grouped send/recv; env BAMSIGNALS_EXCHANGE=peer: peer copies; env BAMSIGNALS_GATHER=direct: the
+ * first GPU reads its peers' shard buffers in place, one pass), put into range order there and
  * downloaded once (env BAMSIGNALS_GATHER=pcie: every GPU's shard over its own PCIe link instead,
- * reassembled by host threads).  maxgap is accepted for signature parity with the
+ * reassembled by host threads).  Index-driven decodes (queries that need less than a third of the genome)
+ * are shared between the GPUs island by island and the last few are kept (env BAMSIGNALS_REGION_CACHE,
+ * default 8, 0 = none): a repeated call whose ranges lie inside an earlier call's finds its reads
+ * resident.  maxgap is accepted for signature parity with the
  * reference (ref: src/bamsignals.cpp:446,476) and does not influence the result.
  * ------------------------------------------------------------------------------------------ */
 /* replaces bamsignals_pileup_core (ref: src/RcppExports.cpp:33-52 -> src/bamsignals.cpp:444-461) */
@@ -288,10 +294,15 @@ int bsig_write_columns_as_bam_with_seq(const char *bampath, int32_t n_ref, const
  * <bam>.bsig) or BAMSIGNALS_SIDECAR_DIR=<dir> additionally keeps the resident layout on disk
  * (bsig_reads_save) so that another process skips the decode.  File-level calls may be made from
  * several host threads at once (the cache is locked for look-ups only; cold decodes take turns).
- * bsig_cache_clear drops all of it (not the sidecar files); entries a running call uses stay alive
- * until that call returns, but the RCCL communicators are destroyed at once: do not call it while a
- * multi-GPU call is in flight.                                                                   */
+ * Every device list seen (device argument / BAMSIGNALS_DEVICES) keeps its own contexts and resident
+ * BAMs: alternating between two GPUs does not evict anything.  Multi-GPU calls on one device list take
+ * turns at the run stage (they share the slots' cached result buffers and the RCCL communicators).
+ * bsig_cache_clear drops all of it (not the sidecar files); whatever a running call uses -- contexts,
+ * resident reads, communicators -- stays alive until that call returns, so it may be called at any time. */
 void bsig_cache_clear(void);
+/* diagnostic: device / page-locked allocations made so far for the buffers the multi-GPU result path keeps
+ * between calls (a call on a resident BAM with shapes seen before adds none)                        */
+int64_t bsig_debug_scratch_allocs(void);
 /* how the calling thread's last file-level call was carried out, e.g.
  * "8 GPU slot(s); reads: sharded decode, columns over rccl; result: xgmi/rccl"                  */
 const char *bsig_last_call_route(void);
@@ -307,6 +318,17 @@ void bsig_last_call_timing(double *t6);
  * ------------------------------------------------------------------------------------------ */
 int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off, int32_t *dst,
                           const int64_t *dst_off, const int64_t *which);
+
+/* The same on the device, for hosts that gather the shards into ONE device buffer on the root GPU (one
+ * process per GPU: torch.distributed / RCCL gather): the segment tables live in HBM with the map, so a
+ * run is one kernel launch on the context's stream, asynchronous, and the result stays in HBM in the
+ * caller's range order.  The tables are checked like bsig_scatter_segments checks them (every segment fits
+ * its destination, inside n_src_cells / n_dst_cells).  src_off: n+1 entries, dst_off: n_dst+1, which: n. */
+typedef struct bsig_segmap bsig_segmap;
+int bsig_segmap_create(bsig_ctx *ctx, int64_t n, const int64_t *src_off, int64_t n_dst, const int64_t *dst_off,
+                       const int64_t *which, bsig_segmap **map);
+int bsig_segmap_run(bsig_segmap *map, const int32_t *src_dev, int32_t *dst_dev);
+void bsig_segmap_free(bsig_segmap *map);
 
 #ifdef __cplusplus
 }

@@ -401,9 +401,44 @@ def test_real_shaped_synthetic_records(tmp_path):
             n += 1
 
 
-def test_csi_only_bam_opens_for_whole_file_decodes(tmp_path, fixture_reads):
-    """htslib's bam_index_load (ref: src/bamsignals.cpp:207) accepts a CSI index as well; here such a
-    file opens, decodes whole, and refuses region queries with a clear message (its bins are not read)."""
+def _bai_to_csi(bai_bytes, depth=5, bgzf_like=True):
+    """A CSI (CSIv1) index equivalent to a BAI: same bins and chunks (for depth 6 every bin moves one level
+    down under a new root: BAI level l is CSI(14, 6) level l + 1), loffset of a bin = the linear index's
+    entry of the bin's first 16-kbp window (what htslib derives when it loads a BAI)."""
+    assert bai_bytes[:4] == b"BAI\x01" and depth in (5, 6)
+    n_ref, = struct.unpack_from("<i", bai_bytes, 4)
+    o = 8
+    out = [b"CSI\x01", struct.pack("<iii", 14, depth, 0), struct.pack("<i", n_ref)]
+    t5 = [((1 << 3 * l) - 1) // 7 for l in range(7)]
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", bai_bytes, o); o += 4
+        bins = []
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", bai_bytes, o); o += 8
+            chunks = bai_bytes[o:o + 16 * n_chunk]; o += 16 * n_chunk
+            bins.append((b, n_chunk, chunks))
+        n_intv, = struct.unpack_from("<i", bai_bytes, o); o += 4
+        linear = struct.unpack_from("<%dQ" % n_intv, bai_bytes, o); o += 8 * n_intv
+        recs = []
+        for b, n_chunk, chunks in bins:
+            if b == 37450:                      # htslib's metadata pseudo-bin: moves to the new scheme's pseudo-bin
+                nb, loff = ((1 << 3 * (depth + 1)) - 1) // 7 + 1, 0
+            else:
+                lvl = max(l for l in range(6) if t5[l] <= b)
+                first_window = (b - t5[lvl]) << (3 * (5 - lvl))
+                loff = linear[first_window] if first_window < n_intv else (linear[-1] if n_intv else 0)
+                nb = b if depth == 5 else t5[lvl + 1] + (b - t5[lvl])
+            recs.append(struct.pack("<IQi", nb, loff, n_chunk) + chunks)
+        out.append(struct.pack("<i", len(recs)) + b"".join(recs))
+    raw = b"".join(out)
+    return gzip.compress(raw) if bgzf_like else raw
+
+
+@pytest.mark.parametrize("depth", [5, 6])
+def test_csi_index_is_read_and_queried(tmp_path, fixture_reads, depth):
+    """htslib's bam_index_load (ref: src/bamsignals.cpp:207) accepts a CSI index as well; here a BAM that has
+    only a .csi opens, decodes whole, and answers region queries exactly as through its BAI (same bins, same
+    chunks; min_shift 14 with depth 5 and, one level deeper, depth 6)."""
     import shutil
     from bamsignals_amd import _lib
     from bamsignals_amd.bamio import BamFile
@@ -411,12 +446,52 @@ def test_csi_only_bam_opens_for_whole_file_decodes(tmp_path, fixture_reads):
     shutil.copy(BAM, p)
     with pytest.raises(_lib.BsigError, match="BAM indexing file is not available"):
         BamFile(str(p))
-    (tmp_path / "c.bam.csi").write_bytes(open(BAM, "rb").read()[:200])        # any BGZF-compressed file: only the magic is looked at
-    b = BamFile(str(p))
-    _cols_equal(b.decode(threads=2), fixture_reads)
-    with pytest.raises(_lib.BsigError, match="csi index only"):
-        b.decode(rid=[0], beg=[0], end=[100])
-    b.close()
+    # a file of that name that is not a CSI index (BGZF-compressed or not) is no index
+    (tmp_path / "c.bam.csi").write_bytes(open(BAM, "rb").read()[:200])
+    with pytest.raises(_lib.BsigError, match="BAM indexing file is not available"):
+        BamFile(str(p))
     (tmp_path / "c.bam.csi").write_bytes(b"not an index")
     with pytest.raises(_lib.BsigError, match="BAM indexing file is not available"):
         BamFile(str(p))
+    (tmp_path / "c.bam.csi").write_bytes(_bai_to_csi(open(BAM + ".bai", "rb").read(), depth))
+    b = BamFile(str(p))
+    _cols_equal(b.decode(threads=2), fixture_reads)
+    ref = BamFile(BAM)
+    rng = np.random.default_rng(17 + depth)
+    for trial in range(12):
+        n = int(rng.integers(1, 9))
+        rid = rng.integers(0, 3, n).astype(np.int32)
+        beg = rng.integers(0, 9000, n).astype(np.int64)
+        end = beg + rng.integers(1, 3000, n)
+        got, want = b.decode(rid=rid, beg=beg, end=end), ref.decode(rid=rid, beg=beg, end=end)
+        for k in ("pos", "flag", "mapq", "tlen", "ref_off", "cigar_off", "cigar"):
+            assert np.array_equal(got[k], want[k]), (trial, k)
+        assert len(got["pos"]) > 0
+    b.close(); ref.close()
+
+
+def test_csi_index_of_a_multibin_bam(tmp_path):
+    """The same on a BAM whose index spans many windows and every bin level (this repo's writer)."""
+    from bamsignals_amd.bamio import BamFile, write_columns_as_bam
+    cols = _synth(80_000, seed=8)
+    names = ["r%d" % i for i in range(len(cols["ref_len"]))]
+    p = str(tmp_path / "m.bam")
+    write_columns_as_bam(p, names, cols)
+    ref = BamFile(p)
+    q = str(tmp_path / "only_csi.bam")
+    os.link(p, q)
+    rng = np.random.default_rng(3)
+    for depth in (5, 6):
+        open(q + ".csi", "wb").write(_bai_to_csi(open(p + ".bai", "rb").read(), depth))
+        b = BamFile(q)
+        for trial in range(10):
+            n = int(rng.integers(1, 20))
+            rid = rng.integers(0, len(names), n).astype(np.int32)
+            beg = (rng.random(n) * cols["ref_len"][rid]).astype(np.int64)
+            end = beg + rng.integers(1, 40_000, n)
+            got, want = b.decode(rid=rid, beg=beg, end=end), ref.decode(rid=rid, beg=beg, end=end)
+            for k in ("pos", "flag", "mapq", "tlen", "ref_off"):
+                assert np.array_equal(got[k], want[k]), (depth, trial, k)
+        b.close()
+        os.remove(q + ".csi")
+    ref.close()

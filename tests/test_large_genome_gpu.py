@@ -179,10 +179,12 @@ def test_eight_slots_in_one_process(synth_bam, decode, monkeypatch):
     """BAMSIGNALS_DEVICES with 8 slots (the box's one GPU listed eight times: eight contexts, streams,
     resident copies and plans) against the 1-slot result and the oracle."""
     from bamsignals_amd import _lib, bamCount, bamCoverage, bamProfile
+    from bamsignals_amd.wrappers import last_call_route
     from oracle import oracle_c
     bam, cols, rg, gr = synth_bam
     orc = _oracle(cols)
     monkeypatch.setenv("BAMSIGNALS_DECODE", decode)
+    monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
     res = {}
     try:
         for devs in ("0", "0,0,0,0,0,0,0,0"):
@@ -190,6 +192,9 @@ def test_eight_slots_in_one_process(synth_bam, decode, monkeypatch):
             _lib.load().bsig_cache_clear()
             for rep in range(2):                          # second call: resident on every slot
                 p = _flat(bamProfile(bam, gr, ss=True, shift=60, paired_end="midpoint", tlenFilter=(40, 600), verbose=False), True)
+                if devs != "0" and rep == 0:
+                    # every slot decodes its share -- of the BGZF blocks, or of the BAI islands of the ranges
+                    assert "sharded" in last_call_route(), last_call_route()
                 c = bamCount(bam, gr, mapqual=20, verbose=False)
                 v = _flat(bamCoverage(bam, gr, paired_end="extend", verbose=False), False)
                 res[(devs, rep)] = (p, c, v)

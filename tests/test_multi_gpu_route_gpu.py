@@ -144,7 +144,7 @@ def _want(cols, rg):
             oracle_c.coverage_core(orc, rg, mapqual=5)[0])
 
 
-@pytest.mark.parametrize("gather", ["xgmi", "pcie"])
+@pytest.mark.parametrize("gather", ["xgmi", "copy", "pcie"])
 @pytest.mark.parametrize("devices", ["0,0,0", "0,0,0,0,0,0,0,0"])
 def test_file_level_route_over_several_slots(synth_bam, devices, gather, monkeypatch):
     from bamsignals_amd import _lib
@@ -164,7 +164,16 @@ def test_file_level_route_over_several_slots(synth_bam, devices, gather, monkeyp
         assert last_call_timing()["bam_was_resident"]
         route = last_call_route()
         assert route.startswith("%d GPU slot(s); reads: resident" % len(devices.split(",")))
-        assert ("xgmi/peer" in route) if gather == "xgmi" else route.endswith("pcie")
+        # same-device slots: the first GPU reads the shard buffers in place ("direct"); "copy" forces the
+        # gather into a receive buffer (what RCCL does with distinct GPUs), here with peer copies
+        assert {"xgmi": "result: xgmi/direct", "copy": "result: xgmi/peer", "pcie": "result: pcie"}[gather] in route, route
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        # a call on a resident BAM with shapes seen before allocates nothing for the result path
+        before = _lib.load().bsig_debug_scratch_allocs()
+        assert before > 0
+        got = _three_calls(bam, gr)
+        assert _lib.load().bsig_debug_scratch_allocs() == before
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
         _lib.load().bsig_cache_clear()
@@ -394,3 +403,177 @@ def test_fewer_ranges_than_slots(synth_bam, gather, monkeypatch):
         assert bamCount(bam, zero, verbose=False).tolist() == [0]
     finally:
         _lib.load().bsig_cache_clear()
+
+
+def test_concurrent_host_threads_on_the_multi_gpu_route(synth_bam, monkeypatch):
+    """Several host threads inside the multi-GPU route at once (slots "0,0" and the forced one-rank RCCL
+    exchange): the runs take turns on the slots' cached buffers and on the exchange (RCCL forbids
+    interleaved group calls on one communicator), and the cache may be cleared while calls are in flight."""
+    import threading
+    from bamsignals_amd import _lib, bamCount, bamProfile
+    from oracle import oracle_c
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+    want_p = oracle_c.pileup_core(_oracle(cols), rg, binsize=1, ss=True, shift=12)[0]
+    want_c = oracle_c.pileup_core(_oracle(cols), rg, binsize=-1)[0]
+    for devices, force in (("0,0", "0"), ("0", "1")):
+        monkeypatch.setenv("BAMSIGNALS_DEVICES", devices)
+        monkeypatch.setenv("BAMSIGNALS_FORCE_SHARDED", force)
+        _lib.load().bsig_cache_clear()
+        errors = []
+
+        def worker(t):
+            try:
+                for it in range(5):
+                    if (t + it) % 2:
+                        got = np.concatenate([m.T.reshape(-1) for m in bamProfile(bam, gr, ss=True, shift=12, verbose=False)])
+                        assert np.array_equal(got, want_p), (t, it)
+                    else:
+                        assert np.array_equal(bamCount(bam, gr, verbose=False), want_c), (t, it)
+                    if t == 0 and it == 2:
+                        _lib.load().bsig_cache_clear()          # while the other threads are inside their calls
+            except Exception as exc:            # noqa: BLE001 - reported below
+                errors.append(repr(exc))
+        try:
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            assert not errors, errors
+        finally:
+            _lib.load().bsig_cache_clear()
+
+
+def test_alternating_device_lists_keep_their_resident_copies(synth_bam, monkeypatch):
+    """A session that alternates between two device lists (here "0" and "0,0") keeps both resident sets."""
+    from bamsignals_amd import _lib, bamCount
+    from bamsignals_amd.wrappers import last_call_timing
+    from oracle import oracle_c
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+    want = oracle_c.pileup_core(_oracle(cols), rg, binsize=-1)[0]
+    _lib.load().bsig_cache_clear()
+    try:
+        seen = []
+        for devices in ("0", "0,0", "0", "0,0", "0"):
+            monkeypatch.setenv("BAMSIGNALS_DEVICES", devices)
+            assert np.array_equal(bamCount(bam, gr, verbose=False), want)
+            seen.append(bool(last_call_timing()["bam_was_resident"]))
+        assert seen == [False, False, True, True, True]
+    finally:
+        _lib.load().bsig_cache_clear()
+
+
+def test_region_decodes_are_remembered(synth_bam, monkeypatch):
+    """Index-driven decodes are kept (a few, LRU): a repeated call -- same ranges, or ranges inside an
+    earlier call's -- finds its reads resident; BAMSIGNALS_REGION_CACHE=0 restores the reference's behaviour."""
+    from bamsignals_amd import _lib, bamCount, bamProfile
+    from bamsignals_amd.wrappers import last_call_route, last_call_timing
+    from oracle import oracle_c
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", "0")
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "regions")
+    pick = list(range(0, 50))
+    sub = {k: v[pick] for k, v in rg.items()}
+    want_c = oracle_c.pileup_core(_oracle(cols), sub, binsize=-1)[0]
+    want_p = oracle_c.pileup_core(_oracle(cols), sub, binsize=1, shift=20)[0]
+    _lib.load().bsig_cache_clear()
+    try:
+        # the wider query first (shift 20 -> ext 20), then the narrower ones inside it
+        got = np.concatenate(bamProfile(bam, gr[pick], shift=20, verbose=False).as_list())
+        assert np.array_equal(got, want_p) and not last_call_timing()["bam_was_resident"]
+        assert "index-driven decode" in last_call_route()
+        for rep in range(3):
+            assert np.array_equal(bamCount(bam, gr[pick], verbose=False), want_c)
+            t = last_call_timing()
+            assert t["bam_was_resident"] and "resident (index-driven" in last_call_route(), last_call_route()
+        assert t["total"] < 0.01, t                       # a resident call on 50 ranges: no decode, no I/O
+        assert np.array_equal(bamCount(bam, gr[pick[:7]], verbose=False), want_c[:7]) and last_call_timing()["bam_was_resident"]
+        # ranges outside what was decoded: decoded afresh
+        other = list(range(60, 90))
+        w2 = oracle_c.pileup_core(_oracle(cols), {k: v[other] for k, v in rg.items()}, binsize=-1)[0]
+        assert np.array_equal(bamCount(bam, gr[other], verbose=False), w2) and not last_call_timing()["bam_was_resident"]
+        monkeypatch.setenv("BAMSIGNALS_REGION_CACHE", "0")
+        _lib.load().bsig_cache_clear()
+        for rep in range(2):
+            assert np.array_equal(bamCount(bam, gr[pick], verbose=False), want_c)
+            assert not last_call_timing()["bam_was_resident"]
+    finally:
+        _lib.load().bsig_cache_clear()
+
+
+def test_damaged_reads_files_are_refused(synth_bam, tmp_path):
+    """bsig_reads_load trusts nothing in the file: a flipped byte in a column or an index (checksum / index
+    check on the device), shapes that do not follow from the counts, foreign unit tables."""
+    import struct
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Context, Reads
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    ctx = Context(0)
+    b = BamFile(bam)
+    r = Reads.from_bam(ctx, b)
+    f = tmp_path / "r.bsig"
+    r.save(str(f), "s")
+    raw = f.read_bytes()
+    Reads.load(ctx, str(f), "s").close()
+    # header: magic 8, version 4, n_ref 4, n_reads 8, stamp_len 4, n_classes 4, file_bytes 8, then 4 x (n 8, maxspan 4, kshift 4, col_cap 8, idx_entries 8)
+    cls0 = 8 + 4 + 4 + 8 + 4 + 4 + 8
+    def patched(off, fmt, value):
+        x = bytearray(raw)
+        x[off:off + struct.calcsize(fmt)] = struct.pack(fmt, value)
+        return bytes(x)
+    n0, = struct.unpack_from("<q", raw, cls0)
+    kshift0, = struct.unpack_from("<i", raw, cls0 + 12)
+    cases = {
+        "a byte of a column": bytes(raw[:len(raw) // 2]) + bytes([raw[len(raw) // 2] ^ 0x40]) + bytes(raw[len(raw) // 2 + 1:]),
+        "a byte near the end (index)": bytes(raw[:-200]) + bytes([raw[-200] ^ 0x01]) + bytes(raw[-199:]),
+        "kshift": patched(cls0 + 12, "<i", kshift0 + 1),
+        "kshift huge": patched(cls0 + 12, "<i", 40),
+        "class count": patched(cls0, "<q", n0 - 1),
+        "read count": patched(16, "<q", struct.unpack_from("<q", raw, 16)[0] + 5),
+        "idx entries": patched(cls0 + 24, "<Q", struct.unpack_from("<Q", raw, cls0 + 24)[0] - 1),
+        "maxspan": patched(cls0 + 8, "<i", 0),
+    }
+    for what, blob in cases.items():
+        g = tmp_path / "bad.bsig"
+        g.write_bytes(blob)
+        with pytest.raises(_lib.BsigError):
+            Reads.load(ctx, str(g), "s")
+    r.close(); b.close(); ctx.close()
+
+
+def test_segment_map_on_the_device(synth_bam):
+    """bsig_segmap_*: the device-side twin of bsig_scatter_segments, and its argument checks."""
+    import torch
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Context, SegmentMap
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 3000, 4000).astype(np.int64)
+    dst_off = np.concatenate([[0], np.cumsum(lens)])
+    which = rng.permutation(len(lens)).astype(np.int64)
+    src_off = np.concatenate([[0], np.cumsum(lens[which])])
+    src = rng.integers(-5, 1 << 20, int(src_off[-1])).astype(np.int32)
+    want = np.zeros(int(dst_off[-1]), np.int32)
+    lib = _lib.load()
+    _lib.check(lib.bsig_scatter_segments(len(which), src.ctypes.data, src_off.ctypes.data, want.ctypes.data, dst_off.ctypes.data, which.ctypes.data))
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = Context(0, stream=stream.cuda_stream)
+        m = SegmentMap(ctx, src_off, dst_off, which)
+        d_src = torch.from_numpy(src).cuda()
+        d_dst = torch.zeros(len(want), dtype=torch.int32, device="cuda")
+        m.run(d_src.data_ptr(), d_dst.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_dst.cpu().numpy(), want)
+        m.close()
+        bad = src_off.copy(); bad[5] += 1
+        with pytest.raises(_lib.BsigError):
+            SegmentMap(ctx, bad, dst_off, which)
+        w2 = which.copy(); w2[0] = len(lens)
+        with pytest.raises(_lib.BsigError):
+            SegmentMap(ctx, src_off, dst_off, w2)
+        ctx.close()
