@@ -120,6 +120,8 @@ std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<R
 bool crc_check_enabled();
 // the 8 x 256 lookup tables of CRC32 (IEEE, reflected) for 8 bytes per step
 const uint32_t *crc32_slice8_tables();
+// CPUs this process may use (hardware threads, affinity mask, cgroup quota)
+int effective_cpus();
 // the number of decode threads a request of `t` (<= 0: default) resolves to
 int decode_threads(int t);
 // runs body(i) for i in [0, n) on the decode thread pool

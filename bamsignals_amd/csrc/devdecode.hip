@@ -653,17 +653,30 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     const uint64_t share_bytes = uoff[Bend] - uoff[Bbeg];
 
     const uint64_t chunk_cap = std::max<uint64_t>(env_mb("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", 8192), 1u << 20);
-    const uint64_t carry_cap = share_bytes <= chunk_cap ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
     size_t batch_bytes = 32u << 20;        // 512 blocks per copy: pinning 2 x 32 MiB is quick, the copies stay hidden
     if (const char *e = getenv("BAMSIGNALS_BATCH_BLOCKS")) {          // testing: many small batches
         const long v = atol(e);
         if (v > 0) batch_bytes = (size_t)v * 65536u;
     }
+    // With the GPU inflating, nothing can overlap the trip of the FIRST pass's compressed bytes to HBM, so the
+    // first pass is one round of resident inflate lanes (40,960 blocks, 2.5 GiB of stream), the second two,
+    // and only then the full chunk: the head of the pipeline waits for 0.3 GB instead of 1 GB of copies
+    // (env BAMSIGNALS_FIRST_PASS_MB, 0 = no ramp).
+    const char *ramp_env = getenv("BAMSIGNALS_FIRST_PASS_MB");
+    const uint64_t ramp0 = !gpu_inflate || (ramp_env && atoll(ramp_env) <= 0) ? 0 : env_mb("BAMSIGNALS_FIRST_PASS_MB", 2560);
+    // (a share that fits its first pass needs no room for a record carried from pass to pass)
+    const uint64_t carry_cap = share_bytes <= (ramp0 ? std::min(chunk_cap, ramp0) : chunk_cap) ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
+    auto cap_at = [&](size_t b0) -> uint64_t {
+        if (!ramp0) return chunk_cap;
+        const uint64_t done = uoff[b0] - uoff[Bbeg];
+        return std::min<uint64_t>(chunk_cap, done == 0 ? ramp0 : done <= ramp0 ? 2 * ramp0 : chunk_cap);
+    };
     // the blocks of one pass [b0, b1) and the end of what it sees (b1 + overlap on a share's last pass)
     auto chunk_end = [&](size_t b0) {
         size_t b1 = b0;
         uint64_t bytes = 0;
-        while (b1 < Bend && (b1 == b0 || bytes + blocks[b1].isize <= chunk_cap)) bytes += blocks[b1++].isize;
+        const uint64_t cap = cap_at(b0);
+        while (b1 < Bend && (b1 == b0 || bytes + blocks[b1].isize <= cap)) bytes += blocks[b1++].isize;
         return b1;
     };
     auto view_end = [&](size_t b1) { return (b1 == Bend && !last_share) ? std::min(nb, Bend + kOverlapBlocks) : b1; };
@@ -835,8 +848,11 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             if (pf.rc) DD_TRY((hipError_t)pf.rc);
             if (pf.B0 != B0 || pf.B1 != Bv) return decline();
             in_off.swap(pf.in_off);
-            R.t_inflate += pf.t_host;
-            R.t_wait += pf.t_wait;
+            // (the helper's own time -- packing into the page-locked halves, waiting for a half to be free -- runs
+            // beside the GPU work of the previous pass; only the join above is time this call waited)
+            if (getenv("BSIG_DIAG_DECODE"))
+                fprintf(stderr, "pass %d: %zu blocks, waited %.1f ms for its compressed bytes (helper: pack %.1f ms, half-wait %.1f ms)\n", pass,
+                        Bv - B0, (now_s() - tj) * 1e3, pf.t_host * 1e3, pf.t_wait * 1e3);
             pf.t_host = pf.t_wait = 0;
             const uint8_t *d_comp_now = d_comp2[pass & 1];
             if (B1 < Bend) start_prefetch(B1, (pass + 1) & 1);
@@ -853,7 +869,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
             DD_TRY(hipStreamSynchronize(st));
             R.t_inflate += now_s() - t0;
-            if (getenv("BSIG_DIAG_INFLATE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d)\n", (now_s() - t0) * 1e3, jobs.size(), status);
+            if (getenv("BSIG_DIAG_INFLATE") || getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d)\n", (now_s() - t0) * 1e3, jobs.size(), status);
             if (status) return decline();      // a damaged block: the CPU path reports it
         } else {
         // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
@@ -1667,9 +1683,13 @@ int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::s
     uint64_t total = 0;
     rc = build_islands(path, idx, regions, threads, f, isl, total);
     if (rc) return rc;
-    size_t min_islands = 2;                                 // per share: fewer islands than that are not worth a GPU
-    if (const char *e = getenv("BAMSIGNALS_SHARD_MIN_ISLANDS")) min_islands = (size_t)std::max(1l, atol(e));
-    if (isl.size() < min_islands * n || total == 0) return kNeedsCpuPath;
+    // enough work to share?  (the same knob as the whole-file shares: blocks per GPU)
+    size_t min_blocks = 16, n_blocks = 0;
+    if (const char *e = getenv("BAMSIGNALS_SHARD_MIN_BLOCKS")) min_blocks = (size_t)std::max(1l, atol(e));
+    for (const Island &I : isl) n_blocks += I.blocks.size();
+    if (isl.size() < 2 || total == 0 || n_blocks < min_blocks * n) return kNeedsCpuPath;
+    // contiguous runs of whole islands of about equal uncompressed size; with fewer islands than GPUs some
+    // shares stay empty (an island cannot be cut: only its ends are vouched for by the index)
     std::vector<size_t> cut(n + 1, isl.size());
     cut[0] = 0;
     {
@@ -1677,9 +1697,8 @@ int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::s
         size_t g = 1;
         for (size_t i = 0; i < isl.size() && g < n; ++i) {
             acc += isl[i].bytes;
-            while (g < n && acc >= total / n * g) { cut[g] = std::min(std::max(i + 1, cut[g - 1] + 1), isl.size() - (n - g)); ++g; }
+            while (g < n && acc * n >= total * g) cut[g++] = i + 1;
         }
-        for (size_t q = 1; q < n; ++q) cut[q] = std::min(std::max(cut[q], cut[q - 1] + 1), isl.size() - (n - q));
     }
     T[0] = now_s() - t_begin;
     const bool gpu_inflate = islands_gpu_inflate(isl, threads);

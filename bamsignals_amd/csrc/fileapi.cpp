@@ -828,6 +828,8 @@ int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const in
     return BSIG_OK;
 }
 
+int32_t bsig_effective_cpus(void) { return (int32_t)bsig::effective_cpus(); }
+
 void bsig_last_call_timing(double *t6)
 {
     for (int k = 0; k < 6; ++k) t6[k] = g_call_timing[k];

@@ -351,8 +351,8 @@ __device__ __forceinline__ void add_vec(int32_t *__restrict__ gbase, int v, int4
 // half never sees a carry from the lower one.  Half the LDS per workgroup: 24 instead of 18
 // single-wave workgroups per CU (LDS is allocated in 1,280-byte granules on gfx950), which puts
 // config 2's 10,000 tiles into two rounds of resident workgroups instead of two and a sparse third.
-template <int NT, bool SS>
-__global__ __launch_bounds__(NT) void k_profile(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
+template <int NT, bool SS, int PRE, int WAVES>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_profile(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
                                                 int32_t *__restrict__ out,
                                                 const uint2 *__restrict__ windows,
                                                 const BsigReadsDev R, const BsigKParams P)
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(NT) void k_profile(const BsigWorkItem *__restrict__
             atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
         }
     };
-    if (!BSIG_ABLATE(1)) for_each_read<NT>(R, P, win, tid, one);
+    if (!BSIG_ABLATE(1)) for_each_read<NT, PRE>(R, P, win, tid, one);
     block_sync<NT>();
     BSIG_STAMP(2);
 
@@ -947,15 +947,30 @@ __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
 // ------------------------------------------------------------------------------------------
 namespace bsig {
 
+// Tuning knobs (defaults from the environment once, changeable at run time through bsig_debug_set_knob for
+// the sweep scripts): 0 = k_profile class-0 passes in flight (BAMSIGNALS_PROFILE_PRE), 1 = count tiles per
+// wave (BAMSIGNALS_COUNT_TILES), 2 = count passes in flight (BAMSIGNALS_COUNT_PRE).
+static int g_knobs[4] = {-1, -1, -1, -1};
+static int knob(int k)
+{
+    static const char *const names[4] = {"BAMSIGNALS_PROFILE_PRE", "BAMSIGNALS_COUNT_TILES", "BAMSIGNALS_COUNT_PRE", "BAMSIGNALS_KNOB3"};
+    static const int dflt[4] = {4, 4, 2, 0};
+    if (g_knobs[k] < 0) {
+        const char *e = getenv(names[k]);
+        g_knobs[k] = e ? atoi(e) : dflt[k];
+    }
+    return g_knobs[k];
+}
+
 template <int NT>
 static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const BsigKParams &P,
                               const BsigWorkItem *items, int64_t n_items, int tile_cells,
                               uint2 *windows, bool resolve_first, int32_t *out, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
-    // count family: consecutive tiles per wave (BAMSIGNALS_COUNT_TILES=1|2|4|8, tuning)
-    static const int count_tiles = [] { const char *e = getenv("BAMSIGNALS_COUNT_TILES"); return e ? atoi(e) : 4; }();
-    static const int count_pre = [] { const char *e = getenv("BAMSIGNALS_COUNT_PRE"); return e ? atoi(e) : 3; }();
+    // count family: consecutive tiles per wave and class-0 passes in flight (knobs 1 and 2; 4 x 2 measured best
+    // on config 3's tiling, scripts/count_sweep.py)
+    const int count_tiles = knob(1), count_pre = knob(2);
     if (windows && resolve_first)
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
                            R, P, mode, items, n_items, windows);
@@ -967,8 +982,16 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
         else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (mode == BSIG_MODE_PROFILE) {
         const size_t lds = (size_t)((tile_cells * (ss ? 2 : 1) + 8 + 7) / 8) * 16;     // 16-bit counters
-        if (ss) hipLaunchKernelGGL((k_profile<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
-        else    hipLaunchKernelGGL((k_profile<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
+        // class-0 passes requested before anything is consumed (knob 0: 2, 3 or 4; fewer = fewer VGPRs = more
+        // resident waves, more = one round trip for denser windows)
+        const int pre = knob(0);
+#define BSIG_KP(SS_, PRE_, W_) hipLaunchKernelGGL((k_profile<NT, SS_, PRE_, W_>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P)
+        // knob 3: ask the compiler for 8 waves per SIMD (96 SGPRs, the rest spilled into VGPR lanes) -- only the
+        // two-pass variant has the VGPRs to spare
+        const bool w8 = knob(3) == 8 && NT == kWave;
+        if (ss) { if (pre <= 2) { if (w8) BSIG_KP(true, 2, 8); else BSIG_KP(true, 2, 1); } else if (pre == 3) BSIG_KP(true, 3, 1); else BSIG_KP(true, 4, 1); }
+        else    { if (pre <= 2) { if (w8) BSIG_KP(false, 2, 8); else BSIG_KP(false, 2, 1); } else if (pre == 3) BSIG_KP(false, 3, 1); else BSIG_KP(false, 4, 1); }
+#undef BSIG_KP
     } else if (mode == BSIG_MODE_COVERAGE) {
         const size_t lds = (size_t)((tile_cells + 8 + 7) / 8) * 16 + (size_t)(NT / 64) * sizeof(int32_t);   // signed 16-bit cells
         hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
@@ -1086,6 +1109,13 @@ hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, 
 }
 
 }  // namespace bsig
+
+extern "C" int bsig_debug_set_knob(int which, int value)
+{
+    if (which < 0 || which >= 4 || value < 0) return -1;
+    bsig::g_knobs[which] = value;
+    return 0;
+}
 
 #ifdef BSIG_STAMPS
 extern "C" int bsig_debug_set_stamp_buffer(void *buf)

@@ -46,6 +46,9 @@ enum {
 enum { BSIG_MODE_PROFILE = 0, BSIG_MODE_COUNT = 1, BSIG_MODE_COVERAGE = 2 };
 
 int bsig_abi_version(void);
+/* CPUs the library sizes its host thread pools by: hardware threads, cut down by the affinity mask and
+ * by a cgroup CPU quota (env BAMSIGNALS_THREADS overrides the pool size itself)                      */
+int32_t bsig_effective_cpus(void);
 const char *bsig_last_error(void);
 
 /* ------------------------------------------------------------------------------------------

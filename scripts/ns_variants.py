@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic: the north star's launch (or --config C2 / C4 / C5) under k_profile's launch-shape knobs --
+class-0 passes in flight (knob 0: 4 / 3 / 2 = 77 / 64 / 53 VGPRs) and the 8-waves-per-SIMD build of the
+two-pass variant (knob 3 = 8: 96 SGPRs, the rest in VGPR lanes, 32 instead of 24-28 workgroups per CU).
+One resident workload, every variant timed on it in turn (twice, interleaved), results compared bit for bit."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="NS")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--ranges", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+
+    import bench
+    from bamsignals_amd import _lib
+    args = argparse.Namespace(seed=0xBA51, tile_cells=0, threads=0)
+    stream = torch.cuda.Stream()
+    w = bench.Workload(args, a.config, 0, 1, 0, stream, a.reads, a.ranges, 0, 0)
+    lib = _lib.load()
+    variants = [("pre4", 4, 0), ("pre3", 3, 0), ("pre2", 2, 0), ("pre2+8waves", 2, 8)]
+    ref = None
+    for rnd in range(2):
+        for name, pre, w8 in variants:
+            assert lib.bsig_debug_set_knob(0, pre) == 0 and lib.bsig_debug_set_knob(3, w8) == 0
+            _, ms = w.timed(a.steps, 10, stream, lambda: None)
+            got = [o.clone() for o in w.outs]
+            if ref is None:
+                ref = got
+            same = all(torch.equal(x, y) for x, y in zip(got, ref))
+            print(json.dumps(dict(config=a.config, variant=name, round=rnd, kernel_ms=ms,
+                                  frac=w.stats["algorithmic_bytes"] / ms / 1e6 / 8000, identical=same)), flush=True)
+            if not same:
+                raise SystemExit("variant differs")
+
+
+if __name__ == "__main__":
+    main()
