@@ -6,8 +6,10 @@
 //     (sorted by reference id, then pos).  A class has four 32-bit columns
 //        pos  : 0-based leftmost position                         (core.pos)
 //        end  : bam_endpos - 1, inclusive                         (src/bamsignals.cpp:16-18)
-//               -- classes 1..3 only; class 0 (span <= 256) keeps span - 1 in fm's top byte
-//        fm   : flag | mapq << 16 [| (span - 1) << 24 in class 0]
+//               -- classes 2..3 only; classes 0 and 1 keep span - 1 inside fm
+//        fm   : class 0 (span <= 256):  flag | mapq << 16 | (span - 1) << 24
+//               class 1 (span <= 4096, flag < 4096): flag | mapq << 12 | (span - 1) << 20
+//               classes 2..3: flag | mapq << 16
 //        tlen : template length                                   (core.isize)
 //     and a bucket index  idx[b] = first read of the class whose global coordinate
 //     g = (ref_unit0[rid] << 16) + pos  falls in bucket >= b, bucket = g >> kshift.

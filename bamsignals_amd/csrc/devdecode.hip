@@ -395,71 +395,40 @@ Staging &staging_for(int device)
 thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
 
 // The decode's device scratch (the view of the uncompressed stream, the compressed bytes, record
-// offsets ...: 2.6 GB for config 2's BAM) is handed back to a per-process cache instead of hipFree:
-// allocating and freeing it cost 8-14 ms of a 50-ms decode.  Dropped by bsig_cache_clear(), and
-// trimmed (largest first) above BAMSIGNALS_SCRATCH_CACHE_GB (default 8).
-struct ScratchCache {
-    struct Blk { int dev; void *p; size_t bytes; };
-    std::mutex mu;
-    std::vector<Blk> free_;
-    size_t cached = 0;
-    void release_all()
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (const Blk &b : free_) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
-        free_.clear();
-        cached = 0;
-    }
-};
-ScratchCache g_scratch;
-
+// offsets ...: 2.6 GB for config 2's BAM, 25 GB for the north star's) comes from the per-process cache of
+// large free blocks (runtime_internal.h: block_alloc / block_free) instead of hipMalloc / hipFree: apart
+// from 8-14 ms per decode, freed memory goes back to the driver in bulk and stalls a later hipMalloc for
+// seconds.  Short-lived, so a cached block of up to twice the size will do.
 struct ScratchPool {
     int device;
     hipStream_t st;
-    std::vector<ScratchCache::Blk> mine;
+    struct Blk { void *p; size_t bytes; bool cached; };
+    std::vector<Blk> mine;
     ScratchPool(int dev, hipStream_t s) : device(dev), st(s) {}
     template <typename T>
     hipError_t alloc(T **p, size_t count)
     {
         const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
-        {
-            std::lock_guard<std::mutex> lk(g_scratch.mu);
-            size_t best = (size_t)-1;
-            for (size_t k = 0; k < g_scratch.free_.size(); ++k) {
-                const ScratchCache::Blk &b = g_scratch.free_[k];
-                if (b.dev != device || b.bytes < bytes || b.bytes > 2 * bytes + (1u << 20)) continue;
-                if (best == (size_t)-1 || b.bytes < g_scratch.free_[best].bytes) best = k;
-            }
-            if (best != (size_t)-1) {
-                mine.push_back(g_scratch.free_[best]);
-                g_scratch.cached -= g_scratch.free_[best].bytes;
-                g_scratch.free_.erase(g_scratch.free_.begin() + (long)best);
-                *p = (T *)mine.back().p;
-                return hipSuccess;
-            }
-        }
         void *q = nullptr;
-        const hipError_t e = hipMalloc(&q, bytes);
-        if (e != hipSuccess) { *p = nullptr; return e; }
-        mine.push_back(ScratchCache::Blk{device, q, bytes});
+        if (bytes >= bsig::kBlockCacheMin) {
+            size_t got = 0;
+            const hipError_t e = bsig::block_alloc(device, bytes, 2.0, &q, &got);
+            if (e != hipSuccess) { *p = nullptr; return e; }
+            mine.push_back(Blk{q, got, true});
+        } else {
+            const hipError_t e = hipMalloc(&q, bytes);
+            if (e != hipSuccess) { *p = nullptr; return e; }
+            mine.push_back(Blk{q, bytes, false});
+        }
         *p = (T *)q;
         return hipSuccess;
     }
     ~ScratchPool()
     {
         (void)hipStreamSynchronize(st);          // nothing in flight may still use the blocks
-        size_t limit = (size_t)8 << 30;
-        if (const char *e = getenv("BAMSIGNALS_SCRATCH_CACHE_GB")) limit = (size_t)std::max(0ll, atoll(e)) << 30;
-        std::lock_guard<std::mutex> lk(g_scratch.mu);
-        for (const ScratchCache::Blk &b : mine) { g_scratch.free_.push_back(b); g_scratch.cached += b.bytes; }
-        while (g_scratch.cached > limit && !g_scratch.free_.empty()) {
-            size_t big = 0;
-            for (size_t k = 1; k < g_scratch.free_.size(); ++k)
-                if (g_scratch.free_[k].bytes > g_scratch.free_[big].bytes) big = k;
-            (void)hipSetDevice(g_scratch.free_[big].dev);
-            (void)hipFree(g_scratch.free_[big].p);
-            g_scratch.cached -= g_scratch.free_[big].bytes;
-            g_scratch.free_.erase(g_scratch.free_.begin() + (long)big);
+        for (const Blk &b : mine) {
+            if (b.cached) bsig::block_free(device, b.p, b.bytes);
+            else (void)hipFree(b.p);
         }
         (void)hipSetDevice(device);
     }
@@ -552,6 +521,17 @@ struct Piece {
     }
 };
 
+// env BSIG_DIAG_DECODE: wall time since the previous mark, per call site (where do 2-3 s stalls come from?)
+void diag_mark(const char *what)
+{
+    static thread_local double last = 0;
+    static const bool on = getenv("BSIG_DIAG_DECODE") != nullptr;
+    if (!on) return;
+    const double t = now_s();
+    if (what) fprintf(stderr, "  [decode] %-34s +%.1f ms\n", what, (t - last) * 1e3);
+    last = t;
+}
+
 uint64_t env_mb(const char *name, uint64_t dflt_mb)
 {
     if (const char *e = getenv(name)) { const long long v = atoll(e); if (v > 0) return (uint64_t)v << 20; }
@@ -604,11 +584,13 @@ int finish_reads(bsig_ctx *ctx, hipStream_t st, ScratchPool &tmp, std::vector<st
         ref_off[(size_t)r] = ref_first[(size_t)r] >= 0 ? ref_first[(size_t)r] : ref_off[(size_t)r + 1];
     ref_off[0] = 0;
     t_gpu_join = now_s() - t_join;
+    diag_mark("join of the column pieces");
     const double t_lay = now_s();
     const int rc = layout_from_device(ctx, R, n_reads, n_ref, hdr.lens.data(), ref_off.data(), cols->pos, cols->end, cols->flag,
                                       cols->mapq, cols->tlen);
     if (rc) return bail(rc);
     t_layout = now_s() - t_lay;
+    diag_mark("resident layout");
     *out = R;
     return BSIG_OK;
 }
@@ -727,10 +709,12 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         if (n_pass > 1) HIP_TRY(tmp.alloc(&d_comp2[1], (size_t)max_comp + 64));     // several passes: two buffers
     }
 
+    diag_mark("  scratch allocations");
     Staging &S = staging_for(ctx->device);
     std::lock_guard<std::mutex> lock(S.mu);
     int rc = S.ensure(batch_bytes);
     if (rc) return rc;
+    diag_mark("  page-locked staging");
 
     // With the GPU inflating, the compressed bytes of pass j + 1 are packed and copied (helper thread,
     // its own stream, the other buffer) while the GPU inflates and parses pass j.
@@ -1056,12 +1040,15 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     const double t_begin = now_s();
     *out = nullptr;
     FileScan F;
+    diag_mark(nullptr);
     int rc = scan_file(path, threads, F);
     if (rc) return rc;
+    diag_mark("map + populate + block scan");
     T[0] = now_s() - t_begin;
     ShareOut S;
     rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, F.f.blocks().size(), threads, F.gpu_inflate, S);
     if (rc) return rc;
+    diag_mark("decode_share (all passes)");
     T[1] = S.t_inflate;
     T[2] = S.t_wait;
     // ---- join the pieces, first read of every reference, resident layout ---------------------------
@@ -1728,7 +1715,7 @@ int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::s
     return BSIG_OK;
 }
 
-void release_decode_scratch() { g_scratch.release_all(); }
+void release_decode_scratch() { block_cache_release(); }
 
 }  // namespace bsig
 

@@ -31,7 +31,7 @@ hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag,
                             const uint32_t *cigar, int32_t *end_out, hipStream_t st);
 int64_t prep_chunks(int64_t n);
 hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, const int32_t *pos,
-                            const int32_t *end, uint32_t *chunk_counts,
+                            const int32_t *end, const uint16_t *flag, uint32_t *chunk_counts,
                             int32_t *maxspan /* BSIG_MAX_CLASSES + 1: [4] = "not sorted" flag */, hipStream_t st);
 hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, const uint32_t *ref_unit0,
                           const uint32_t *ref_units, const int32_t *pos, const int32_t *end,

@@ -192,6 +192,10 @@ __global__ void k_count_heavy(const uint2 *__restrict__ windows, int64_t n_items
     if (total > heavy_reads) atomicAdd(count, 1ull);
 }
 
+// class 1's word (flag (12 bits) | mapq << 12 | (span - 1) << 20, see span_class below) in the layout the
+// filters read: flag | mapq << 16
+__device__ __forceinline__ uint32_t fm_of_class1(uint32_t w) { return (w & 0xFFFu) | ((w >> 12) & 0xFFu) << 16; }
+
 // Stream the reads of all span-class windows of one tile through `one(pos, end, fm, tlen, valid)`.
 // Everything a typical tile needs is requested before anything is consumed, so the workgroup pays
 // ONE memory round trip for its reads: the first kPre0 passes (kPre0 * 4 * NT reads) of class 0,
@@ -201,7 +205,7 @@ template <int NT, int kPre0 = 4, typename F>
 __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
                                               const uint2 (&win)[BSIG_MAX_CLASSES], int tid, F &&one)
 {
-    int4 p0[kPre0], t0[kPre0], p1, e1, t1 = make_int4(0, 0, 0, 0);
+    int4 p0[kPre0], t0[kPre0], p1, t1 = make_int4(0, 0, 0, 0);
     uint4 f0[kPre0], f1;
     const uint32_t jb0 = (win[0].x & ~3u) + 4u * tid;
 #pragma unroll
@@ -218,7 +222,6 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     if (jb1 < win[1].y) {
         p1 = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
         f1 = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
-        e1 = *reinterpret_cast<const int4 *>(R.cls[1].end + jb1);
         if (P.use_tlen) t1 = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
     }
     // The 16-B aligned loads may start before j_lo (possibly on the previous reference) and end
@@ -255,21 +258,33 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
             if (j2 < j_hi) four(pb, fb, tb, j2);
         }
     }
+    {   // ---- class 1 (span <= 4096, 12-bit flags): no end column either, end = pos + (word >> 20) -----------
+        const BsigClassCols &C = R.cls[1];
+        const uint32_t j_lo = win[1].x, j_hi = win[1].y, nj = j_hi - j_lo;
+        auto four1 = [&](const int4 &p, const uint4 &f, const int4 &t, uint32_t j) {
+            const uint32_t dj = j - j_lo;
+            one(p.x, p.x + (int)(f.x >> 20), fm_of_class1(f.x), t.x, dj < nj);
+            one(p.y, p.y + (int)(f.y >> 20), fm_of_class1(f.y), t.y, dj + 1u < nj);
+            one(p.z, p.z + (int)(f.z >> 20), fm_of_class1(f.z), t.z, dj + 2u < nj);
+            one(p.w, p.w + (int)(f.w >> 20), fm_of_class1(f.w), t.w, dj + 3u < nj);
+        };
+        uint32_t j = jb1;
+        if (j < j_hi) {
+            four1(p1, f1, t1, j);
+            for (j += 4u * NT; j < j_hi; j += 4u * NT) {
+                const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
+                const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+                int4 t = make_int4(0, 0, 0, 0);
+                if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
+                four1(p, f, t, j);
+            }
+        }
+    }
 #pragma unroll
-    for (int c = 1; c < BSIG_MAX_CLASSES; ++c) {   // ---- classes 1-3: pos, end, fm columns ---------
+    for (int c = 2; c < BSIG_MAX_CLASSES; ++c) {   // ---- classes 2-3: pos, end, fm columns ---------
         const BsigClassCols &C = R.cls[c];
         const uint32_t j_lo = win[c].x, j_hi = win[c].y, nj = j_hi - j_lo;
-        uint32_t j = (j_lo & ~3u) + 4u * tid;
-        if (c == 1) {
-            if (j >= j_hi) continue;
-            const uint32_t dj = j - j_lo;
-            one(p1.x, e1.x, f1.x, t1.x, dj < nj);
-            one(p1.y, e1.y, f1.y, t1.y, dj + 1u < nj);
-            one(p1.z, e1.z, f1.z, t1.z, dj + 2u < nj);
-            one(p1.w, e1.w, f1.w, t1.w, dj + 3u < nj);
-            j += 4u * NT;
-        }
-        for (; j < j_hi; j += 4u * NT) {
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
             const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
             const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
             const int4 e = *reinterpret_cast<const int4 *>(C.end + j);
@@ -736,10 +751,16 @@ __global__ void k_cigar_end(int64_t n, const int32_t *__restrict__ pos,
     end_out[i] = (int32_t)(pos[i] + rlen - 1);
 }
 
-__device__ __forceinline__ int span_class(int span)
+// Span classes 0 and 1 keep `span - 1` next to flag and mapq in ONE word (no end column: 8 B per visit):
+//   class 0 (span <= 256):   flag (16 bits) | mapq << 16 | (span - 1) << 24
+//   class 1 (span <= 4096):  flag (12 bits) | mapq << 12 | (span - 1) << 20
+// The SAM specification defines 12 flag bits; a read that sets a higher one (a uint16 can) and spans more
+// than 256 bp goes to class 2, whose words hold all 16.
+__device__ __forceinline__ int span_class(int span, uint32_t flag)
 {
-    return span <= 256 ? 0 : span <= 4096 ? 1 : span <= 65536 ? 2 : 3;
+    return span <= 256 ? 0 : (span <= 4096 && flag < 4096u) ? 1 : span <= 65536 ? 2 : 3;
 }
+
 
 constexpr int kPrepThreads = 256;
 constexpr int kPrepChunk = 2048;     // reads per workgroup in k_span_hist / k_scatter
@@ -750,6 +771,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n
                                                             const int64_t *__restrict__ ref_off,
                                                             const int32_t *__restrict__ pos,
                                                             const int32_t *__restrict__ end,
+                                                            const uint16_t *__restrict__ flag,
                                                             uint32_t *__restrict__ chunk_counts,
                                                             int32_t *__restrict__ maxspan)
 {
@@ -763,7 +785,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n
         const int64_t i = base + r * kPrepThreads + tid;
         if (i < n) {
             const int span = end[i] - pos[i] + 1;
-            const int c = span_class(span);
+            const int c = span_class(span, flag[i]);
             atomicAdd(&cnt[c], 1u);
             atomicMax(&mx[c], span);
             if (i > 0 && pos[i] < pos[i - 1]) {
@@ -817,7 +839,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
         const int64_t i = base + r * kPrepThreads + tid;
         const bool valid = i < n;
         int p = 0, e = 0, cls = -1;
-        if (valid) { p = pos[i]; e = end[i]; cls = span_class(e - p + 1); }
+        if (valid) { p = pos[i]; e = end[i]; cls = span_class(e - p + 1, flag[i]); }
         uint32_t rank = 0;
 #pragma unroll
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
@@ -842,6 +864,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
             O.pos[cls][dst] = p;
             uint32_t fmw = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 16);
             if (cls == 0) fmw |= (uint32_t)(e - p) << 24;      // span - 1 <= 255
+            else if (cls == 1) fmw = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 12) | ((uint32_t)(e - p) << 20);   // flag < 4096, span - 1 <= 4095
             else O.end[cls][dst] = e;
             O.fm[cls][dst] = fmw;
             O.tlen[cls][dst] = tlen[i];
@@ -954,7 +977,7 @@ static int g_knobs[4] = {-1, -1, -1, -1};
 static int knob(int k)
 {
     static const char *const names[4] = {"BAMSIGNALS_PROFILE_PRE", "BAMSIGNALS_COUNT_TILES", "BAMSIGNALS_COUNT_PRE", "BAMSIGNALS_KNOB3"};
-    static const int dflt[4] = {4, 4, 2, 0};
+    static const int dflt[4] = {3, 4, 2, 0};
     if (g_knobs[k] < 0) {
         const char *e = getenv(names[k]);
         g_knobs[k] = e ? atoi(e) : dflt[k];
@@ -1053,11 +1076,11 @@ hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag,
 int64_t prep_chunks(int64_t n) { return (n + kPrepChunk - 1) / kPrepChunk; }
 
 hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, const int32_t *pos,
-                            const int32_t *end, uint32_t *chunk_counts, int32_t *maxspan, hipStream_t st)
+                            const int32_t *end, const uint16_t *flag, uint32_t *chunk_counts, int32_t *maxspan, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_span_hist, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
-                       n, n_ref, ref_off, pos, end, chunk_counts, maxspan);
+                       n, n_ref, ref_off, pos, end, flag, chunk_counts, maxspan);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +49,100 @@ int fail(int code, const char *fmt, ...)
 using bsig::fail;
 
 #include "runtime_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// the per-process cache of large free device blocks (runtime_internal.h)
+// ---------------------------------------------------------------------------------------------
+namespace bsig {
+namespace {
+struct BlockCache {
+    struct Blk { int dev; void *p; size_t bytes; };
+    std::mutex mu;
+    std::vector<Blk> free_;
+    size_t cached = 0;
+} g_blocks;
+size_t block_cache_limit()
+{
+    size_t gb = 48;
+    if (const char *e = getenv("BAMSIGNALS_SCRATCH_CACHE_GB")) gb = (size_t)std::max(0ll, atoll(e));
+    return gb << 30;
+}
+}  // namespace
+
+hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, size_t *got)
+{
+    bytes = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lk(g_blocks.mu);
+        size_t best = (size_t)-1;
+        const size_t cap = (size_t)((double)bytes * max_waste) + (1u << 20);
+        for (size_t k = 0; k < g_blocks.free_.size(); ++k) {
+            const BlockCache::Blk &b = g_blocks.free_[k];
+            if (b.dev != device || b.bytes < bytes || b.bytes > cap) continue;
+            if (best == (size_t)-1 || b.bytes < g_blocks.free_[best].bytes) best = k;
+        }
+        if (best != (size_t)-1) {
+            *p = g_blocks.free_[best].p;
+            *got = g_blocks.free_[best].bytes;
+            g_blocks.cached -= g_blocks.free_[best].bytes;
+            g_blocks.free_.erase(g_blocks.free_.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        // the cache itself may be what fills the device: hand it back and try once more
+        (void)hipGetLastError();
+        block_cache_release();
+        (void)hipSetDevice(device);
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) { *p = nullptr; return e; }
+    *got = bytes;
+    return hipSuccess;
+}
+
+void block_free(int device, void *p, size_t bytes)
+{
+    if (!p) return;
+    const size_t limit = block_cache_limit();
+    std::vector<BlockCache::Blk> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_blocks.mu);
+        g_blocks.free_.push_back(BlockCache::Blk{device, p, bytes});
+        g_blocks.cached += bytes;
+        while (g_blocks.cached > limit && !g_blocks.free_.empty()) {
+            size_t big = 0;
+            for (size_t k = 1; k < g_blocks.free_.size(); ++k)
+                if (g_blocks.free_[k].bytes > g_blocks.free_[big].bytes) big = k;
+            drop.push_back(g_blocks.free_[big]);
+            g_blocks.cached -= g_blocks.free_[big].bytes;
+            g_blocks.free_.erase(g_blocks.free_.begin() + (long)big);
+        }
+    }
+    if (drop.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const BlockCache::Blk &b : drop) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    (void)hipSetDevice(cur);
+}
+
+void block_cache_release()
+{
+    std::vector<BlockCache::Blk> all;
+    {
+        std::lock_guard<std::mutex> lk(g_blocks.mu);
+        all.swap(g_blocks.free_);
+        g_blocks.cached = 0;
+    }
+    if (all.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const BlockCache::Blk &b : all) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    (void)hipSetDevice(cur);
+}
+}  // namespace bsig
 
 struct bsig_plan {
     bsig_ctx *ctx = nullptr;
@@ -206,7 +301,7 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
     int64_t *d_ref_off;
     HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
     HIP_TRY(hipMemcpyAsync(d_ref_off, ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_pos, d_end, d_counts, d_maxspan, st));
+    HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_pos, d_end, d_flag, d_counts, d_maxspan, st));
     std::vector<uint32_t> counts(n_chunks * BSIG_MAX_CLASSES);
     int32_t maxspan[BSIG_MAX_CLASSES + 1];
     HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -222,6 +317,8 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
             class_n[c] += counts[k * BSIG_MAX_CLASSES + c];
         }
 
+    const bool diag = getenv("BSIG_DIAG_DECODE") != nullptr;
+    const auto t_diag0 = std::chrono::steady_clock::now();
     // bucket width per class: about 16 reads per bucket, 16 bp .. 64 kbp
     bsig::ScatterPtrs S{};
     uint64_t n_buckets[BSIG_MAX_CLASSES] = {0, 0, 0, 0};
@@ -244,7 +341,7 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         uint32_t *f, *gb, *idx;
         HIP_TRY(R->pool.alloc(&p, cap));
         e = nullptr;
-        if (c != 0) HIP_TRY(R->pool.alloc(&e, cap));      // class 0 packs its span into fm
+        if (c >= 2) HIP_TRY(R->pool.alloc(&e, cap));      // classes 0 and 1 pack their span into fm
         HIP_TRY(R->pool.alloc(&f, cap));
         HIP_TRY(R->pool.alloc(&t, cap));
         HIP_TRY(tmp.alloc(&gb, cap));
@@ -266,6 +363,9 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         R->info.n_classes += 1;
     }
 
+    if (diag)
+        fprintf(stderr, "  [layout] column + index allocations %.1f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_diag0).count());
     uint32_t *d_unit0, *d_units;
     uint64_t *d_base;
     HIP_TRY(tmp.alloc(&d_unit0, n_ref));
@@ -554,7 +654,7 @@ struct SidecarHeader {
     SidecarClass cls[BSIG_MAX_CLASSES];
     uint64_t checksum;              // of every column and index as it lay in HBM when the file was written
 };
-constexpr uint32_t kSidecarVersion = 2;
+constexpr uint32_t kSidecarVersion = 3;
 inline uint64_t pad64(uint64_t v) { return (v + 63) & ~(uint64_t)63; }
 }  // namespace
 
@@ -606,7 +706,7 @@ int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp
         const BsigClassCols &C = reads->dev.cls[c];
         H.cls[c] = SidecarClass{C.n, C.maxspan, C.kshift, C.n ? reads->col_cap[c] : 0, C.n ? reads->idx_entries[c] : 0};
         if (!C.n) continue;
-        bytes += (c ? 4 : 3) * pad64(H.cls[c].col_cap * 4) + pad64(H.cls[c].idx_entries * 4);
+        bytes += (c >= 2 ? 4 : 3) * pad64(H.cls[c].col_cap * 4) + pad64(H.cls[c].idx_entries * 4);
     }
     H.file_bytes = bytes;
     {
@@ -640,7 +740,7 @@ int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp
         const BsigClassCols &C = reads->dev.cls[c];
         if (!C.n) continue;
         put_dev(C.pos, H.cls[c].col_cap * 4);
-        if (c) put_dev(C.end, H.cls[c].col_cap * 4);
+        if (c >= 2) put_dev(C.end, H.cls[c].col_cap * 4);
         put_dev(C.fm, H.cls[c].col_cap * 4);
         put_dev(C.tlen, H.cls[c].col_cap * 4);
         put_dev(C.idx, H.cls[c].idx_entries * 4);
@@ -771,7 +871,7 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
             return upload_staged(ctx->device, ctx->stream, src, (uint8_t *)d, (size_t)count * 4);
         };
         int rc = load(K.col_cap, (const void **)&C.pos);
-        if (!rc && c) rc = load(K.col_cap, (const void **)&C.end);
+        if (!rc && c >= 2) rc = load(K.col_cap, (const void **)&C.end);
         if (!rc) rc = load(K.col_cap, (const void **)&C.fm);
         if (!rc) rc = load(K.col_cap, (const void **)&C.tlen);
         if (!rc) rc = load(K.idx_entries, (const void **)&C.idx);
@@ -1102,10 +1202,10 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         t.n_ranges = p->n_ranges;
         t.n_items = p->n_items;
         t.cells = p->off.back();
-        t.visits_short = (int64_t)acc[0];
+        t.visits_short = (int64_t)(acc[0] + acc[1]);         // classes 0 and 1: no end column
         t.visits = (int64_t)(acc[0] + acc[1] + acc[2] + acc[3]);
         t.streamed = (int64_t)acc[4];
-        t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // pos + packed flag/mapq/span [+ tlen]
+        t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // span <= 4096: pos + packed flag/mapq/span [+ tlen]
         t.bytes_per_visit_long = p->kp.use_tlen ? 16 : 12;     // pos + end + flag/mapq [+ tlen]
         // reads + work items + index entries + result cells
         const int64_t per_item = (int64_t)sizeof(BsigWorkItem);

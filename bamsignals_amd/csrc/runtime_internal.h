@@ -21,26 +21,55 @@
                         __FILE__, __LINE__, #expr);                                            \
     } while (0)
 
+namespace bsig {
+// Large device blocks are kept and reused instead of going back to the driver.  Measured on MI355X / ROCm 7.2
+// with plain hipMalloc / hipFree (scripts/hipmalloc_stalls.py): a hipMalloc normally returns in 0.3 ms, but
+// once about 70 GB have been freed since the last time, ONE hipMalloc takes 2.2-3.4 s (the freed memory is
+// handed back in bulk).  A decode of the north star's BAM allocates and frees 25 GB of scratch, so every third
+// cold decode of a session paid that.  Blocks of kBlockCacheMin bytes or more therefore come from, and
+// return to, a per-process cache of free blocks (best fit within `max_waste`), bounded by env
+// BAMSIGNALS_SCRATCH_CACHE_GB (default 48; above it the largest free blocks are released first);
+// bsig_cache_clear() releases all of it.
+constexpr size_t kBlockCacheMin = (size_t)8 << 20;
+// *got receives the block's real size (>= bytes), which block_free wants back
+hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, size_t *got);
+void block_free(int device, void *p, size_t bytes);
+void block_cache_release();
+}  // namespace bsig
+
 // owns a set of device allocations
 struct DevPool {
-    std::vector<void *> ptrs;
+    struct Blk { void *p; size_t bytes; int device; };       // device < 0: plain hipMalloc
+    std::vector<Blk> blks;
     int64_t bytes = 0;
     template <typename T>
     hipError_t alloc(T **p, size_t count)
     {
         void *q = nullptr;
         const size_t nbytes = std::max<size_t>(count * sizeof(T), 16);
-        hipError_t e = hipMalloc(&q, nbytes);
-        if (e != hipSuccess) { *p = nullptr; return e; }
-        ptrs.push_back(q);
+        if (nbytes >= bsig::kBlockCacheMin) {
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
+            size_t got = 0;
+            if (e == hipSuccess) e = bsig::block_alloc(dev, nbytes, 1.125, &q, &got);      // long-lived: little slack
+            if (e != hipSuccess) { *p = nullptr; return e; }
+            blks.push_back(Blk{q, got, dev});
+        } else {
+            hipError_t e = hipMalloc(&q, nbytes);
+            if (e != hipSuccess) { *p = nullptr; return e; }
+            blks.push_back(Blk{q, nbytes, -1});
+        }
         bytes += (int64_t)nbytes;
         *p = (T *)q;
         return hipSuccess;
     }
     void release()
     {
-        for (void *p : ptrs) (void)hipFree(p);
-        ptrs.clear();
+        for (const Blk &b : blks) {
+            if (b.device >= 0) bsig::block_free(b.device, b.p, b.bytes);
+            else (void)hipFree(b.p);
+        }
+        blks.clear();
         bytes = 0;
     }
     ~DevPool() { release(); }

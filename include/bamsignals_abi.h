@@ -159,10 +159,10 @@ typedef struct {
     int64_t n_items;           /* workgroup tiles                                               */
     int64_t cells;             /* int32 output cells                                            */
     int64_t visits;            /* reads in the exact candidate windows of all tiles (V)         */
-    int64_t visits_short;      /* ... of them in span class 0 (span <= 256, 4 B shorter)        */
+    int64_t visits_short;      /* ... of them in span classes 0-1 (span <= 4096: 4 B shorter)   */
     int64_t streamed;          /* reads actually loaded (windows rounded to index buckets)      */
     int64_t algorithmic_bytes; /* sum(bytes_per_visit*V) + 32*items + 8*items*classes + 4*cells */
-    int32_t bytes_per_visit_short;   /* 8  (pos + flag|mapq|span), 12 with the tlen column      */
+    int32_t bytes_per_visit_short;   /* 8  (pos + flag|mapq|span - 1), 12 with the tlen column  */
     int32_t bytes_per_visit_long;    /* 12 (pos + end + flag|mapq), 16 with the tlen column     */
 } bsig_plan_stats;
 

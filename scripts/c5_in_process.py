@@ -35,9 +35,9 @@ print("GRanges", round(time.time() - t, 1), flush=True)
 os.environ["BAMSIGNALS_DEVICES"] = ",".join(["0"] * slots)
 os.environ["BAMSIGNALS_DECODE"] = "all"
 res = {}
-for gather in ("xgmi", "pcie"):
+for gather in ("xgmi", "pcie"):          # (same-device slots: "xgmi" = the first GPU reads the shards in place)
     os.environ["BAMSIGNALS_GATHER"] = gather
-    for rep in ("cold", "resident"):
+    for rep in ("cold", "resident", "resident"):
         if rep == "cold":
             _lib.load().bsig_cache_clear()
         t = time.time(); sig = bamProfile(bam, gr, verbose=False); dt = time.time() - t

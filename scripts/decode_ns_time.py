@@ -19,15 +19,10 @@ t = time.time(); write_columns_as_bam(bam, ["c%d" % i for i in range(10)], cols,
 del cols
 ctx = Context(0)
 b = BamFile(bam)
-os.environ["BSIG_DIAG_INFLATE"] = "1"
-for rep in range(3):
+os.environ["BSIG_DIAG_DECODE"] = "1"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+for rep in range(reps):
     t = time.time(); r = Reads.from_bam(ctx, b); dt = time.time() - t
     print("decode", rep, round(dt, 3), {k: round(v, 3) for k, v in Reads.device_decode_timing().items()}, flush=True)
-    r.close()
-for chunk in ("4096", "16384", "32768"):
-    os.environ["BAMSIGNALS_DEVICE_DECODE_CHUNK_MB"] = chunk
-    for rep in range(2):
-        t = time.time(); r = Reads.from_bam(ctx, b); dt = time.time() - t
-        print("chunk", chunk, rep, round(dt, 3), {k: round(v, 3) for k, v in Reads.device_decode_timing().items()}, flush=True)
-        r.close()
+    t = time.time(); r.close(); print("  free of the resident reads", round((time.time() - t) * 1e3, 1), "ms", flush=True)
 os.remove(bam); os.remove(bam + ".bai")

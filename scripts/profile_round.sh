@@ -3,11 +3,11 @@
 # rocprofv3 kernel trace of the same command and the two PMC passes (FETCH_SIZE and WRITE_SIZE need
 # separate passes on gfx950; counters are never combined with other trace domains).  Nothing is
 # deleted: scripts/summarize_profile.py takes the newest output of every case.
-# Usage: scripts/profile_round.sh r02 [cases...]    -> gpurun_out/r02_*   (then scripts/summarize_profile.py r02)
+# Usage: scripts/profile_round.sh r03 [cases...]    -> gpurun_out/r03_*   (then scripts/summarize_profile.py r03)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift || true
-CASES=${*:-ns c2 c3 c4 count decode}
+CASES=${*:-ns c2 c3 c4 c5 count decode}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -26,6 +26,7 @@ for c in $CASES; do
     case $c in
     ns)    run_case ns python3 $R/bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also || exit 1 ;;
     c2)    run_case c2 python3 $R/bench.py --config C2 --steps 64 --warmup 16 --no-cpu-baseline --no-e2e || exit 1 ;;
+    c5)    run_case c5 python3 $R/bench.py --config C5 --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also || exit 1 ;;
     c3)    run_case c3 python3 $R/scripts/profile_case.py C3 || exit 1 ;;
     c4)    run_case c4 python3 $R/scripts/profile_case.py C4 || exit 1 ;;
     count) run_case count python3 $R/scripts/profile_case.py count || exit 1 ;;

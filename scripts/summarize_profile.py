@@ -9,17 +9,18 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 # case -> (substring of the dominant kernel's name, the command that was profiled)
 CASES = {
-    "ns": ("k_profile<64, false>", "python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also"),
-    "c2": ("k_profile<64, false>", "python3 bench.py --config C2 --steps 64 --warmup 16 --no-cpu-baseline --no-e2e"),
+    "ns": ("k_profile<64, false", "python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also"),
+    "c2": ("k_profile<64, false", "python3 bench.py --config C2 --steps 64 --warmup 16 --no-cpu-baseline --no-e2e"),
+    "c5": ("k_profile<64, false", "python3 bench.py --config C5 --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also"),
     "c3": ("k_coverage<64>", "python3 scripts/profile_case.py C3"),
-    "c4": ("k_profile<64, true>", "python3 scripts/profile_case.py C4"),
-    "count": ("k_count<64>", "python3 scripts/profile_case.py count"),
+    "c4": ("k_profile<64, true", "python3 scripts/profile_case.py C4"),
+    "count": ("k_count", "python3 scripts/profile_case.py count"),
 }
 
 

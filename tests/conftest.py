@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullsize: BASELINE configurations at full size that take minutes (opt-in: BAMSIGNALS_FULLSIZE=1)")
     # a fresh checkout has no built libraries (they are git-ignored): build them once, as
     # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU)
     so = os.path.join(ROOT, "bamsignals_amd", "libbamsignals_hip.so")

@@ -167,6 +167,40 @@ PE_CASES = [
 ]
 
 
+def test_flag_bits_above_the_sam_specification(ctx, synth):
+    """Span classes 0 and 1 pack span - 1 next to the flag; class 1 has room for the 12 flag bits SAM defines.
+    Reads that set a higher bit (a uint16 can) and span more than 256 bp must land in class 2 and still be
+    filtered on all 16 bits, exactly as the reference filters them (ref: src/bamsignals.cpp:328-333)."""
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_ranges
+    from oracle import oracle_c
+    _, _, cols, end = synth["pe"]
+    flag = cols["flag"].copy()
+    span = end - cols["pos"] + 1
+    rng = np.random.default_rng(77)
+    hit = rng.random(len(flag)) < 0.2
+    flag[hit] |= rng.choice(np.asarray([0x1000, 0x2000, 0x4000, 0x8000, 0x9000], np.uint16), int(hit.sum()))
+    reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], flag, cols["mapq"], cols["tlen"], end=end)
+    info = reads.info()
+    c1 = (span > 256) & (span <= 4096)
+    assert info["class_n"][1] == int(np.sum(c1 & (flag < 4096))) and info["class_n"][1] > 0
+    assert info["class_n"][2] == int(np.sum((span > 4096) & (span <= 65536))) + int(np.sum(c1 & (flag >= 4096)))
+    assert int(np.sum(c1 & (flag >= 4096))) > 0
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], end, flag, cols["mapq"], cols["tlen"])
+    rg = synth_ranges(400, 3000, cols["ref_len"], seed=78, jitter=2000)
+    for a in (dict(binsize=1, ss=True, requiredF=0x1000), dict(binsize=1, filteredF=0x8010), dict(binsize=-1, requiredF=0x9000, ss=True),
+              dict(binsize=13, requiredF=66, filteredF=0x4000, tlen_filter=(0, 900), pe_mid=True, shift=7)):
+        got, _ = _gpu(ctx, reads, rg, "pileup", **dict(a))
+        want, _ = oracle_c.pileup_core(orc, rg, **a)
+        assert got.any() and np.array_equal(got, want), a
+    for a in (dict(requiredF=0x2000), dict(filteredF=0x1400, requiredF=66, tlen_filter=(0, 1000), tspan=True)):
+        got, _ = _gpu(ctx, reads, rg, "coverage", **dict(a))
+        want, _ = oracle_c.coverage_core(orc, rg, **a)
+        assert np.array_equal(got, want), a
+    reads.close()
+
+
+
 @pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
 def test_pileup_vs_oracle(ctx, synth, which, cases):
     from oracle import oracle_c
