@@ -278,7 +278,7 @@ static_assert(sizeof(LaneSlot) % 8 == 4, "LaneSlot must be an odd number of dwor
 // more waves on the chip, which hides that latency and wastes less on lanes that wait for the
 // longest code or match of their wave.
 template <int LANES>
-__global__ __launch_bounds__(LANES) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
+__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
                                                    int64_t n, uint8_t *__restrict__ out, uint8_t *__restrict__ lens,
                                                    int *__restrict__ status)
 {
@@ -329,16 +329,21 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
                           int *crc_status = nullptr)
 {
     if (n <= 0) return hipSuccess;
-    // resident lanes per CU = min(160 KB / 940 B of tables = 174, 8 waves (182 VGPRs) x LANES) in whole
-    // workgroups: 32 lanes per wave -> five 30-KB workgroups = 160 lanes (16: 128, 64: two 60-KB = 128)
+    // resident lanes per CU = min(160 KB / 548 B of first-level tables = 298, 8 waves (182 VGPRs) x LANES) in
+    // whole workgroups: 32 lanes per wave -> eight 17.5-KB workgroups = 256 lanes (160 while the sorted symbols
+    // and the construction scratch lived in LDS too: 964 B per lane)
     int lanes = 32;
     if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
+    // (tuning: extra LDS bytes per lane that nobody uses, to run the kernel at a lower occupancy -- 416 gives
+    // the 160 lanes per CU of the layout that kept the sorted symbols in LDS)
+    size_t lds_pad = 0;
+    if (const char *e = getenv("BAMSIGNALS_INFLATE_LDS_PAD")) lds_pad = (size_t)std::max(0, atoi(e));
     switch (lanes) {
-    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
-    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3((unsigned)((n + 31) / 32)), dim3(32), 32 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
-    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3((unsigned)((n + 15) / 16)), dim3(16), 16 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
-    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(4), 4 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
-    default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(8), 8 * sizeof(LaneSlot), st, comp, jobs, n, out, lens, status); break;
+    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
+    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3((unsigned)((n + 31) / 32)), dim3(32), 32 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
+    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3((unsigned)((n + 15) / 16)), dim3(16), 16 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
+    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(4), 4 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
+    default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(8), 8 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
     }
     if (crc_tables && crc_st) {
         hipError_t e = hipEventRecord(inflated, st);

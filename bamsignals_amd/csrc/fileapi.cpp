@@ -2,6 +2,7 @@
 // the BAM writers.  Pure host code; the compute goes through bsig_reads_upload / bsig_plan_*.
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -9,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -31,9 +33,15 @@ struct bsig_bam {
     bsig::BaiIndex idx;
     bool from_csi = false;      // the index was read from a .csi file (htslib's bam_index_load accepts both, ref: :207)
     bsig::HostColumns cols;
+    std::string idx_err;
+    // file-level handles: the index is parsed by a helper thread.  LAST member: its destructor waits for that
+    // thread, which writes idx and idx_err above
+    std::shared_future<int> idx_job;
 };
 
 const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b);
+int bam_index_wait(const bsig_bam *b);
+namespace { int bam_open_impl(const char *path, bool lazy, bsig_bam **out); }
 
 namespace {
 
@@ -514,7 +522,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     }
     if (!ob) {
         bsig_bam *fresh = nullptr;
-        rc = bsig_bam_open(bampath, &fresh);
+        rc = bam_open_impl(bampath, true, &fresh);
         if (rc) return rc;
         ob = std::make_shared<OpenBam>();
         ob->key = bkey;
@@ -691,6 +699,8 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             // index-driven: only the blocks the BAI lists for the ranges (ref: one bam_itr_queryi per
             // chunk of ranges, :252-267), parsed on the GPU like the whole file.  With several GPUs the
             // islands are dealt to them and the column shares all-gathered (devdecode.hip).
+            rc = bam_index_wait(bam);                 // (parsed in the background since the open)
+            if (rc) return rc;
             rc = bsig::kNeedsCpuPath;
             how_decoded = "index-driven decode";
             if (many && !env_is("BAMSIGNALS_DEVICE_DECODE", "0") && !env_is("BAMSIGNALS_SHARDED_DECODE", "0")) {
@@ -745,6 +755,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (!many) rc = bsig_pileup_columns(slots->ctx[0], res->reads[0], n, rid.data(), loc.data(), width, strand, &prm, out, off);
     else rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, gather);
     T[3] = now_s() - t_run;
+    if (rc == BSIG_OK) rc = bam_index_wait(bam);      // a damaged index fails the call, as it does in the reference's open
     T[4] = now_s() - t_begin;
     snprintf(g_call_route, sizeof g_call_route, "%zu GPU slot(s); reads: %s; result: %s", nd, how_decoded.c_str(),
              many ? gather.c_str() : "download");
@@ -755,7 +766,64 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
 
 extern "C" {
 
-int bsig_bam_open(const char *path, bsig_bam **out)
+}  // extern "C"
+
+namespace {
+// the index files htslib's bam_index_load tries (ref: src/bamsignals.cpp:207), in its order: <bam>.bai,
+// <stem>.bai, <bam>.csi, <stem>.csi
+std::vector<std::pair<std::string, bool>> index_candidates(const std::string &bam)
+{
+    std::string stem = bam;
+    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".bam") == 0) stem.erase(stem.size() - 4);
+    std::vector<std::pair<std::string, bool>> c = {{bam + ".bai", false}};
+    if (stem != bam) c.push_back({stem + ".bai", false});
+    c.push_back({bam + ".csi", true});
+    if (stem != bam) c.push_back({stem + ".csi", true});
+    return c;
+}
+
+// parses the index of b (whichever candidate exists first); 0, or an error with its message in b->idx_err
+int load_index(bsig_bam *b)
+{
+    int rc = BSIG_ERR_NOINDEX;
+    for (const auto &cand : index_candidates(b->path)) {
+        struct stat sb;
+        if (stat(cand.first.c_str(), &sb) != 0) continue;
+        const int r = cand.second ? bsig::csi_load(cand.first, b->idx) : bsig::bai_load(cand.first, b->idx);
+        if (r == 0) { b->from_csi = cand.second; return 0; }
+        // a .csi that is not a CSI index is no index at all (a stale or foreign file of that name must not hide
+        // the reference's "not available"); a damaged BAI is reported as such
+        if (!cand.second && r != BSIG_ERR_NOINDEX) { b->idx_err = bsig_last_error(); return r; }
+        rc = cand.second ? rc : r;
+    }
+    b->idx_err = "BAM indexing file is not available for file " + b->path;
+    return BSIG_ERR_NOINDEX;
+}
+
+// does some index file with the right magic exist?  (cheap: the file-level calls parse the index in the
+// background and only need to know now whether the reference's "not available" error is due)
+bool index_present(const std::string &bam)
+{
+    for (const auto &cand : index_candidates(bam)) {
+        unsigned char magic[4] = {0, 0, 0, 0};
+        if (!cand.second) {
+            FILE *f = fopen(cand.first.c_str(), "rb");
+            if (!f) continue;
+            fclose(f);
+            return true;      // (a BAI of that name that is damaged: the parse reports it)
+        }
+        gzFile g = gzopen(cand.first.c_str(), "rb");
+        if (!g) continue;
+        const bool ok = gzread(g, magic, 4) == 4 && !memcmp(magic, "CSI\1", 4);
+        gzclose(g);
+        if (ok) return true;
+    }
+    return false;
+}
+
+// lazy: header now, index parsed by a helper thread (the north star's 10-MB BAI takes 35 ms; a whole-file
+// decode never looks at it).  bam_index_wait() joins and reports what the parse found.
+int bam_open_impl(const char *path, bool lazy, bsig_bam **out)
 {
     if (!path || !out) return fail(BSIG_ERR_ARG, "NULL argument to bsig_bam_open");
     *out = nullptr;
@@ -764,35 +832,48 @@ int bsig_bam_open(const char *path, bsig_bam **out)
     int rc = bsig::bam_read_header(b->path, b->hdr);
     if (rc == BSIG_ERR_IO) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path);
     if (rc) return rc;
-    rc = bsig::bai_load(b->path + ".bai", b->idx);
-    if (rc == BSIG_ERR_NOINDEX) {
-        // samtools also accepts foo.bai next to foo.bam
-        std::string alt = b->path;
-        if (alt.size() > 4 && alt.compare(alt.size() - 4, 4, ".bam") == 0) {
-            alt.replace(alt.size() - 4, 4, ".bai");
-            if (bsig::bai_load(alt, b->idx) == 0) rc = 0;
+    if (lazy && index_present(b->path)) {
+        bsig_bam *raw = b.get();
+        try {
+            b->idx_job = std::async(std::launch::async, [raw] { return load_index(raw); }).share();
+        } catch (const std::system_error &) {
+            lazy = false;                                  // no thread to be had: parse here
         }
-        if (rc) {
-            // htslib's bam_index_load (ref: src/bamsignals.cpp:207) also accepts a CSI index (references beyond
-            // 2^29 bp need one): <bam>.csi, then <stem>.csi.  A file of that name that does not inflate to a
-            // CSIv1 index is not an index: the reference's "not available" error stands
-            for (const std::string &cand : {b->path + ".csi", alt.size() > 4 ? alt.substr(0, alt.size() - 4) + ".csi" : std::string()}) {
-                if (cand.empty()) continue;
-                if (bsig::csi_load(cand, b->idx) == 0) { b->from_csi = true; rc = 0; break; }
-            }
-        }
-        if (rc) return fail(BSIG_ERR_NOINDEX, "BAM indexing file is not available for file %s", path);
+    } else {
+        lazy = false;
     }
-    if (rc) return rc;
+    if (!lazy) {
+        rc = load_index(b.get());
+        if (rc) return fail(rc, "%s", b->idx_err.c_str());
+    }
     *out = b.release();
     return BSIG_OK;
 }
+}  // namespace
+
+// the parsed index of an opened BAM (joins the background parse of the file-level calls' handles)
+int bam_index_wait(const bsig_bam *b)
+{
+    if (b->idx_job.valid()) {
+        const int rc = b->idx_job.get();
+        if (rc) return fail(rc, "%s", b->idx_err.c_str());
+    }
+    return BSIG_OK;
+}
+const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b)
+{
+    if (b->idx_job.valid()) b->idx_job.wait();
+    return &b->idx;
+}
+
+extern "C" {
+
+int bsig_bam_open(const char *path, bsig_bam **out) { return bam_open_impl(path, false, out); }
 
 void bsig_bam_close(bsig_bam *b) { delete b; }
 
 const char *bsig_bam_path(const bsig_bam *b) { return b ? b->path.c_str() : nullptr; }
 }  // extern "C"
-const bsig::BaiIndex *bsig_bam_index(const bsig_bam *b) { return &b->idx; }
 extern "C" {
 
 int32_t bsig_bam_n_ref(const bsig_bam *b) { return b ? (int32_t)b->hdr.names.size() : 0; }
@@ -821,6 +902,8 @@ int bsig_bam_decode(bsig_bam *b, int64_t n_regions, const int32_t *rid, const in
         if (n_regions > 0 && (!rid || !beg || !end)) return fail(BSIG_ERR_ARG, "region arrays missing");
         std::vector<bsig::Region> rg((size_t)n_regions);
         for (int64_t i = 0; i < n_regions; ++i) rg[(size_t)i] = bsig::Region{rid[i], beg[i], end[i]};
+        rc = bam_index_wait(b);
+        if (rc) return rc;
         rc = bsig::bam_decode_regions(b->path, b->idx, rg, threads, h, b->cols);
     }
     if (rc) return rc;

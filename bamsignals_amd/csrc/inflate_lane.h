@@ -37,10 +37,16 @@ constexpr int kLFast = BSIG_LFAST, kDFast = 5;   // first-level table bits (lite
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
-// per-lane working storage (LDS on the device): 964 bytes
+// per-lane working storage that nearly every symbol touches (LDS on the device): 544 bytes.  How many lanes
+// are resident is what sets the speed (every turn of a lane is a chain of dependent steps), and LDS is what
+// limits them: 160 lanes per CU with everything below in LDS (964 bytes), 256 with only these two tables.
 struct LaneTables {
     uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
     uint8_t dfast[1 << kDFast];    // distance: (symbol << 3) | code length (<= 5), 0 = longer code
+};
+// ... and what only the table construction and the walk for codes longer than the first-level tables
+// touch: it lives behind the code-length scratch (global memory on the device)
+struct ColdTables {
     uint32_t lhi[9];               // bit 8 of the literal/length symbols below
     uint16_t offs[16];             // scratch of the table construction
     uint16_t next[16];             // scratch: next canonical code of every length
@@ -252,7 +258,9 @@ BSIG_HD int cl_order(int k)
     return (int)((k < 12 ? lo >> (5 * k) : hi >> (5 * (k - 12))) & 31);
 }
 
-constexpr int kLensBytes = 352;   // scratch of inflate_block: 32 for the code-length code + 316 lengths
+constexpr int kLensCodes = 352;   // scratch of inflate_block: 32 for the code-length code + 316 lengths
+constexpr int kLensBytes = 784;   // ... + ColdTables (420 bytes) behind it; the scratch must be 4-byte aligned
+static_assert(kLensCodes % 4 == 0 && kLensCodes + (int)sizeof(ColdTables) <= kLensBytes, "scratch layout");
 
 // true once more bits were consumed than the input holds
 BSIG_HD bool overrun(const BitIn &in) { return in.p - (in.cnt >> 3) > in.end; }
@@ -269,7 +277,7 @@ BSIG_HD int dist_base(int s)    // distance symbols 0..29
 BSIG_HD int dist_extra(int s) { return s < 4 ? 0 : (s >> 1) - 1; }
 
 // Inflates one raw DEFLATE stream of in_len bytes into exactly out_len bytes (nothing behind
-// out + out_len is touched).  lens: kLensBytes of scratch (global memory on the device).
+// out + out_len is touched).  lens: kLensBytes of scratch, 4-byte aligned (global memory on the device).
 // Returns OK or an ERR_ code.
 BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, uint32_t out_len, LaneTables &T,
                           uint8_t *lens)
@@ -279,8 +287,9 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
     in.ahead = peek64(in.p, in.end);
     uint32_t op = 0;
     Counts lc, dc;
-    const LSyms ls{T.lsym, T.lhi};
-    const DSyms ds{T.dsym};
+    ColdTables &Cd = *reinterpret_cast<ColdTables *>(lens + kLensCodes);
+    const LSyms ls{Cd.lsym, Cd.lhi};
+    const DSyms ds{Cd.dsym};
     for (;;) {
         refill(in);
         const uint32_t last = take(in, 1);
@@ -306,8 +315,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
                 auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
                 auto fd = [](int) { return 5; };
-                construct<kLFast>(lc, Fast16{T.lfast}, ls, T.offs, T.next, 288, fl);
-                construct<kDFast>(dc, Fast8{T.dfast}, ds, T.offs, T.next, 30, fd);
+                construct<kLFast>(lc, Fast16{T.lfast}, ls, Cd.offs, Cd.next, 288, fl);
+                construct<kDFast>(dc, Fast8{T.dfast}, ds, Cd.offs, Cd.next, 30, fd);
             } else {
                 const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
                 if (nlen > 286 || ndist > 30) return ERR_TABLE;
@@ -319,7 +328,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 }
                 Counts cc;
                 // the code-length symbols are sorted into dsym (free until the distance code is built)
-                if (!construct<0>(cc, Fast8{nullptr}, ds, T.offs, T.next, 19, [&](int i) { return (int)lens[i]; }))
+                if (!construct<0>(cc, Fast8{nullptr}, ds, Cd.offs, Cd.next, 19, [&](int i) { return (int)lens[i]; }))
                     return ERR_TABLE;
                 // literal/length + distance code lengths, run-length coded
                 int idx = 0;
@@ -347,8 +356,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     if (overrun(in)) return ERR_INPUT;
                 }
                 if (ll[256] == 0) return ERR_TABLE;               // no end-of-block code
-                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, T.offs, T.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
-                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, T.offs, T.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
+                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, Cd.offs, Cd.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
+                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, Cd.offs, Cd.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
                     return ERR_TABLE;
             }
             // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.

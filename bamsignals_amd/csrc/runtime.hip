@@ -212,6 +212,13 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(BSIG_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    {
+        // the first hipMalloc of a process sets the runtime's allocator up (76 ms measured): that belongs to
+        // bringing the device up, not to whichever call happens to allocate first
+        void *warm = nullptr;
+        if (hipMalloc(&warm, 256) == hipSuccess) (void)hipFree(warm);
+        (void)hipGetLastError();
+    }
     bsig_ctx *c = new bsig_ctx;
     c->device = device;
     if (stream) {

@@ -132,6 +132,20 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
     return out, flat
 
 
+def _settle(path):
+    """A BAM the bench has just written is still dirty in the page cache; the timed calls are meant to see a
+    file that has been on disk for a while and is cached clean: flush it and read it once."""
+    for p in (path, path + ".bai"):
+        fd = os.open(p, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        finally:
+            os.close(fd)
+    with open(path, "rb") as fh:
+        while fh.read(64 << 20):
+            pass
+
+
 def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
     """Informational (NOT `value`): the file-level call bamProfile(bampath, gr) on the bench's own reads
     written to local disk as a BAM -- BGZF inflate, records -> columns, HBM layout, kernels, result in
@@ -151,6 +165,7 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         names = ["ref%d" % (i + 1) for i in range(len(cfg["ref_len"]))]
         bam = os.path.join(d, "synth.bam")
         t0 = time.perf_counter(); write_columns_as_bam(bam, names, cols, level=1); t_write = time.perf_counter() - t0
+        _settle(bam)
         cols.pop("cigar"); cols.pop("cigar_off")
         log(f"end_to_end: wrote {os.path.getsize(bam) / 1e6:.0f} MB BAM in {t_write:.1f} s")
         call = dict(tlen_filter=args.get("tlen_filter", ()), mapqual=args.get("mapqual", 0), binsize=args.get("binsize", 1),
@@ -222,11 +237,9 @@ def end_to_end_realistic(seed, device, oracle_c):
         out = dict(bam_bytes=os.path.getsize(bam), reads=n_reads, record_bytes=108 + l_seq - 4, write_bam_s=t_write,
                    workload=f"bamProfile binsize=1, 10k x 2kb ranges, {n_reads:.0e} SE {l_seq}-bp reads with names, bases, qualities")
         bases = int(rg["len"].astype(np.int64).sum())
-        # every engine sees the file in the same state: read it once so that the page cache is settled (the
-        # first of three otherwise identical cold calls paid 0.08 s more in its block scan)
-        with open(bam, "rb") as fh:
-            while fh.read(64 << 20):
-                pass
+        # every engine sees the file in the same state (the first of three otherwise identical cold calls paid
+        # 0.08-0.14 s more in its block scan while the freshly written pages were still under write-back)
+        _settle(bam)
         call = dict(tlen_filter=(), device=device)
         for eng in ("default", "gpu", "cpu"):
             env = {} if eng == "default" else {"BAMSIGNALS_INFLATE": eng}

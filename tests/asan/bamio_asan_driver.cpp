@@ -98,7 +98,7 @@ int main(int argc, char **argv)
         std::vector<uint8_t> out(isize);
         std::vector<uint8_t> exact(in);
         bsig_inflate::LaneTables tables;
-        uint8_t lens[bsig_inflate::kLensBytes];
+        alignas(8) uint8_t lens[bsig_inflate::kLensBytes];
         const int rc = bsig_inflate::inflate_block(exact.data(), (uint32_t)exact.size(), out.data(), isize, tables, lens);
         unsigned long sum = 0;
         if (!rc) for (uint8_t b : out) sum += b;

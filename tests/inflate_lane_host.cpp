@@ -6,6 +6,6 @@
 extern "C" int inflate_lane_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len)
 {
     bsig_inflate::LaneTables tables;
-    uint8_t lens[bsig_inflate::kLensBytes];
+    alignas(8) uint8_t lens[bsig_inflate::kLensBytes];
     return bsig_inflate::inflate_block(in, in_len, out, out_len, tables, lens);
 }
