@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ view, 
 // its verdict lands in `crc_status`, which the caller reads once crc_st has drained.
 hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n, uint8_t *out, uint8_t *lens, int *status,
                           const uint32_t *crc_tables, hipStream_t st, hipStream_t crc_st = nullptr, hipEvent_t inflated = nullptr,
-                          int *crc_status = nullptr)
+                          int *crc_status = nullptr, hipEvent_t crc_done = nullptr)
 {
     if (n <= 0) return hipSuccess;
     // resident lanes per CU = min(160 KB / 548 B of first-level tables = 298, 8 waves (182 VGPRs) x LANES) in
@@ -350,6 +350,10 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
         if (e == hipSuccess) e = hipStreamWaitEvent(crc_st, inflated, 0);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, crc_st, out, jobs, n, crc_tables, crc_status);
+        if (crc_done) {
+            e = hipEventRecord(crc_done, crc_st);
+            if (e != hipSuccess) return e;
+        }
     } else if (crc_tables) {
         hipLaunchKernelGGL(k_crc32, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, out, jobs, n, crc_tables, status);
     }
@@ -672,9 +676,12 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     hipStream_t st = ctx->stream;
     R.tmp.reset(new ScratchPool(ctx->device, st));
     ScratchPool &tmp = *R.tmp;
-    uint8_t *d_view = nullptr;
-    HIP_TRY(tmp.alloc(&d_view, (size_t)(carry_cap + std::min(share_bytes, chunk_cap)) + kOverlapBlocks * 65536u + 64));
-    uint8_t *const d_data = d_view + carry_cap;        // where every chunk's own bytes begin
+    // the view of the uncompressed stream [carry | chunk]; with the GPU inflating and several passes there are
+    // TWO, so that pass j + 1 is inflated (its own stream) while pass j is walked and extracted
+    uint8_t *d_view2[2] = {nullptr, nullptr};
+    const size_t view_bytes = (size_t)(carry_cap + std::min(share_bytes, chunk_cap)) + kOverlapBlocks * 65536u + 64;
+    HIP_TRY(tmp.alloc(&d_view2[0], view_bytes));
+    d_view2[1] = d_view2[0];
     int32_t *d_ref_len = nullptr;
     HIP_TRY(tmp.alloc(&d_ref_len, (size_t)std::max(n_ref, 1)));
     HIP_TRY(tmp.alloc(&R.d_ref_first, (size_t)n_ref + 1));
@@ -693,17 +700,26 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         ++n_pass;
         b = e;
     }
-    uint8_t *d_lens = nullptr;
-    InflateJob *d_jobs = nullptr;
+    uint8_t *d_lens2[2] = {nullptr, nullptr};
+    InflateJob *d_jobs2[2] = {nullptr, nullptr};
     int *d_status = nullptr;
     uint32_t *d_crc_tables = nullptr;
     uint8_t *d_comp2[2] = {nullptr, nullptr};
-    std::vector<InflateJob> jobs;
+    std::vector<InflateJob> jobs2[2];
     std::vector<uint64_t> in_off;
+    int status2[2] = {0, 0};
+    const bool two_views = gpu_inflate && n_pass > 1 && !getenv("BAMSIGNALS_ONE_VIEW");
+    if (two_views) HIP_TRY(tmp.alloc(&d_view2[1], view_bytes));
+    uint8_t *const d_data2[2] = {d_view2[0] + carry_cap, d_view2[1] + carry_cap};     // where every chunk's own bytes begin
     if (gpu_inflate) {
         HIP_TRY(tmp.alloc(&d_comp2[0], (size_t)max_comp + 64));
-        HIP_TRY(tmp.alloc(&d_lens, max_blk * (size_t)bsig_inflate::kLensBytes));
-        HIP_TRY(tmp.alloc(&d_jobs, max_blk));
+        HIP_TRY(tmp.alloc(&d_lens2[0], max_blk * (size_t)bsig_inflate::kLensBytes));
+        HIP_TRY(tmp.alloc(&d_jobs2[0], max_blk));
+        d_lens2[1] = d_lens2[0]; d_jobs2[1] = d_jobs2[0];
+        if (two_views) {
+            HIP_TRY(tmp.alloc(&d_lens2[1], max_blk * (size_t)bsig_inflate::kLensBytes));
+            HIP_TRY(tmp.alloc(&d_jobs2[1], max_blk));
+        }
         HIP_TRY(tmp.alloc(&d_status, 4));
         HIP_TRY(hipMemsetAsync(d_status, 0, 4 * sizeof(int), st));
         if (crc_check_enabled()) {
@@ -743,16 +759,25 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     // the CRC check of a pass runs on its own stream beside the record walk and extraction of that pass
     struct CrcSide {
         hipStream_t st = nullptr;
-        hipEvent_t inflated = nullptr;
+        hipStream_t inf = nullptr;               // k_inflate's own stream (beside the walk / extraction on `st`)
+        hipEvent_t inflated[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
         ~CrcSide()
         {
+            if (inf) { (void)hipStreamSynchronize(inf); (void)hipStreamDestroy(inf); }
             if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-            if (inflated) (void)hipEventDestroy(inflated);
+            for (int k = 0; k < 2; ++k) {
+                if (inflated[k]) (void)hipEventDestroy(inflated[k]);
+                if (done[k]) (void)hipEventDestroy(done[k]);
+            }
         }
     } crc;
+    if (gpu_inflate) HIP_TRY(hipStreamCreateWithFlags(&crc.inf, hipStreamNonBlocking));
     if (gpu_inflate && d_crc_tables) {
         HIP_TRY(hipStreamCreateWithFlags(&crc.st, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&crc.inflated, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&crc.inflated[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&crc.done[k], hipEventDisableTiming));
+        }
     }
     bool crc_pending = false;
     int pass = 0;
@@ -771,12 +796,19 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     if (gpu_inflate) start_prefetch(Bbeg, 0);
 
     // a failure from here on must drain the stream before the buffers go away
-    auto decline = [&]() { pf.join(); (void)hipStreamSynchronize(st); if (crc.st) (void)hipStreamSynchronize(crc.st); return kNeedsCpuPath; };
+    auto decline = [&]() {
+        pf.join();
+        if (crc.inf) (void)hipStreamSynchronize(crc.inf);
+        (void)hipStreamSynchronize(st);
+        if (crc.st) (void)hipStreamSynchronize(crc.st);
+        return kNeedsCpuPath;
+    };
 #define DD_TRY(expr)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
             pf.join();                                                                             \
+            if (crc.inf) (void)hipStreamSynchronize(crc.inf);                                      \
             (void)hipStreamSynchronize(st);                                                        \
             if (crc.st) (void)hipStreamSynchronize(crc.st);                                        \
             return fail(e_ == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE,              \
@@ -786,6 +818,9 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
 
     int32_t last_rid = -1, last_pos = -1;
     uint64_t tail = 0;                         // bytes carried in front of d_data
+    uint8_t *d_data = d_data2[0];              // this pass's view ...
+    uint8_t *d_next = d_data2[0];              // ... and the next one's (the cut-off record is carried in front of it)
+    int cur_q = 0;                             // which of the two views / event pairs this pass uses
     int half = 0;
     bool used[2] = {false, false};
     bool first_chunk = true;
@@ -830,36 +865,70 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
                 if (header_end < 0) return decline();
                 std::vector<uint8_t>().swap(head);
             }
-            // this pass's compressed bytes (requested before the previous pass was worked on)
-            const double tj = now_s();
-            pf.join();
-            R.t_wait += now_s() - tj;
-            if (pf.rc) DD_TRY((hipError_t)pf.rc);
-            if (pf.B0 != B0 || pf.B1 != Bv) return decline();
-            in_off.swap(pf.in_off);
-            // (the helper's own time -- packing into the page-locked halves, waiting for a half to be free -- runs
-            // beside the GPU work of the previous pass; only the join above is time this call waited)
-            if (getenv("BSIG_DIAG_DECODE"))
-                fprintf(stderr, "pass %d: %zu blocks, waited %.1f ms for its compressed bytes (helper: pack %.1f ms, half-wait %.1f ms)\n", pass,
-                        Bv - B0, (now_s() - tj) * 1e3, pf.t_host * 1e3, pf.t_wait * 1e3);
-            pf.t_host = pf.t_wait = 0;
-            const uint8_t *d_comp_now = d_comp2[pass & 1];
-            if (B1 < Bend) start_prefetch(B1, (pass + 1) & 1);
-            ++pass;
-            jobs.resize(Bv - B0);
-            for (size_t k = B0; k < Bv; ++k)
-                jobs[k - B0] = InflateJob{in_off[k - B0], uoff[k] - uoff[B0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
+            // The pipeline: pass j is walked and extracted on `st` while pass j + 1 is inflated on its own stream
+            // into the other view (the walk keeps about two waves per CU busy, the inflate lanes about one per
+            // SIMD: they fit beside each other) and pass j + 2's compressed bytes cross PCIe (helper thread).
+            // join_bytes: this call waits for a pass's compressed bytes; issue: queue its inflate (+ CRC) and the
+            // read-back of the status word, nothing is waited for.
+            auto join_bytes = [&](size_t b0, size_t bv, int p) -> int {
+                const double tj = now_s();
+                pf.join();
+                R.t_wait += now_s() - tj;
+                if (pf.rc) return pf.rc < 0 ? pf.rc : fail(BSIG_ERR_DEVICE, "copying the compressed bytes failed (HIP error %d)", pf.rc);
+                if (pf.B0 != b0 || pf.B1 != bv) return kNeedsCpuPath;
+                in_off.swap(pf.in_off);
+                // (the helper's own time -- packing into the page-locked halves, waiting for a half to be free -- runs
+                // beside the GPU work of the previous pass; only the join above is time this call waited)
+                if (getenv("BSIG_DIAG_DECODE"))
+                    fprintf(stderr, "pass %d: %zu blocks, waited %.1f ms for its compressed bytes (helper: pack %.1f ms, half-wait %.1f ms)\n", p,
+                            bv - b0, (now_s() - tj) * 1e3, pf.t_host * 1e3, pf.t_wait * 1e3);
+                pf.t_host = pf.t_wait = 0;
+                return BSIG_OK;
+            };
+            auto issue_inflate = [&](size_t b0, size_t bv, int p) -> hipError_t {
+                const int q = two_views ? (p & 1) : 0;
+                std::vector<InflateJob> &jobs = jobs2[q];
+                jobs.resize(bv - b0);
+                for (size_t k = b0; k < bv; ++k)
+                    jobs[k - b0] = InflateJob{in_off[k - b0], uoff[k] - uoff[b0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
+                hipError_t e = hipMemcpyAsync(d_jobs2[q], jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, crc.inf);
+                if (e == hipSuccess)
+                    e = launch_inflate(d_comp2[p & 1], d_jobs2[q], (int64_t)jobs.size(), d_data2[q], d_lens2[q], d_status, d_crc_tables, crc.inf,
+                                       crc.st, crc.inflated[q], d_status + 1, crc.done[q]);
+                if (e == hipSuccess) e = hipMemcpyAsync(&status2[q], d_status, sizeof(int), hipMemcpyDeviceToHost, crc.inf);
+                return e;
+            };
+            if (pass == 0) {
+                // (the set-up copies and fills queued on `st` above must have landed before another stream reads them)
+                DD_TRY(hipStreamSynchronize(st));
+                rc = join_bytes(B0, Bv, 0);
+                if (rc == kNeedsCpuPath) return decline();
+                if (rc) { (void)decline(); return rc; }
+                if (B1 < Bend) start_prefetch(B1, 1);
+                DD_TRY(issue_inflate(B0, Bv, 0));
+            }
+            else if (!two_views) DD_TRY(issue_inflate(B0, Bv, pass));      // one view: nothing could run ahead
+            const int q = two_views ? (pass & 1) : 0;
+            cur_q = q;
             const double t0 = now_s();
-            DD_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, st));
-            DD_TRY(launch_inflate(d_comp_now, d_jobs, (int64_t)jobs.size(), d_data, d_lens, d_status, d_crc_tables, st, crc.st,
-                                  crc.inflated, d_status + 1));
-            crc_pending = crc.st != nullptr;
-            int status = 0;
-            DD_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
-            DD_TRY(hipStreamSynchronize(st));
+            DD_TRY(hipStreamSynchronize(crc.inf));             // this pass's view is complete
             R.t_inflate += now_s() - t0;
-            if (getenv("BSIG_DIAG_INFLATE") || getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "k_inflate + sync: %.2f ms for %zu blocks (status %d)\n", (now_s() - t0) * 1e3, jobs.size(), status);
-            if (status) return decline();      // a damaged block: the CPU path reports it
+            if (getenv("BSIG_DIAG_INFLATE") || getenv("BSIG_DIAG_DECODE"))
+                fprintf(stderr, "pass %d: waited %.2f ms for k_inflate of %zu blocks (status %d)\n", pass, (now_s() - t0) * 1e3, Bv - B0, status2[q]);
+            if (status2[q]) return decline();      // a damaged block: the CPU path reports it
+            crc_pending = crc.st != nullptr;
+            if (B1 < Bend) {
+                // the next pass: its bytes (requested a pass ago), then its inflate beside this pass's walk
+                const size_t nB1 = chunk_end(B1), nBv = view_end(nB1);
+                rc = join_bytes(B1, nBv, pass + 1);
+                if (rc == kNeedsCpuPath) return decline();
+                if (rc) { (void)decline(); return rc; }
+                if (nB1 < Bend) start_prefetch(nB1, pass & 1);             // (inflate of this pass is done with that buffer)
+                if (two_views) DD_TRY(issue_inflate(B1, nBv, pass + 1));
+            }
+            d_data = d_data2[q];
+            d_next = d_data2[two_views ? ((pass + 1) & 1) : 0];
+            ++pass;
         } else {
         // ---- inflate (CPU thread pool) into page-locked halves, copy to HBM behind it ------------
         for (size_t b0 = B0; b0 < Bv;) {
@@ -982,14 +1051,14 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         }
         // the cut-off record moves in front of the next chunk (source and destination do not overlap:
         // it starts inside this chunk's own bytes)
-        if (new_tail) DD_TRY(hipMemcpyAsync(d_data - new_tail, d_stream + o, (size_t)new_tail, hipMemcpyDeviceToDevice, st));
+        if (new_tail) DD_TRY(hipMemcpyAsync(d_next - new_tail, d_stream + o, (size_t)new_tail, hipMemcpyDeviceToDevice, st));
         // the host arrays of this chunk are reused: the copies above must have left them
         DD_TRY(hipStreamSynchronize(st));
         if (crc_pending) {
             // the blocks' CRCs were checked meanwhile: a mismatch sends the call down the CPU path, which
             // reports it (nothing of this share is used then)
             int bad = 0;
-            DD_TRY(hipStreamSynchronize(crc.st));
+            DD_TRY(hipEventSynchronize(crc.done[cur_q]));          // (this pass's CRC kernel; the next pass's may be queued behind it)
             DD_TRY(hipMemcpyAsync(&bad, d_status + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             DD_TRY(hipStreamSynchronize(st));
             if (bad) return decline();
