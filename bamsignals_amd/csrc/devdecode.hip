@@ -372,8 +372,11 @@ struct Staging {
     uint8_t *buf[2] = {nullptr, nullptr};
     size_t cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    int *h_flags = nullptr;      // a few page-locked words: status read-backs that must not block the host (a
+                                 // device-to-host copy into pageable memory waits for everything queued before it)
     int ensure(size_t bytes)
     {
+        if (!h_flags) HIP_TRY(hipHostMalloc((void **)&h_flags, 16 * sizeof(int), hipHostMallocDefault));
         if (cap >= bytes) return BSIG_OK;
         for (int k = 0; k < 2; ++k) {
             if (buf[k]) (void)hipHostFree(buf[k]);
@@ -497,7 +500,7 @@ namespace bsig {
 // Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so.  Both engines'
 // times follow the COMPRESSED size (the number of Huffman symbols): the CPU pool needs 0.13-0.2 ms per
 // MB with 32 threads (libdeflate; 300 MB of 52-byte records and 315 MB of sequence-bearing records
-// both take ~41 ms), k_inflate 1.9-2.3 ms per KB of the average block per round of 40,960 resident
+// both take ~41 ms), k_inflate 1.2-2.3 ms per KB of the average block per round of 73,728 resident
 // lanes -- every lane walks its block's symbols one after the other -- plus the trip of the
 // compressed bytes.  Few or badly compressible blocks: CPU; many: GPU.
 inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, int threads)
@@ -505,7 +508,7 @@ inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, int threads)
     if (n_blocks == 0) return false;
     const double comp_mb = (double)comp_bytes / (1 << 20);
     const double t_cpu = comp_mb * 0.15 * 32.0 / (double)std::max(1, bsig::decode_threads(threads));
-    const double rounds = (double)((n_blocks + 40959) / 40960);
+    const double rounds = (double)((n_blocks + 73727) / 73728);
     const double t_gpu = rounds * ((double)comp_bytes / (double)n_blocks / 1024.0) * 2.4 + comp_mb * 0.03 + 0.3;
     return t_gpu < t_cpu;
 }
@@ -707,7 +710,6 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     uint8_t *d_comp2[2] = {nullptr, nullptr};
     std::vector<InflateJob> jobs2[2];
     std::vector<uint64_t> in_off;
-    int status2[2] = {0, 0};
     const bool two_views = gpu_inflate && n_pass > 1 && !getenv("BAMSIGNALS_ONE_VIEW");
     if (two_views) HIP_TRY(tmp.alloc(&d_view2[1], view_bytes));
     uint8_t *const d_data2[2] = {d_view2[0] + carry_cap, d_view2[1] + carry_cap};     // where every chunk's own bytes begin
@@ -736,6 +738,8 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     int rc = S.ensure(batch_bytes);
     if (rc) return rc;
     diag_mark("  page-locked staging");
+    volatile int *status2 = S.h_flags;           // [q]: k_inflate's status word of the pass in view q
+    status2[0] = status2[1] = 0;
 
     // With the GPU inflating, the compressed bytes of pass j + 1 are packed and copied (helper thread,
     // its own stream, the other buffer) while the GPU inflates and parses pass j.
@@ -895,7 +899,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
                 if (e == hipSuccess)
                     e = launch_inflate(d_comp2[p & 1], d_jobs2[q], (int64_t)jobs.size(), d_data2[q], d_lens2[q], d_status, d_crc_tables, crc.inf,
                                        crc.st, crc.inflated[q], d_status + 1, crc.done[q]);
-                if (e == hipSuccess) e = hipMemcpyAsync(&status2[q], d_status, sizeof(int), hipMemcpyDeviceToHost, crc.inf);
+                if (e == hipSuccess) e = hipMemcpyAsync((void *)&status2[q], d_status, sizeof(int), hipMemcpyDeviceToHost, crc.inf);
                 return e;
             };
             if (pass == 0) {
