@@ -679,8 +679,11 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     hipStream_t st = ctx->stream;
     R.tmp.reset(new ScratchPool(ctx->device, st));
     ScratchPool &tmp = *R.tmp;
-    // the view of the uncompressed stream [carry | chunk]; with the GPU inflating and several passes there are
-    // TWO, so that pass j + 1 is inflated (its own stream) while pass j is walked and extracted
+    // the view of the uncompressed stream [carry | chunk].  env BAMSIGNALS_TWO_VIEWS=1 (GPU inflate, several
+    // passes): a second one, so that pass j + 1 is inflated on its own stream while pass j is walked and
+    // extracted.  Built, tested and measured at the north star's file -- and left off: k_inflate's waves hold
+    // 504 of a SIMD's 512 VGPRs, so the walk and the extraction only find room when inflate waves retire; both
+    // kernels get slower by about what the overlap hides (decode 0.287 s with two views, 0.271 s with one).
     uint8_t *d_view2[2] = {nullptr, nullptr};
     const size_t view_bytes = (size_t)(carry_cap + std::min(share_bytes, chunk_cap)) + kOverlapBlocks * 65536u + 64;
     HIP_TRY(tmp.alloc(&d_view2[0], view_bytes));
@@ -710,7 +713,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     uint8_t *d_comp2[2] = {nullptr, nullptr};
     std::vector<InflateJob> jobs2[2];
     std::vector<uint64_t> in_off;
-    const bool two_views = gpu_inflate && n_pass > 1 && !getenv("BAMSIGNALS_ONE_VIEW");
+    const bool two_views = gpu_inflate && n_pass > 1 && getenv("BAMSIGNALS_TWO_VIEWS") && !strcmp(getenv("BAMSIGNALS_TWO_VIEWS"), "1");
     if (two_views) HIP_TRY(tmp.alloc(&d_view2[1], view_bytes));
     uint8_t *const d_data2[2] = {d_view2[0] + carry_cap, d_view2[1] + carry_cap};     // where every chunk's own bytes begin
     if (gpu_inflate) {
@@ -869,9 +872,9 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
                 if (header_end < 0) return decline();
                 std::vector<uint8_t>().swap(head);
             }
-            // The pipeline: pass j is walked and extracted on `st` while pass j + 1 is inflated on its own stream
-            // into the other view (the walk keeps about two waves per CU busy, the inflate lanes about one per
-            // SIMD: they fit beside each other) and pass j + 2's compressed bytes cross PCIe (helper thread).
+            // The pipeline: pass j is inflated on its own stream, walked and extracted on `st`, while pass j + 1's
+            // compressed bytes cross PCIe (helper thread); with two views (see above) pass j + 1 is also inflated,
+            // into the other view, while pass j is walked.
             // join_bytes: this call waits for a pass's compressed bytes; issue: queue its inflate (+ CRC) and the
             // read-back of the status word, nothing is waited for.
             auto join_bytes = [&](size_t b0, size_t bv, int p) -> int {

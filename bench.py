@@ -817,7 +817,7 @@ def main():
         from oracle import oracle_c
         orc, parity = w.check_parity(oracle_c, a.seed)
         log(f"parity ok ({parity}); step {kernel_ms * 1e3:.1f} us")
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:          # (the contract: rank 0 at N = 1 only)
             # the oracle (C restatement of overlapAndPileup + Pileupper, single thread) on the
             # rank's whole workload, repeated until about 10 s have passed
             reps, t_cpu = 0, 0.0

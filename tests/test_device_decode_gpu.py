@@ -250,15 +250,20 @@ def test_records_crossing_block_borders_and_oversized_records(ctx, tmp_path, mon
     dev.close()
 
 
-@pytest.mark.parametrize("inflate", ["cpu", "gpu"])
+@pytest.mark.parametrize("inflate", ["cpu", "gpu", "gpu-two-views"])
 def test_stream_in_chunks(ctx, tmp_path, monkeypatch, inflate):
     """the uncompressed stream passes through HBM in chunks (8 GiB by default; 1 MiB here): the record
     cut off by a chunk border is carried in front of the next chunk.  With the GPU inflating, the
     compressed bytes of pass j + 1 are packed and copied by the helper thread into the other buffer
-    while pass j is worked on (every file here takes at least four passes)."""
+    while pass j is worked on (every file here takes at least four passes); with BAMSIGNALS_TWO_VIEWS=1
+    pass j + 1 is also inflated, into a second view, while pass j is walked (the carried record then
+    moves from one view into the other)."""
     from bamsignals_amd import write_columns_as_bam
     from bamsignals_amd.synth import synth_reads
     monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", "1")
+    if inflate == "gpu-two-views":
+        monkeypatch.setenv("BAMSIGNALS_TWO_VIEWS", "1")
+        inflate = "gpu"
     monkeypatch.setenv("BAMSIGNALS_INFLATE", inflate)
     monkeypatch.setenv("BAMSIGNALS_BATCH_BLOCKS", "5")
     stream = gzip.decompress(open(BAM, "rb").read())
