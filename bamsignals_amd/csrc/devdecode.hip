@@ -277,8 +277,12 @@ static_assert(sizeof(LaneSlot) % 8 == 4, "LaneSlot must be an odd number of dwor
 // a lane does is a chain of dependent steps (bits -> table -> bits ...): fewer blocks per wave put
 // more waves on the chip, which hides that latency and wastes less on lanes that wait for the
 // longest code or match of their wave.
+// (three waves per SIMD: 168 VGPRs instead of the 172 the compiler would take, which would stop at two)
+#ifndef BSIG_INFLATE_WAVES
+#define BSIG_INFLATE_WAVES 3
+#endif
 template <int LANES>
-__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
+__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(BSIG_INFLATE_WAVES, 8))) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
                                                    int64_t n, uint8_t *__restrict__ out, uint8_t *__restrict__ lens,
                                                    int *__restrict__ status)
 {
