@@ -609,6 +609,135 @@ static void populate_spans(const MappedFile &f, std::vector<std::pair<uint64_t, 
     });
 }
 
+// ---- the same header walk through pread() -------------------------------------------------------------
+// The device-side decode needs the block table, not the pages: walking the headers through the mapping
+// touches nearly every page of the file, and filling the page tables of a fresh 3-GB mapping costs 0.05-0.13 s
+// (more than the walk) although every byte is in the page cache.  pread() copies the few bytes the walk
+// looks at -- a block's trailer and the next block's header are neighbours: one 96-byte read per block --
+// and creates no mapping at all.  Same segments, same join rule as scan_blocks() below; any doubt (a segment
+// without a provable start, a chain that does not meet the next segment) returns false and the mapped walk,
+// which owns the error messages, runs instead.
+namespace {
+struct HeadReader {
+    int fd;
+    uint64_t size;
+    uint8_t buf[192];
+    uint64_t base = ~0ull;
+    size_t len = 0;
+    // the bytes [off, off + need) of the file, need <= 96; nullptr behind the end of the file
+    const uint8_t *at(uint64_t off, size_t need)
+    {
+        if (off + need > size) return nullptr;
+        if (base != ~0ull && off >= base && off + need <= base + len) return buf + (off - base);
+        const size_t want = (size_t)std::min<uint64_t>(sizeof buf, size - off);
+        size_t got = 0;
+        while (got < want) {
+            const ssize_t r = ::pread(fd, buf + got, want - got, (off_t)(off + got));
+            if (r <= 0) return nullptr;
+            got += (size_t)r;
+        }
+        base = off;
+        len = got;
+        return buf;
+    }
+};
+
+// parse_block() on bytes fetched with pread(); after a success the reader holds the next block's header
+bool parse_block_fd(HeadReader &r, uint64_t off, Block &b)
+{
+    const uint8_t *p = r.at(off, 18);
+    if (!p || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return false;
+    const uint32_t xlen = rd16(p + 10);
+    if (xlen > 64) return false;                         // (odd extra fields: the mapped walk handles them)
+    p = r.at(off, 12 + xlen);
+    if (!p) return false;
+    uint32_t bsize = 0;
+    bool found = false;
+    for (uint32_t x = 0; x + 4 <= xlen;) {
+        const uint8_t *s = p + 12 + x;
+        const uint32_t slen = rd16(s + 2);
+        if (s[0] == 'B' && s[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = rd16(s + 4); found = true; }
+        x += 4 + slen;
+    }
+    if (!found) return false;
+    b.coff = off;
+    b.csize = bsize + 1;
+    if (off + b.csize > r.size || b.csize < 12 + xlen + 8) return false;
+    b.doff = 12 + xlen;
+    b.dlen = b.csize - b.doff - 8;
+    // the trailer, together with the next block's header (what the next call asks for)
+    const uint64_t t = off + b.csize - 8;
+    const uint8_t *q = r.at(t, (size_t)std::min<uint64_t>(8 + 32, r.size - t));
+    if (!q) return false;
+    b.crc = rd32(q);
+    b.isize = rd32(q + 4);
+    return true;
+}
+}  // namespace
+
+static bool scan_blocks_pread(const MappedFile &f, std::vector<Block> &blocks)
+{
+    const int kHops = 4;
+    uint64_t seg_bytes = 8u << 20;
+    if (const char *e = getenv("BAMSIGNALS_SCAN_SEGMENT_KB")) {
+        const long v = atol(e);
+        if (v > 0) seg_bytes = (uint64_t)v << 10;
+    }
+    if (f.fd < 0 || f.size < 2 * seg_bytes) return false;
+    const size_t K = (size_t)std::min<uint64_t>(1024, f.size / seg_bytes);
+    std::vector<std::vector<Block>> part(K);
+    std::vector<uint64_t> first(K, 0), last_end(K, 0);
+    std::vector<char> ok(K, 0);
+    parallel_for((int64_t)K, std::min(n_threads(0), 32), [&](int64_t k, int) {
+        HeadReader r{f.fd, f.size};
+        const uint64_t cut = (uint64_t)k * (f.size / K), next_cut = k + 1 == (int64_t)K ? f.size : (uint64_t)(k + 1) * (f.size / K);
+        uint64_t start = cut;
+        if (k > 0) {
+            // the first offset behind the cut from which a chain of kHops valid headers follows
+            std::vector<uint8_t> win((size_t)std::min<uint64_t>(next_cut - cut + 2, 256u << 10));
+            size_t got = 0;
+            while (got < win.size()) {
+                const ssize_t n = ::pread(f.fd, win.data() + got, win.size() - got, (off_t)(cut + got));
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            bool found = false;
+            for (size_t i = 0; i + 1 < got && !found; ++i) {
+                if (win[i] != 31 || win[i + 1] != 139) continue;
+                uint64_t q = cut + i;
+                int hops = 0;
+                Block b;
+                while (hops < kHops && q < f.size && parse_block_fd(r, q, b)) { q += b.csize; ++hops; }
+                if (hops == kHops || (hops > 0 && q == f.size)) { start = cut + i; found = true; }
+            }
+            if (!found) return;
+        }
+        first[(size_t)k] = start;
+        uint64_t o = start;
+        std::vector<Block> &out = part[(size_t)k];
+        out.reserve((size_t)((next_cut - cut) / 4096 + 16));
+        while (o < next_cut) {
+            Block b;
+            if (!parse_block_fd(r, o, b)) return;
+            out.push_back(b);
+            o += b.csize;
+        }
+        last_end[(size_t)k] = o;
+        ok[(size_t)k] = 1;
+    });
+    for (size_t k = 0; k < K; ++k) {
+        if (!ok[k]) return false;
+        if (k + 1 < K && (!ok[k + 1] || last_end[k] != first[k + 1])) return false;
+        if (k + 1 == K && last_end[k] != f.size) return false;
+    }
+    size_t n = 0;
+    for (const auto &v : part) n += v.size();
+    blocks.clear();
+    blocks.reserve(n);
+    for (const auto &v : part) blocks.insert(blocks.end(), v.begin(), v.end());
+    return true;
+}
+
 static int scan_blocks(const MappedFile &f, const std::string &path, std::vector<Block> &blocks)
 {
     // The scan below touches one header per block, i.e. nearly every page of the mapping, one page
@@ -711,6 +840,11 @@ int BgzfFile::open(const std::string &path)
 {
     if (p_->f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
     p_->blocks.clear();
+    // (the device-side decode: the block table without touching the mapping; env BAMSIGNALS_SCAN=mmap: the walk
+    // through the populated mapping, which is also what any doubt falls back to)
+    const char *how = getenv("BAMSIGNALS_SCAN");
+    if (!(how && !strcmp(how, "mmap")) && scan_blocks_pread(p_->f, p_->blocks)) return 0;
+    p_->blocks.clear();
     return scan_blocks(p_->f, path, p_->blocks);
 }
 int BgzfFile::map(const std::string &path)
@@ -721,6 +855,17 @@ int BgzfFile::map(const std::string &path)
 }
 bool BgzfFile::block_at(uint64_t off, BgzfBlock &b) const { return parse_block(p_->f, off, b); }
 void BgzfFile::populate(const std::vector<std::pair<uint64_t, uint64_t>> &spans) const { populate_spans(p_->f, spans); }
+bool BgzfFile::read_span(uint64_t off, size_t len, uint8_t *dst) const
+{
+    if (p_->f.fd < 0 || off + len > p_->f.size) return false;
+    size_t got = 0;
+    while (got < len) {
+        const ssize_t r = ::pread(p_->f.fd, dst + got, len - got, (off_t)(off + got));
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
+    return true;
+}
 int BgzfFile::inflate_list(const BgzfBlock *list, size_t n, uint8_t *dst, int threads) const
 {
     if (n == 0) return 0;

@@ -103,6 +103,8 @@ public:
     int inflate(size_t b0, size_t b1, uint8_t *dst, int threads) const;
     // maps the pages of these byte spans of the file in (several threads) before they are read
     void populate(const std::vector<std::pair<uint64_t, uint64_t>> &spans) const;
+    // copies file bytes [off, off + len) to dst with pread(): page cache -> dst without touching the mapping
+    bool read_span(uint64_t off, size_t len, uint8_t *dst) const;
     // the block whose header sits at file offset `off`; false if there is none / it is malformed
     bool block_at(uint64_t off, BgzfBlock &b) const;
     // inflates the listed blocks back to back into dst

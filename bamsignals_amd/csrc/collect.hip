@@ -300,6 +300,13 @@ __global__ __launch_bounds__(256) void k_place_segments(int64_t n, const int32_t
 }
 }  // namespace
 
+namespace { __global__ void k_warm_collect() {} }
+hipError_t warm_collect_module(hipStream_t st)
+{
+    hipLaunchKernelGGL(k_warm_collect, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+
 hipError_t launch_place_segments(int64_t n, const int32_t *src, const int64_t *src_off, int32_t *dst,
                                  const int64_t *dst_off, const int64_t *which, hipStream_t st)
 {

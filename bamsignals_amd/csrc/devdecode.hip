@@ -25,6 +25,7 @@
 // Results are identical by construction and by tests/test_device_decode_gpu.py.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -457,17 +458,28 @@ int copy_deflate_data(Staging &S, const bsig::BgzfFile &f, const bsig::BgzfBlock
                       int threads, size_t batch_bytes, int &half, bool (&used)[2], std::vector<uint64_t> &in_off,
                       double &t_host, double &t_wait)
 {
+    // The blocks' bytes reach the page-locked halves with pread() -- page cache -> staging, no mapping involved
+    // (filling the page tables of a fresh mapping of the north star's 3-GB file costs 0.05-0.13 s) -- as RAW
+    // runs of consecutive blocks, headers and trailers included (26 bytes per block of ~9 KB): a run is one
+    // read instead of one memcpy per block, and in_off simply points behind each block's header.  Blocks that
+    // are not consecutive in the file (index-driven decodes: islands) start a new run.
     in_off.resize(n);
     uint64_t packed = 0;
-    std::vector<uint32_t> at;
+    struct Run { uint64_t file_off; size_t len; size_t at; };
+    std::vector<Run> runs;
     for (size_t b0 = 0; b0 < n;) {
         size_t b1 = b0;
         uint64_t bytes = 0;
-        at.clear();
-        while (b1 < n && (b1 == b0 || bytes + list[b1].dlen <= batch_bytes)) {
-            at.push_back((uint32_t)bytes);
-            in_off[b1] = packed + bytes;
-            bytes += list[b1++].dlen;
+        runs.clear();
+        const size_t per_run = 1u << 20;                         // a task reads about this much
+        while (b1 < n && (b1 == b0 || bytes + list[b1].csize <= batch_bytes)) {
+            const bsig::BgzfBlock &bk = list[b1];
+            if (runs.empty() || runs.back().file_off + runs.back().len != bk.coff || runs.back().len >= per_run)
+                runs.push_back(Run{bk.coff, 0, (size_t)bytes});
+            in_off[b1] = packed + bytes + bk.doff;
+            runs.back().len += bk.csize;
+            bytes += bk.csize;
+            ++b1;
         }
         if (bytes > S.cap) return (int)hipErrorInvalidValue;
         double t0 = now_s();
@@ -478,13 +490,12 @@ int copy_deflate_data(Staging &S, const bsig::BgzfFile &f, const bsig::BgzfBlock
         t_wait += now_s() - t0;
         t0 = now_s();
         uint8_t *dst = S.buf[half];
-        const uint8_t *file = f.data();
-        const size_t per = 64;                                  // blocks per task
-        bsig::pool_for((int64_t)((b1 - b0 + per - 1) / per), threads, [&](int64_t q) {
-            const size_t k1 = std::min(b1, b0 + (size_t)(q + 1) * per);
-            for (size_t k = b0 + (size_t)q * per; k < k1; ++k)
-                memcpy(dst + at[k - b0], file + list[k].coff + list[k].doff, list[k].dlen);
+        std::atomic<int> bad(0);
+        bsig::pool_for((int64_t)runs.size(), threads, [&](int64_t q) {
+            const Run &r = runs[(size_t)q];
+            if (!f.read_span(r.file_off, r.len, dst + r.at)) bad.store(1);
         });
+        if (bad.load()) return (int)hipErrorInvalidValue;
         t_host += now_s() - t0;
         hipError_t e = bytes ? hipMemcpyAsync(d_comp + packed, dst, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
         if (e == hipSuccess) e = hipEventRecord(S.ev[half], st);
@@ -683,6 +694,10 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     hipStream_t st = ctx->stream;
     R.tmp.reset(new ScratchPool(ctx->device, st));
     ScratchPool &tmp = *R.tmp;
+    // (the CPU pool inflates out of the mapping: its pages are mapped in by several threads first -- the block
+    // table came through pread() and touched none; the GPU-inflate route never touches the mapping at all)
+    if (!gpu_inflate && Bend > Bbeg)
+        f.populate({{blocks[Bbeg].coff, blocks[view_end(Bend) - 1].coff + blocks[view_end(Bend) - 1].csize}});
     // the view of the uncompressed stream [carry | chunk].  env BAMSIGNALS_TWO_VIEWS=1 (GPU inflate, several
     // passes): a second one, so that pass j + 1 is inflated on its own stream while pass j is walked and
     // extracted.  Built, tested and measured at the north star's file -- and left off: k_inflate's waves hold
@@ -1551,7 +1566,7 @@ int decode_islands(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const
         }
         if (gpu_inflate) {
             uint64_t comp_bytes = 0;
-            for (const BgzfBlock &b : list) comp_bytes += b.dlen;
+            for (const BgzfBlock &b : list) comp_bytes += b.csize;          // (whole blocks travel: see copy_deflate_data)
             if (comp_bytes > max_group + 64 * (uint64_t)max_seg || list.size() > max_seg) return decline();
             DR_TRY((hipError_t)copy_deflate_data(S, f, list.data(), list.size(), d_comp, st, threads, batch_bytes, half, used, in_off,
                                                  t_inflate, t_wait));
@@ -1801,6 +1816,13 @@ int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::s
 }
 
 void release_decode_scratch() { block_cache_release(); }
+
+namespace { __global__ void k_warm_decode() {} }
+hipError_t warm_decode_module(hipStream_t st)
+{
+    hipLaunchKernelGGL(k_warm_decode, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
 
 }  // namespace bsig
 

@@ -1142,6 +1142,25 @@ void bsig_cache_clear(void)
     bsig::release_decode_scratch();
 }
 
+int bsig_debug_block_table(const char *path, int64_t *n_blocks, uint64_t *checksum)
+{
+    // the BGZF block table as the device-side decode builds it (env BAMSIGNALS_SCAN=mmap|pread picks the walk):
+    // tests compare the two walks
+    if (!path || !n_blocks || !checksum) return fail(BSIG_ERR_ARG, "NULL argument");
+    bsig::BgzfFile f;
+    const int rc = f.open(path);
+    if (rc) return rc;
+    uint64_t h = 1469598103934665603ull;
+    for (const bsig::BgzfBlock &b : f.blocks())
+        for (uint64_t v : {(uint64_t)b.coff, (uint64_t)b.csize, (uint64_t)b.doff, (uint64_t)b.dlen, (uint64_t)b.isize, (uint64_t)b.crc}) {
+            h ^= v;
+            h *= 1099511628211ull;
+        }
+    *n_blocks = (int64_t)f.blocks().size();
+    *checksum = h;
+    return BSIG_OK;
+}
+
 int64_t bsig_debug_scratch_allocs(void)
 {
     // allocations made so far for the multi-GPU result path's cached buffers (tests: flat across resident calls)

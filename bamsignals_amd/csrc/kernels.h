@@ -42,6 +42,7 @@ hipError_t launch_build_idx(int64_t n, const uint32_t *gb, uint64_t n_buckets, u
 hipError_t launch_checksum(const void *words, uint64_t n_words, uint64_t salt, unsigned long long *acc, hipStream_t st);
 // *bad (device) = 1 unless idx[0..n_buckets] is non-decreasing, <= n_reads, and ends at n_reads
 hipError_t launch_check_idx(const uint32_t *idx, uint64_t n_buckets, uint32_t n_reads, int *bad, hipStream_t st);
+hipError_t warm_pileup_module(hipStream_t st);
 hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
                          int64_t n_items, unsigned long long *acc, hipStream_t st);
 

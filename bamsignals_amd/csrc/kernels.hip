@@ -1133,6 +1133,14 @@ hipError_t launch_visits(const BsigReadsDev &R, const BsigKParams &P, int mode, 
 
 }  // namespace bsig
 
+namespace { __global__ void k_warm_pileup() {} }
+// loads this file's code object onto the current device (first launch of a process: ~10 ms per code object)
+hipError_t bsig::warm_pileup_module(hipStream_t st)
+{
+    hipLaunchKernelGGL(k_warm_pileup, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+
 extern "C" int bsig_debug_set_knob(int which, int value)
 {
     if (which < 0 || which >= 4 || value < 0) return -1;

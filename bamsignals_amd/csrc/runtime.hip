@@ -220,6 +220,7 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
         (void)hipGetLastError();
     }
     bsig_ctx *c = new bsig_ctx;
+    c->warm_pending = true;
     c->device = device;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -227,6 +228,16 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail(BSIG_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->owns_stream = true;
+    }
+    if (c->warm_pending) {
+        // ... and so does the first launch out of each code object of this library (walk / extract / inflate,
+        // pileup, reassembly): about 10 ms apiece, once per process and device
+        (void)bsig::warm_pileup_module(c->stream);
+        (void)bsig::warm_decode_module(c->stream);
+        (void)bsig::warm_collect_module(c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        c->warm_pending = false;
     }
     *out = c;
     return BSIG_OK;

@@ -79,6 +79,7 @@ struct bsig_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    bool warm_pending = false;
 };
 
 struct bsig_reads {
@@ -101,6 +102,9 @@ struct BaiIndex;
 int layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_ref, const int32_t *ref_len,
                        const int64_t *ref_off, const int32_t *d_pos, const int32_t *d_end,
                        const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tlen);
+// first launches of a process load each source file's code object onto the device: done with the context
+hipError_t warm_decode_module(hipStream_t st);      // devdecode.hip
+hipError_t warm_collect_module(hipStream_t st);     // collect.hip
 // hands the device-side decode's cached scratch back to the driver (devdecode.hip)
 void release_decode_scratch();
 // > 0: the file (or this build's limits) needs another decode path; nothing was allocated

@@ -306,6 +306,9 @@ void bsig_cache_clear(void);
 /* diagnostic: device / page-locked allocations made so far for the buffers the multi-GPU result path keeps
  * between calls (a call on a resident BAM with shapes seen before adds none)                        */
 int64_t bsig_debug_scratch_allocs(void);
+/* diagnostic: number and a checksum of the BGZF blocks of a file as the device-side decode tabulates them
+ * (env BAMSIGNALS_SCAN=mmap: the walk through the mapped file; default: through pread())              */
+int bsig_debug_block_table(const char *path, int64_t *n_blocks, uint64_t *checksum);
 /* how the calling thread's last file-level call was carried out, e.g.
  * "8 GPU slot(s); reads: sharded decode, columns over rccl; result: xgmi/rccl"                  */
 const char *bsig_last_call_route(void);

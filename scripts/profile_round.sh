@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-CASES=${*:-ns c2 c3 c4 c5 count decode}
+CASES=${*:-ns c2 c3 c4 c5 count decode decodereal}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -34,6 +34,11 @@ for c in $CASES; do
         # the device-side decode kernels (whole file + index-driven) on the 5e7-read BAM
         timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decode_trace" -- python3 $R/scripts/decode_device_time.py > "$OUT/${TAG}_decode_trace.log" 2>&1 || exit 1
         echo "[decode] trace done" ;;
+    decodereal)
+        # k_inflate on literal-heavy blocks: a BAM with read names, bases and qualities (2e7 reads, 2.1 GB)
+        timeout 900 python3 $R/scripts/decode_realshaped_device_time.py > "$OUT/${TAG}_decodereal_plain.txt" 2>&1 || exit 1
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decodereal_trace" -- python3 $R/scripts/decode_realshaped_device_time.py > "$OUT/${TAG}_decodereal_trace.log" 2>&1 || exit 1
+        echo "[decodereal] trace done" ;;
     esac
 done
 ls "$OUT" | grep "${TAG}_" | head -50

@@ -85,5 +85,25 @@ if dec:
     for r in csv.DictReader(open(dec)):
         if any(s in r["Name"] for s in ("k_inflate", "k_crc32", "k_bam_walk", "k_bam_extract", "k_scatter", "k_span_hist", "k_build_idx")):
             lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |")
+real = newest(f"{tag}_decodereal_trace/*/*_kernel_stats.csv")
+plain = os.path.join(G, f"{tag}_decodereal_plain.txt")
+if real:
+    shutil.copyfile(real, os.path.join(P, f"{tag}_decode_realshaped_kernel_stats.csv"))
+    lines.append("\n## Device-side decode of a REAL-SHAPED BAM (`rocprofv3 --kernel-trace --stats -- python3 "
+                 "scripts/decode_realshaped_device_time.py`: 2e7 reads with names, bases, qualities; 2.1 GB file, 4.08 GB of "
+                 "stream in 62,000 blocks; four decodes with the GPU inflating)\n")
+    lines.append("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|")
+    infl = 0.0
+    for r in csv.DictReader(open(real)):
+        if any(s in r["Name"] for s in ("k_inflate", "k_crc32", "k_bam_walk", "k_bam_extract")):
+            lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |")
+        if "k_inflate" in r["Name"]:
+            infl = float(r["TotalDurationNs"]) / 4.0 if "TotalDurationNs" in r else float(r["AverageNs"]) * float(r["Calls"]) / 4.0
+    if infl:
+        lines.append(f"\n`k_inflate` per decode (all its launches): {infl / 1e6:.1f} ms for 4.08 GB of output = "
+                     f"**{4.08e9 / infl:.1f} GB/s of output**")
+    if os.path.exists(plain):
+        shutil.copyfile(plain, os.path.join(P, f"{tag}_decode_realshaped_plain.txt"))
+        lines.append("\nun-profiled stage times (last of four decodes): `" + open(plain).read().strip().splitlines()[-1] + "`")
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

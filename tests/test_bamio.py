@@ -317,6 +317,46 @@ def test_block_scan_in_segments(fixture_reads, monkeypatch, tmp_path):
             assert np.array_equal(got[k], want[k])
 
 
+def test_block_table_through_pread_equals_the_mapped_walk(tmp_path, monkeypatch):
+    """The device-side decode tabulates the BGZF blocks with pread() (a block's trailer and the next block's
+    header in one small read; no page of the mapping is touched) in parallel segments; the table must be the
+    one the walk through the mapped file gives, whatever the segment size, and a file the segments cannot be
+    proven on (too small, damaged) must fall back to that walk with its error messages."""
+    import ctypes as C
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import write_columns_as_bam
+    lib = _lib.load()
+
+    def table(path, how, seg_kb=None):
+        monkeypatch.setenv("BAMSIGNALS_SCAN", how)
+        if seg_kb:
+            monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", seg_kb)
+        else:
+            monkeypatch.delenv("BAMSIGNALS_SCAN_SEGMENT_KB", raising=False)
+        n, h = C.c_int64(), C.c_uint64()
+        _lib.check(lib.bsig_debug_block_table(path.encode(), C.byref(n), C.byref(h)))
+        return n.value, h.value
+
+    want = table(BAM, "mmap")
+    assert want[0] > 5
+    for kb in ("16", "40", "100", None):
+        assert table(BAM, "pread", kb) == want
+    cols = _synth(900_000, seed=10)
+    p = str(tmp_path / "syn.bam")
+    write_columns_as_bam(p, ["a", "b", "c"], cols)
+    want = table(p, "mmap")
+    assert want[0] > 500
+    for kb in ("8", "64", "1024", None):
+        assert table(p, "pread", kb) == want
+    # a file cut in the middle of a block: both walks refuse it with the same message
+    raw = open(p, "rb").read()
+    q = str(tmp_path / "cut.bam")
+    open(q, "wb").write(raw[: len(raw) // 2 + 1234])
+    for how in ("mmap", "pread"):
+        with pytest.raises(_lib.BsigError, match="malformed BGZF block"):
+            table(q, how, "64")
+
+
 def test_crc_of_bgzf_blocks_is_checked(tmp_path):
     """a block whose trailer CRC32 does not match what it inflates to is refused (as htslib does)"""
     from bamsignals_amd import _lib
