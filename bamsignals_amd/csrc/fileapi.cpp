@@ -107,13 +107,14 @@ struct Slots {
     {
         for (size_t k = 0; k < scratch.size(); ++k) {
             (void)hipSetDevice(devices[k]);
-            if (scratch[k].d_shard) (void)hipFree(scratch[k].d_shard);
+            if (scratch[k].d_shard) bsig::block_free(devices[k], scratch[k].d_shard, scratch[k].shard_cap * sizeof(int32_t));
             if (scratch[k].h_shard) (void)hipHostFree(scratch[k].h_shard);
         }
         if (!devices.empty()) (void)hipSetDevice(devices[0]);
-        if (root.d_gather) (void)hipFree(root.d_gather);
-        if (root.d_final) (void)hipFree(root.d_final);
-        for (int64_t *t : root.d_tab) if (t) (void)hipFree(t);
+        if (root.d_gather) bsig::block_free(devices[0], root.d_gather, root.gather_cap * sizeof(int32_t));
+        if (root.d_final) bsig::block_free(devices[0], root.d_final, root.final_cap * sizeof(int32_t));
+        for (int k = 0; k < 3; ++k)
+            if (root.d_tab[k]) bsig::block_free(devices[0], root.d_tab[k], root.tab_cap[k] * sizeof(int64_t));
         for (bsig_ctx *c : ctx) if (c) bsig_ctx_destroy(c);
     }
 };
@@ -240,16 +241,21 @@ int for_each_slot(size_t n, const std::function<int(size_t)> &body)
     return BSIG_OK;
 }
 
-// grows a cached buffer of the multi-GPU result path (never shrinks; freed with the Slots)
+// grows a cached buffer of the multi-GPU result path (never shrinks; released with the Slots).  The memory comes
+// from the library's cache of free device blocks (runtime_internal.h): right after a cold decode that cache
+// holds the decode's scratch, and a fresh hipMalloc at that moment is exactly the one that stalls for seconds
 template <typename T>
 int grow_dev(Slots &sl, int device, T **p, size_t *cap, size_t want)
 {
     if (*p && *cap >= want) return BSIG_OK;
     HIP_TRY(hipSetDevice(device));
-    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    if (*p) { bsig::block_free(device, *p, *cap * sizeof(T)); *p = nullptr; *cap = 0; }
     const size_t n = std::max<size_t>(want + want / 8, 1024);          // head-room: a slightly larger call fits too
-    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
-    *cap = n;
+    void *q = nullptr;
+    size_t got = 0;
+    HIP_TRY(bsig::block_alloc(device, n * sizeof(T), 2.0, &q, &got));
+    *p = (T *)q;
+    *cap = got / sizeof(T);
     sl.scratch_allocs.fetch_add(1);
     return BSIG_OK;
 }
