@@ -220,7 +220,12 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
         (void)hipGetLastError();
     }
     bsig_ctx *c = new bsig_ctx;
-    c->warm_pending = true;
+    {
+        static std::mutex warm_mu;
+        static std::vector<int> warmed;
+        std::lock_guard<std::mutex> lk(warm_mu);
+        if (std::find(warmed.begin(), warmed.end(), device) == warmed.end()) { warmed.push_back(device); c->warm_pending = true; }
+    }
     c->device = device;
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -235,6 +240,18 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
         (void)bsig::warm_pileup_module(c->stream);
         (void)bsig::warm_decode_module(c->stream);
         (void)bsig::warm_collect_module(c->stream);
+        // ... and so do the runtime's own staging buffers for copies from and to pageable memory (the record
+        // walk's per-block summaries come back that way)
+        {
+            void *d = nullptr;
+            std::vector<uint8_t> h((size_t)4 << 20, 0);
+            if (hipMalloc(&d, h.size()) == hipSuccess) {
+                (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, c->stream);
+                (void)hipMemcpyAsync(h.data(), d, h.size(), hipMemcpyDeviceToHost, c->stream);
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipFree(d);
+            }
+        }
         (void)hipStreamSynchronize(c->stream);
         (void)hipGetLastError();
         c->warm_pending = false;
