@@ -133,17 +133,19 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
 
 
 def _settle(path):
-    """A BAM the bench has just written is still dirty in the page cache; the timed calls are meant to see a
-    file that has been on disk for a while and is cached clean: flush it and read it once."""
+    """A BAM the bench has just written is still dirty in the page cache and its pages have never been read;
+    the timed calls are meant to see a file that has been on disk for a while and has been used before (cached,
+    clean, on the active list: mapping such a file is 4-8 x faster): flush it and read it twice."""
     for p in (path, path + ".bai"):
         fd = os.open(p, os.O_RDONLY)
         try:
             os.fsync(fd)
         finally:
             os.close(fd)
-    with open(path, "rb") as fh:
-        while fh.read(64 << 20):
-            pass
+    for _ in range(2):
+        with open(path, "rb") as fh:
+            while fh.read(64 << 20):
+                pass
 
 
 def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
