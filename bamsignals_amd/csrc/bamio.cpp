@@ -854,13 +854,14 @@ int BgzfFile::open(const std::string &path)
 {
     if (p_->f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
     p_->blocks.clear();
-    // (env BAMSIGNALS_SCAN=pread: the block table without touching the mapping -- 0.06-0.09 s for the north
-    // star's 327,000 blocks whatever state the file's pages are in, one small read per block; default: the walk
-    // through the populated mapping -- 0.015 s on a file that has been read before, 0.05-0.13 s on one that was
-    // written a second ago; its teardown runs in the background.  The compressed bytes themselves are copied
-    // with pread() either way.)
+    // The block table through pread(), without touching the mapping (env BAMSIGNALS_SCAN=mmap: through the
+    // populated mapping, which is also what any doubt falls back to).  Measured on the north star's file in
+    // fresh processes (scripts/cold_call_scan_ab.py): the mapped walk itself is quicker on a file that has been
+    // read before (0.015 s against 0.04-0.06 s for 327,000 small reads), but the call is not -- 0.45 s against
+    // 0.41 s: filling and tearing down the page tables of a 3-GB mapping holds the process's mmap lock, and the
+    // 800-MB result array that is being first-touched at the other end of the call waits behind it.
     const char *how = getenv("BAMSIGNALS_SCAN");
-    if (how && !strcmp(how, "pread") && scan_blocks_pread(p_->f, p_->blocks)) return 0;
+    if (!(how && !strcmp(how, "mmap")) && scan_blocks_pread(p_->f, p_->blocks)) return 0;
     p_->blocks.clear();
     return scan_blocks(p_->f, path, p_->blocks);
 }
