@@ -689,66 +689,99 @@ bool parse_block_fd(HeadReader &r, uint64_t off, Block &b)
 }
 }  // namespace
 
+// The walk in K parallel segments; segments [k0, k1) can be run and stitched on their own, so that the head of a
+// large file is tabulated first and the rest while the GPU already works on the head (BgzfFile::open_progressive).
+struct PreadScan {
+    const MappedFile &f;
+    size_t K = 0;
+    std::vector<std::vector<Block>> part;
+    std::vector<uint64_t> first, last_end;
+    std::vector<char> ok;
+    explicit PreadScan(const MappedFile &file) : f(file)
+    {
+        uint64_t seg_bytes = 8u << 20;
+        if (const char *e = getenv("BAMSIGNALS_SCAN_SEGMENT_KB")) {
+            const long v = atol(e);
+            if (v > 0) seg_bytes = (uint64_t)v << 10;
+        }
+        if (f.fd < 0 || f.size < 2 * seg_bytes) return;
+        K = (size_t)std::min<uint64_t>(1024, f.size / seg_bytes);
+        part.resize(K);
+        first.assign(K, 0);
+        last_end.assign(K, 0);
+        ok.assign(K, 0);
+    }
+    uint64_t cut(size_t k) const { return k >= K ? f.size : (uint64_t)k * (f.size / K); }
+    void run(size_t k0, size_t k1, int threads)
+    {
+        const int kHops = 4;
+        parallel_for((int64_t)(k1 - k0), threads, [&](int64_t kk, int) {
+            const size_t k = k0 + (size_t)kk;
+            HeadReader r{f.fd, f.size};
+            const uint64_t c = cut(k), next_cut = cut(k + 1);
+            uint64_t start = c;
+            if (k > 0) {
+                // the first offset behind the cut from which a chain of kHops valid headers follows
+                std::vector<uint8_t> win((size_t)std::min<uint64_t>(next_cut - c + 2, 256u << 10));
+                size_t got = 0;
+                while (got < win.size()) {
+                    const ssize_t n = ::pread(f.fd, win.data() + got, win.size() - got, (off_t)(c + got));
+                    if (n <= 0) break;
+                    got += (size_t)n;
+                }
+                bool found = false;
+                for (size_t i = 0; i + 1 < got && !found; ++i) {
+                    if (win[i] != 31 || win[i + 1] != 139) continue;
+                    uint64_t q = c + i;
+                    int hops = 0;
+                    Block b;
+                    while (hops < kHops && q < f.size && parse_block_fd(r, q, b)) { q += b.csize; ++hops; }
+                    if (hops == kHops || (hops > 0 && q == f.size)) { start = c + i; found = true; }
+                }
+                if (!found) return;
+            }
+            first[k] = start;
+            uint64_t o = start;
+            std::vector<Block> &out = part[k];
+            out.reserve((size_t)((next_cut - c) / 4096 + 16));
+            while (o < next_cut) {
+                Block b;
+                if (!parse_block_fd(r, o, b)) return;
+                out.push_back(b);
+                o += b.csize;
+            }
+            last_end[k] = o;
+            ok[k] = 1;
+        });
+    }
+    // appends the blocks of segments [k0, k1) to `blocks` if their chains meet (`at`: where the chain stands,
+    // 0 before segment 0); false on any doubt
+    bool stitch(size_t k0, size_t k1, uint64_t &at, std::vector<Block> &blocks)
+    {
+        for (size_t k = k0; k < k1; ++k) {
+            if (!ok[k] || first[k] != at) return false;
+            at = last_end[k];
+        }
+        if (k1 == K && at != f.size) return false;
+        size_t n = 0;
+        for (size_t k = k0; k < k1; ++k) n += part[k].size();
+        blocks.reserve(blocks.size() + n);
+        for (size_t k = k0; k < k1; ++k) {
+            blocks.insert(blocks.end(), part[k].begin(), part[k].end());
+            std::vector<Block>().swap(part[k]);
+        }
+        return true;
+    }
+};
+
 static bool scan_blocks_pread(const MappedFile &f, std::vector<Block> &blocks)
 {
-    const int kHops = 4;
-    uint64_t seg_bytes = 8u << 20;
-    if (const char *e = getenv("BAMSIGNALS_SCAN_SEGMENT_KB")) {
-        const long v = atol(e);
-        if (v > 0) seg_bytes = (uint64_t)v << 10;
-    }
-    if (f.fd < 0 || f.size < 2 * seg_bytes) return false;
-    const size_t K = (size_t)std::min<uint64_t>(1024, f.size / seg_bytes);
-    std::vector<std::vector<Block>> part(K);
-    std::vector<uint64_t> first(K, 0), last_end(K, 0);
-    std::vector<char> ok(K, 0);
-    parallel_for((int64_t)K, std::min(n_threads(0), 32), [&](int64_t k, int) {
-        HeadReader r{f.fd, f.size};
-        const uint64_t cut = (uint64_t)k * (f.size / K), next_cut = k + 1 == (int64_t)K ? f.size : (uint64_t)(k + 1) * (f.size / K);
-        uint64_t start = cut;
-        if (k > 0) {
-            // the first offset behind the cut from which a chain of kHops valid headers follows
-            std::vector<uint8_t> win((size_t)std::min<uint64_t>(next_cut - cut + 2, 256u << 10));
-            size_t got = 0;
-            while (got < win.size()) {
-                const ssize_t n = ::pread(f.fd, win.data() + got, win.size() - got, (off_t)(cut + got));
-                if (n <= 0) break;
-                got += (size_t)n;
-            }
-            bool found = false;
-            for (size_t i = 0; i + 1 < got && !found; ++i) {
-                if (win[i] != 31 || win[i + 1] != 139) continue;
-                uint64_t q = cut + i;
-                int hops = 0;
-                Block b;
-                while (hops < kHops && q < f.size && parse_block_fd(r, q, b)) { q += b.csize; ++hops; }
-                if (hops == kHops || (hops > 0 && q == f.size)) { start = cut + i; found = true; }
-            }
-            if (!found) return;
-        }
-        first[(size_t)k] = start;
-        uint64_t o = start;
-        std::vector<Block> &out = part[(size_t)k];
-        out.reserve((size_t)((next_cut - cut) / 4096 + 16));
-        while (o < next_cut) {
-            Block b;
-            if (!parse_block_fd(r, o, b)) return;
-            out.push_back(b);
-            o += b.csize;
-        }
-        last_end[(size_t)k] = o;
-        ok[(size_t)k] = 1;
-    });
-    for (size_t k = 0; k < K; ++k) {
-        if (!ok[k]) return false;
-        if (k + 1 < K && (!ok[k + 1] || last_end[k] != first[k + 1])) return false;
-        if (k + 1 == K && last_end[k] != f.size) return false;
-    }
-    size_t n = 0;
-    for (const auto &v : part) n += v.size();
+    PreadScan sc(f);
+    if (sc.K == 0) return false;
+    sc.run(0, sc.K, std::min(n_threads(0), 32));
     blocks.clear();
-    blocks.reserve(n);
-    for (const auto &v : part) blocks.insert(blocks.end(), v.begin(), v.end());
+    uint64_t at = 0;
+    if (!sc.stitch(0, sc.K, at, blocks)) { blocks.clear(); return false; }
     return true;
 }
 
@@ -847,6 +880,13 @@ static int inflate_batch(const MappedFile &f, const std::vector<Block> &blocks, 
 struct BgzfFile::Impl {
     MappedFile f;
     std::vector<Block> blocks;
+    // open_progressive: the rest of the table is being walked by `bg`
+    std::unique_ptr<PreadScan> scan;
+    size_t k_head = 0;
+    uint64_t at = 0;
+    std::thread bg;
+    std::string path;
+    ~Impl() { if (bg.joinable()) bg.join(); }
 };
 BgzfFile::BgzfFile() : p_(new Impl) {}
 BgzfFile::~BgzfFile() { delete p_; }
@@ -864,6 +904,53 @@ int BgzfFile::open(const std::string &path)
     if (!(how && !strcmp(how, "mmap")) && scan_blocks_pread(p_->f, p_->blocks)) return 0;
     p_->blocks.clear();
     return scan_blocks(p_->f, path, p_->blocks);
+}
+int BgzfFile::open_progressive(const std::string &path, uint64_t head_bytes)
+{
+    const char *how = getenv("BAMSIGNALS_SCAN");
+    if (p_->f.open(path) != 0) return fail(BSIG_ERR_IO, "Fail to open BAM file %s", path.c_str());
+    p_->blocks.clear();
+    p_->path = path;
+    if (!(how && !strcmp(how, "mmap")) && p_->f.size > 2 * head_bytes) {
+        std::unique_ptr<PreadScan> sc(new PreadScan(p_->f));
+        if (sc->K > 0) {
+            size_t kh = 1;
+            while (kh < sc->K && sc->cut(kh) < head_bytes) ++kh;
+            const int thr = std::min(n_threads(0), 32);
+            sc->run(0, kh, thr);
+            uint64_t at = 0;
+            if (kh < sc->K && sc->stitch(0, kh, at, p_->blocks) && p_->blocks.size() > 64) {
+                p_->scan = std::move(sc);
+                p_->k_head = kh;
+                p_->at = at;
+                PreadScan *raw = p_->scan.get();
+                try {
+                    p_->bg = std::thread([raw, kh, thr] { raw->run(kh, raw->K, thr); });
+                    return 0;
+                } catch (const std::system_error &) {
+                    raw->run(kh, raw->K, thr);
+                    return 0;                      // (finish() stitches)
+                }
+            }
+            p_->blocks.clear();
+        }
+    }
+    // small file, or a head that could not be proven: the whole table now
+    if (!(how && !strcmp(how, "mmap")) && scan_blocks_pread(p_->f, p_->blocks)) return 0;
+    p_->blocks.clear();
+    return scan_blocks(p_->f, path, p_->blocks);
+}
+bool BgzfFile::complete() const { return !p_->scan; }
+int BgzfFile::finish()
+{
+    if (!p_->scan) return 0;
+    if (p_->bg.joinable()) p_->bg.join();
+    std::unique_ptr<PreadScan> sc = std::move(p_->scan);
+    uint64_t at = p_->at;
+    if (sc->stitch(p_->k_head, sc->K, at, p_->blocks)) return 0;
+    // the rest could not be proven: the mapped walk over the whole file (it owns the error messages)
+    p_->blocks.clear();
+    return scan_blocks(p_->f, p_->path, p_->blocks);
 }
 int BgzfFile::map(const std::string &path)
 {

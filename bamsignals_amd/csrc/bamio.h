@@ -95,6 +95,12 @@ public:
     BgzfFile();
     ~BgzfFile();
     int open(const std::string &path);                        // maps the file and scans every block header
+    // the same in two steps: returns once the blocks of the first head_bytes of the file are tabulated (blocks()
+    // then holds exactly those, from the start of the file) while the rest is walked in the background; finish()
+    // waits for it and completes blocks().  Small files, and any doubt, are tabulated whole at once.
+    int open_progressive(const std::string &path, uint64_t head_bytes);
+    bool complete() const;                                    // is blocks() the whole table?
+    int finish();
     int map(const std::string &path);                         // maps the file only (index-driven access)
     const std::vector<BgzfBlock> &blocks() const;
     const uint8_t *data() const;                              // the mapped (compressed) file

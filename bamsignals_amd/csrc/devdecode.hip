@@ -652,12 +652,14 @@ struct ShareOut {
 constexpr size_t kOverlapBlocks = 4;
 
 // Returns BSIG_OK, kNeedsCpuPath (this file / this split cannot be proven on the device), or an error.
+// more_follow: f.blocks() is only the head of the file's table (BgzfFile::open_progressive): the share cannot be
+// the stream's last, whatever its end.
 int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const std::vector<uint64_t> &uoff, size_t Bbeg,
-                 size_t Bend, int threads, bool gpu_inflate, ShareOut &R)
+                 size_t Bend, int threads, bool gpu_inflate, ShareOut &R, bool more_follow = false)
 {
     const std::vector<BgzfBlock> &blocks = f.blocks();
     const size_t nb = blocks.size();
-    const bool first_share = Bbeg == 0, last_share = Bend == nb;
+    const bool first_share = Bbeg == 0, last_share = Bend == nb && !more_follow;
     const int32_t n_ref = (int32_t)hdr.names.size();
     const uint64_t share_bytes = uoff[Bend] - uoff[Bbeg];
 
@@ -874,7 +876,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         const uint64_t own_bytes = uoff[B1] - uoff[B0];        // the blocks whose records this pass walks
         const uint64_t seen_bytes = uoff[Bv] - uoff[B0];       // ... and what it can read (overlap included)
         const bool share_end = B1 == Bend;
-        const bool stream_end = Bv == nb;                      // the view ends where the stream ends
+        const bool stream_end = Bv == nb && !more_follow;      // the view ends where the stream ends
 
         int64_t header_end = -1;
         std::vector<uint8_t> head;             // the head of the stream, only if the header spans batches
@@ -1107,10 +1109,10 @@ struct FileScan {
     std::vector<uint64_t> uoff;
     bool gpu_inflate = false;
 };
-int scan_file(const std::string &path, int threads, FileScan &F)
+// fills F.uoff and decides the inflate engine from F.f.blocks() (the whole table, or -- progressive -- its head,
+// from which the whole file's numbers are extrapolated)
+int tabulate(const std::string &path, int threads, FileScan &F)
 {
-    int rc = F.f.open(path);
-    if (rc) return rc;
     const std::vector<BgzfBlock> &blocks = F.f.blocks();
     if (blocks.empty()) return kNeedsCpuPath;
     const size_t nb = blocks.size();
@@ -1121,18 +1123,50 @@ int scan_file(const std::string &path, int threads, FileScan &F)
         F.uoff[k + 1] = F.uoff[k] + blocks[k].isize;
         comp_total += blocks[k].dlen;
     }
-    if (F.uoff[nb] < 12) return kNeedsCpuPath;
-    rc = bam_read_header(path, F.hdr);
-    if (rc) return kNeedsCpuPath;                      // the CPU path reports what is wrong
+    if (F.f.complete() && F.uoff[nb] < 12) return kNeedsCpuPath;
+    size_t n_est = nb;
+    if (!F.f.complete()) {
+        const uint64_t seen = blocks[nb - 1].coff + blocks[nb - 1].csize;
+        const double scale = (double)F.f.size() / (double)std::max<uint64_t>(seen, 1);
+        n_est = (size_t)((double)nb * scale);
+        comp_total = (uint64_t)((double)comp_total * scale);
+    }
     // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
     const char *eng = getenv("BAMSIGNALS_INFLATE");
-    F.gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(nb, comp_total, threads);
+    F.gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_est, comp_total, threads);
+    (void)path;
     return BSIG_OK;
+}
+int scan_file(const std::string &path, int threads, FileScan &F, uint64_t head_bytes = ~0ull >> 2)
+{
+    int rc = head_bytes >= (~0ull >> 2) ? F.f.open(path) : F.f.open_progressive(path, head_bytes);
+    if (rc) return rc;
+    rc = bam_read_header(path, F.hdr);
+    if (rc) { (void)F.f.finish(); return kNeedsCpuPath; }      // the CPU path reports what is wrong
+    rc = tabulate(path, threads, F);
+    if (rc) (void)F.f.finish();
+    return rc;
+}
+// the rest of a progressive table: waits for the background walk, recomputes F.uoff (the engine choice stands)
+int finish_scan(const std::string &path, FileScan &F)
+{
+    const bool gpu = F.gpu_inflate;
+    int rc = F.f.finish();
+    if (rc) return rc;
+    rc = tabulate(path, 0, F);
+    F.gpu_inflate = gpu;
+    return rc;
 }
 
 }  // namespace
 
 // Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
+//
+// Large files in two steps (GPU inflate only): the blocks of the file's head (about one first pass: 640 MB of
+// file) are tabulated, the head is decoded as a share of its own -- and while the GPU inflates and walks it,
+// the rest of the table is built by the host (327,000 small reads for the north star's file: 0.04-0.06 s that
+// the call used to spend before its first launch).  The two shares are then joined like the shares of several
+// GPUs: the chains must meet, the reads must stay in order.
 int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, bsig_reads **out)
 {
     double *T = g_dev_decode_timing;
@@ -1141,21 +1175,74 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     *out = nullptr;
     FileScan F;
     diag_mark(nullptr);
-    int rc = scan_file(path, threads, F);
+    uint64_t head_bytes = env_mb("BAMSIGNALS_SCAN_HEAD_MB", 640);
+    {
+        const char *e = getenv("BAMSIGNALS_SCAN_HEAD_MB");
+        if (e && atoll(e) <= 0) head_bytes = ~0ull >> 2;                       // 0: the whole table first
+    }
+    int rc = scan_file(path, threads, F, head_bytes);
     if (rc) return rc;
-    diag_mark("map + populate + block scan");
+    diag_mark("map + block table (head)");
     T[0] = now_s() - t_begin;
-    ShareOut S;
-    rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, F.f.blocks().size(), threads, F.gpu_inflate, S);
-    if (rc) return rc;
+    ShareOut S, S2;
+    bool two = false;
+    if (!F.f.complete()) {
+        if (F.gpu_inflate && F.f.blocks().size() > 4 * kOverlapBlocks) {
+            // the head share ends kOverlapBlocks before the end of what is tabulated: its last record may run on
+            const size_t Bh = F.f.blocks().size() - kOverlapBlocks;
+            rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, Bh, threads, true, S, true);
+            diag_mark("decode_share (head)");
+            const double tw = now_s();
+            const int rc2 = finish_scan(path, F);                               // (waits for the background walk)
+            T[0] += now_s() - tw;
+            diag_mark("rest of the block table");
+            if (rc2) return rc2;
+            if (rc) return rc;
+            rc = decode_share(ctx, F.f, F.hdr, F.uoff, Bh, F.f.blocks().size(), threads, true, S2);
+            if (rc) return rc;
+            // the head's chain must end where the rest's begins; the reads must stay in coordinate order
+            if (S.chain_end != S2.chain_first) return kNeedsCpuPath;
+            if (S.n_reads && S2.n_reads &&
+                (S2.first_rid < S.last_rid || (S2.first_rid == S.last_rid && S2.first_pos < S.last_pos)))
+                return kNeedsCpuPath;
+            two = true;
+        } else {
+            rc = finish_scan(path, F);
+            if (rc) return rc;
+            T[0] = now_s() - t_begin;
+        }
+    }
+    if (!two) {
+        rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, F.f.blocks().size(), threads, F.gpu_inflate, S);
+        if (rc) return rc;
+    }
     diag_mark("decode_share (all passes)");
-    T[1] = S.t_inflate;
-    T[2] = S.t_wait;
+    T[1] = S.t_inflate + S2.t_inflate;
+    T[2] = S.t_wait + S2.t_wait;
     // ---- join the pieces, first read of every reference, resident layout ---------------------------
     double t_join = 0, t_layout = 0;
-    rc = finish_reads(ctx, ctx->stream, *S.tmp, S.pieces, S.n_reads, F.hdr, S.d_ref_first, t_join, t_layout, out);
+    if (two) {
+        // first read of every reference: the head's index where the head knows the reference, else the rest's,
+        // moved behind the head's reads (the rule of join_shares)
+        const int32_t n_ref = (int32_t)F.hdr.names.size();
+        std::vector<long long> a((size_t)n_ref + 1, -1), b2((size_t)n_ref + 1, -1);
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMemcpyAsync(a.data(), S.d_ref_first, a.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b2.data(), S2.d_ref_first, b2.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t q = 0; q < a.size(); ++q)
+            if (a[q] < 0 && b2[q] >= 0) a[q] = S.n_reads + b2[q];
+        HIP_TRY(hipMemcpyAsync(S2.d_ref_first, a.data(), a.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<std::unique_ptr<Piece>> pieces;
+        for (auto &pp : S.pieces) pieces.push_back(std::move(pp));
+        for (auto &pp : S2.pieces) pieces.push_back(std::move(pp));
+        rc = finish_reads(ctx, ctx->stream, *S2.tmp, pieces, S.n_reads + S2.n_reads, F.hdr, S2.d_ref_first, t_join, t_layout, out);
+    } else {
+        rc = finish_reads(ctx, ctx->stream, *S.tmp, S.pieces, S.n_reads, F.hdr, S.d_ref_first, t_join, t_layout, out);
+    }
     if (rc) return rc;
-    T[3] = S.t_gpu + t_join;
+    T[3] = S.t_gpu + S2.t_gpu + t_join;
     T[5] = t_layout;
     T[4] = now_s() - t_begin;
     return BSIG_OK;
