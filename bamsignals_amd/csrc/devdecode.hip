@@ -427,16 +427,10 @@ struct ScratchPool {
     {
         const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
         void *q = nullptr;
-        if (bytes >= bsig::kBlockCacheMin) {
-            size_t got = 0;
-            const hipError_t e = bsig::block_alloc(device, bytes, 2.0, &q, &got);
-            if (e != hipSuccess) { *p = nullptr; return e; }
-            mine.push_back(Blk{q, got, true});
-        } else {
-            const hipError_t e = hipMalloc(&q, bytes);
-            if (e != hipSuccess) { *p = nullptr; return e; }
-            mine.push_back(Blk{q, bytes, false});
-        }
+        size_t got = 0;
+        const hipError_t e = bsig::block_alloc(device, bytes, 2.0, &q, &got);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        mine.push_back(Blk{q, got, true});
         *p = (T *)q;
         return hipSuccess;
     }

@@ -69,10 +69,94 @@ size_t block_cache_limit()
 }
 }  // namespace
 
+// ---- an arena reserved with the context (env BAMSIGNALS_ARENA_GB, default 0 = none) -------------------------
+// Every hipMalloc is a trip into the driver, and on a shared host those trips are where a call's time goes
+// astray (the stalls above; 0.1-0.5 s extra in the walk and the layout of one cold call in four on a busy
+// box).  With an arena ONE allocation is made when the context comes up; blocks are carved out of it (first
+// fit, 4-KiB aligned, neighbours merged again when they come back) and a cold call makes no allocation at all
+// as long as its scratch and its resident reads fit.  What does not fit takes the paths above.
+namespace {
+struct Arena {
+    int dev = -1;
+    uint8_t *base = nullptr;
+    size_t size = 0;
+    std::vector<std::pair<size_t, size_t>> free_;      // (offset, length), sorted by offset, never adjacent
+};
+std::mutex g_arena_mu;
+std::vector<Arena> g_arenas;
+Arena *arena_of(int device)
+{
+    for (Arena &a : g_arenas)
+        if (a.dev == device) return &a;
+    return nullptr;
+}
+bool arena_take(int device, size_t bytes, void **p, size_t *got)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    Arena *a = arena_of(device);
+    if (!a) return false;
+    const size_t need = (bytes + 4095) & ~(size_t)4095;
+    for (size_t k = 0; k < a->free_.size(); ++k) {
+        if (a->free_[k].second < need) continue;
+        *p = a->base + a->free_[k].first;
+        *got = need;
+        a->free_[k].first += need;
+        a->free_[k].second -= need;
+        if (a->free_[k].second == 0) a->free_.erase(a->free_.begin() + (long)k);
+        return true;
+    }
+    return false;
+}
+bool arena_give(int device, void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    Arena *a = arena_of(device);
+    if (!a || (uint8_t *)p < a->base || (uint8_t *)p >= a->base + a->size) return false;
+    const size_t off = (size_t)((uint8_t *)p - a->base);
+    auto it = std::lower_bound(a->free_.begin(), a->free_.end(), std::make_pair(off, (size_t)0));
+    it = a->free_.insert(it, {off, bytes});
+    if (it + 1 != a->free_.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; a->free_.erase(it + 1); }
+    if (it != a->free_.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; a->free_.erase(it); }
+    return true;
+}
+}  // namespace
+
+void arena_reserve(int device)
+{
+    const char *e = getenv("BAMSIGNALS_ARENA_GB");
+    const long long gb = e ? atoll(e) : 0;
+    if (gb <= 0) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    if (arena_of(device)) return;
+    Arena a;
+    a.dev = device;
+    a.size = (size_t)gb << 30;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&a.base, a.size) != hipSuccess) { (void)hipGetLastError(); return; }
+    a.free_.push_back({0, a.size});
+    g_arenas.push_back(a);
+}
+
+// (bsig_cache_clear: an arena nobody holds a block of goes back to the driver)
+static void arena_release_idle()
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (size_t k = 0; k < g_arenas.size();) {
+        Arena &a = g_arenas[k];
+        if (a.free_.size() == 1 && a.free_[0].first == 0 && a.free_[0].second == a.size) {
+            (void)hipSetDevice(a.dev);
+            (void)hipFree(a.base);
+            g_arenas.erase(g_arenas.begin() + (long)k);
+        } else {
+            ++k;
+        }
+    }
+}
+
 hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, size_t *got)
 {
+    if (arena_take(device, std::max<size_t>(bytes, 256), p, got)) return hipSuccess;
     bytes = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
-    {
+    if (bytes >= kBlockCacheMin) {
         std::lock_guard<std::mutex> lk(g_blocks.mu);
         size_t best = (size_t)-1;
         const size_t cap = (size_t)((double)bytes * max_waste) + (1u << 20);
@@ -106,6 +190,15 @@ hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, siz
 void block_free(int device, void *p, size_t bytes)
 {
     if (!p) return;
+    if (arena_give(device, p, bytes)) return;
+    if (bytes < kBlockCacheMin) {                     // small blocks are not worth keeping
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipFree(p);
+        if (cur != device) (void)hipSetDevice(cur);
+        return;
+    }
     const size_t limit = block_cache_limit();
     std::vector<BlockCache::Blk> drop;
     {
@@ -130,6 +223,7 @@ void block_free(int device, void *p, size_t bytes)
 
 void block_cache_release()
 {
+    arena_release_idle();
     std::vector<BlockCache::Blk> all;
     {
         std::lock_guard<std::mutex> lk(g_blocks.mu);
@@ -219,6 +313,7 @@ int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **out)
         if (hipMalloc(&warm, 256) == hipSuccess) (void)hipFree(warm);
         (void)hipGetLastError();
     }
+    bsig::arena_reserve(device);
     bsig_ctx *c = new bsig_ctx;
     {
         static std::mutex warm_mu;

@@ -35,11 +35,15 @@ constexpr size_t kBlockCacheMin = (size_t)8 << 20;
 hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, size_t *got);
 void block_free(int device, void *p, size_t bytes);
 void block_cache_release();
+// env BAMSIGNALS_ARENA_GB > 0: one allocation of that size made with the first context of a device; block_alloc
+// carves out of it first (runtime.hip)
+void arena_reserve(int device);
 }  // namespace bsig
 
-// owns a set of device allocations
+// owns a set of device allocations (all of them through block_alloc: the arena if there is one, the cache of
+// free blocks for large ones, hipMalloc otherwise)
 struct DevPool {
-    struct Blk { void *p; size_t bytes; int device; };       // device < 0: plain hipMalloc
+    struct Blk { void *p; size_t bytes; int device; };
     std::vector<Blk> blks;
     int64_t bytes = 0;
     template <typename T>
@@ -47,28 +51,19 @@ struct DevPool {
     {
         void *q = nullptr;
         const size_t nbytes = std::max<size_t>(count * sizeof(T), 16);
-        if (nbytes >= bsig::kBlockCacheMin) {
-            int dev = 0;
-            hipError_t e = hipGetDevice(&dev);
-            size_t got = 0;
-            if (e == hipSuccess) e = bsig::block_alloc(dev, nbytes, 1.125, &q, &got);      // long-lived: little slack
-            if (e != hipSuccess) { *p = nullptr; return e; }
-            blks.push_back(Blk{q, got, dev});
-        } else {
-            hipError_t e = hipMalloc(&q, nbytes);
-            if (e != hipSuccess) { *p = nullptr; return e; }
-            blks.push_back(Blk{q, nbytes, -1});
-        }
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        size_t got = 0;
+        if (e == hipSuccess) e = bsig::block_alloc(dev, nbytes, 1.125, &q, &got);      // long-lived: little slack
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        blks.push_back(Blk{q, got, dev});
         bytes += (int64_t)nbytes;
         *p = (T *)q;
         return hipSuccess;
     }
     void release()
     {
-        for (const Blk &b : blks) {
-            if (b.device >= 0) bsig::block_free(b.device, b.p, b.bytes);
-            else (void)hipFree(b.p);
-        }
+        for (const Blk &b : blks) bsig::block_free(b.device, b.p, b.bytes);
         blks.clear();
         bytes = 0;
     }

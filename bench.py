@@ -105,7 +105,7 @@ def _cold_call_child(spec_path):
     print(json.dumps(out), flush=True)
 
 
-def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=None, reps=2):
+def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=None, reps=2, arena_gb=0):
     """The cold file-level call as a NEW session sees it.  Why a child process: on this platform a hipMalloc
     stalls for 2-3 s once about 70 GB have been freed since the last stall (plain HIP, scripts/hipmalloc_stalls.py),
     and by the time the end-to-end sections run this process has allocated and freed well over that -- the
@@ -114,6 +114,10 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
     import subprocess
     spec = dict(bam=bam, names=list(names), ranges=os.path.join(workdir, tag + "_ranges.npz"), call=dict(call), device=int(device),
                 env=dict(env or {}), result=os.path.join(workdir, tag + "_result.npy"), reps=reps)
+    if arena_gb and "BAMSIGNALS_ARENA_GB" not in os.environ:
+        # the session reserves its device memory with the context (one allocation; the call itself then makes
+        # none): trips into the driver are where a call's time goes astray on a shared host
+        spec["env"]["BAMSIGNALS_ARENA_GB"] = str(int(arena_gb))
     spec["call"].pop("device", None)
     spec["call"]["device"] = int(device)
     spec["call"]["tlen_filter"] = list(spec["call"].get("tlen_filter", ()))
@@ -173,7 +177,8 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         call = dict(tlen_filter=args.get("tlen_filter", ()), mapqual=args.get("mapqual", 0), binsize=args.get("binsize", 1),
                     shift=args.get("shift", 0), ss=args.get("ss", False), requiredF=args.get("requiredF", 0),
                     filteredF=args.get("filteredF", -1), pe_mid=args.get("pe_mid", False), device=device)
-        child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device)
+        arena_gb = max(8, int(os.path.getsize(bam) * 16 / 2**30))          # scratch + resident reads of this file
+        child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device, arena_gb=arena_gb)
         t_cold, t_warm = child["calls"][0]["call_s"], child["calls"][1]["call_s"]
         stages = child["calls"][0]["stages_s"]
         if not np.array_equal(flat, want_flat):
@@ -201,6 +206,7 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
                    copy_wait_s=dd.get("copy_wait"), decode_ingest_GBps=os.path.getsize(bam) / max(dd.get("total") or 1e-9, 1e-9) / 1e9,
                    host_cpus_used=child["host_cpus_used"], hip_context_s=child["hip_context_s"], route=child["calls"][0]["route"],
                    measured_in="a fresh child process with its HIP context up (a new session's first BAM; see cold_call_in_fresh_process)",
+                   arena_gb=arena_gb,
                    cold_Mbases_s=bases / t_cold / 1e6, warm_Mbases_s=bases / t_warm / 1e6,
                    vs_cpu_path_cold=(t_dec1 + t_orc) / t_cold, vs_cpu_path_warm=(t_dec1 + t_orc) / t_warm,
                    note="pileup_core(bampath, GRanges) -> per-range arrays in host memory (PCIe-inclusive); compared "
@@ -245,23 +251,23 @@ def end_to_end_realistic(seed, device, oracle_c):
         call = dict(tlen_filter=(), device=device)
         for eng in ("default", "gpu", "cpu"):
             env = {} if eng == "default" else {"BAMSIGNALS_INFLATE": eng}
-            child, flat = cold_call_in_fresh_process(d, "real_" + eng, bam, ["ref1"], rg, call, device, env=env, reps=1)
+            child, flat = cold_call_in_fresh_process(d, "real_" + eng, bam, ["ref1"], rg, call, device, env=env, reps=1, arena_gb=16)
             if not np.array_equal(flat, want):
                 raise SystemExit("file-level result on the real-shaped BAM differs from the oracle")
             c0 = child["calls"][0]
             out["cold_" + eng] = dict(call_s=c0["call_s"], Mbases_s=bases / c0["call_s"] / 1e6, stages_s=c0["stages_s"],
                                       decode_stages_s=c0["stages_s"]["decode_stages_s"], route=c0["route"])
         # the on-disk reads file: written by one cold call, loaded by the next process
-        child, flat = cold_call_in_fresh_process(d, "side_w", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1)
+        child, flat = cold_call_in_fresh_process(d, "side_w", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1, arena_gb=16)
         t_make = child["calls"][0]["call_s"]
-        child, flat = cold_call_in_fresh_process(d, "side_r", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1)
+        child, flat = cold_call_in_fresh_process(d, "side_r", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1, arena_gb=16)
         t_load = child["calls"][0]["call_s"]
         if not np.array_equal(flat, want) or "sidecar" not in child["calls"][0]["route"]:
             raise SystemExit("the call from the reads file differs from the oracle")
         side = [f for f in os.listdir(d) if f.endswith(".bsig")]
         out["sidecar"] = dict(bytes=os.path.getsize(os.path.join(d, side[0])), cold_call_writing_it_s=t_make,
                               cold_call_loading_it_s=t_load, Mbases_s=bases / t_load / 1e6)
-        out["measured_in"] = "fresh child processes with their HIP context up (see cold_call_in_fresh_process)"
+        out["measured_in"] = "fresh child processes with their HIP context up and a 16-GB arena (see cold_call_in_fresh_process)"
         del flat
         b = BamFile(bam)
         dec = b.decode(threads=1)

@@ -74,6 +74,10 @@ void bsig_fast_width(int64_t n, const int64_t *length, int32_t ss, int32_t *widt
  * ------------------------------------------------------------------------------------------ */
 typedef struct bsig_ctx bsig_ctx;
 int bsig_device_count(int32_t *n);
+/* env BAMSIGNALS_ARENA_GB=<n> (default 0): the first context of a device reserves n GB of HBM in ONE allocation;
+ * scratch, resident reads and result buffers are carved out of it first, so that calls whose memory fits make no
+ * allocation of their own (every allocation is a trip into the driver, and on a shared host that is where a call's
+ * time goes astray).  An arena nobody holds a block of is released by bsig_cache_clear().               */
 int bsig_ctx_create(int32_t device, void *stream, bsig_ctx **ctx);
 void bsig_ctx_destroy(bsig_ctx *ctx);
 int bsig_ctx_sync(bsig_ctx *ctx);

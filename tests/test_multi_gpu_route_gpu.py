@@ -577,3 +577,28 @@ def test_segment_map_on_the_device(synth_bam):
         with pytest.raises(_lib.BsigError):
             SegmentMap(ctx, src_off, dst_off, w2)
         ctx.close()
+
+
+def test_arena_reserved_with_the_context(synth_bam, monkeypatch):
+    """BAMSIGNALS_ARENA_GB: one allocation made when a context comes up; scratch, resident reads and result
+    buffers are carved out of it (and come back to it), what does not fit takes the ordinary route; the results
+    are the same, and bsig_cache_clear() hands an idle arena back."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Context
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    want = _want(cols, rg)
+    for gb, devices in (("1", "0"), ("1", "0,0,0")):
+        monkeypatch.setenv("BAMSIGNALS_ARENA_GB", gb)
+        monkeypatch.setenv("BAMSIGNALS_DEVICES", devices)
+        monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+        monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+        _lib.load().bsig_cache_clear()
+        try:
+            Context(0).close()                               # (the arena comes with the first context)
+            for rep in range(3):
+                for a, b in zip(_three_calls(bam, gr), want):
+                    assert np.array_equal(a, b)
+        finally:
+            _lib.load().bsig_cache_clear()
+    monkeypatch.delenv("BAMSIGNALS_ARENA_GB")
+    _lib.load().bsig_cache_clear()
