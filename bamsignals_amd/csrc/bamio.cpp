@@ -919,7 +919,7 @@ int BgzfFile::open_progressive(const std::string &path, uint64_t head_bytes)
             const int thr = std::min(n_threads(0), 32);
             sc->run(0, kh, thr);
             uint64_t at = 0;
-            if (kh < sc->K && sc->stitch(0, kh, at, p_->blocks) && p_->blocks.size() > 64) {
+            if (kh < sc->K && sc->stitch(0, kh, at, p_->blocks) && p_->blocks.size() > 8) {
                 p_->scan = std::move(sc);
                 p_->k_head = kh;
                 p_->at = at;

@@ -546,8 +546,7 @@ struct Piece {
 void diag_mark(const char *what)
 {
     static thread_local double last = 0;
-    static const bool on = getenv("BSIG_DIAG_DECODE") != nullptr;
-    if (!on) return;
+    if (!getenv("BSIG_DIAG_DECODE")) return;
     const double t = now_s();
     if (what) fprintf(stderr, "  [decode] %-34s +%.1f ms\n", what, (t - last) * 1e3);
     last = t;
@@ -649,7 +648,7 @@ constexpr size_t kOverlapBlocks = 4;
 // more_follow: f.blocks() is only the head of the file's table (BgzfFile::open_progressive): the share cannot be
 // the stream's last, whatever its end.
 int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const std::vector<uint64_t> &uoff, size_t Bbeg,
-                 size_t Bend, int threads, bool gpu_inflate, ShareOut &R, bool more_follow = false)
+                 size_t Bend, int threads, bool gpu_inflate, ShareOut &R, bool more_follow = false, bool no_ramp = false)
 {
     const std::vector<BgzfBlock> &blocks = f.blocks();
     const size_t nb = blocks.size();
@@ -668,7 +667,8 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     // and only then the full chunk: the head of the pipeline waits for 0.3 GB instead of 1 GB of copies
     // (env BAMSIGNALS_FIRST_PASS_MB, 0 = no ramp).
     const char *ramp_env = getenv("BAMSIGNALS_FIRST_PASS_MB");
-    const uint64_t ramp0 = !gpu_inflate || (ramp_env && atoll(ramp_env) <= 0) ? 0 : env_mb("BAMSIGNALS_FIRST_PASS_MB", 2560);
+    // (the head share of a two-step decode IS the first pass: no ramp inside it)
+    const uint64_t ramp0 = !gpu_inflate || no_ramp || (ramp_env && atoll(ramp_env) <= 0) ? 0 : env_mb("BAMSIGNALS_FIRST_PASS_MB", 2560);
     // (a share that fits its first pass needs no room for a record carried from pass to pass)
     const uint64_t carry_cap = share_bytes <= (ramp0 ? std::min(chunk_cap, ramp0) : chunk_cap) ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
     auto cap_at = [&](size_t b0) -> uint64_t {
@@ -1173,6 +1173,8 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     {
         const char *e = getenv("BAMSIGNALS_SCAN_HEAD_MB");
         if (e && atoll(e) <= 0) head_bytes = ~0ull >> 2;                       // 0: the whole table first
+        if (const char *kb = getenv("BAMSIGNALS_SCAN_HEAD_KB"))                // (tests: a head of a few blocks)
+            if (atoll(kb) > 0) head_bytes = (uint64_t)atoll(kb) << 10;
     }
     int rc = scan_file(path, threads, F, head_bytes);
     if (rc) return rc;
@@ -1184,7 +1186,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         if (F.gpu_inflate && F.f.blocks().size() > 4 * kOverlapBlocks) {
             // the head share ends kOverlapBlocks before the end of what is tabulated: its last record may run on
             const size_t Bh = F.f.blocks().size() - kOverlapBlocks;
-            rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, Bh, threads, true, S, true);
+            rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, Bh, threads, true, S, true, true);
             diag_mark("decode_share (head)");
             const double tw = now_s();
             const int rc2 = finish_scan(path, F);                               // (waits for the background walk)

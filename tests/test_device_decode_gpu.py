@@ -304,6 +304,46 @@ def test_stream_in_chunks(ctx, tmp_path, monkeypatch, inflate):
     dev.close()
 
 
+def test_head_of_the_file_decoded_while_the_rest_is_tabulated(ctx, tmp_path, monkeypatch, capfd):
+    """Large files are decoded in two steps (GPU inflate): the head as a share of its own while the host walks the
+    rest of the block table, joined like the shares of several GPUs.  Forced here on small files: htslib's
+    fixture, files whose records cross block borders (the second share must find where the chain stands) and a
+    synthetic one with several references, with the stream also cut into many passes."""
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu")
+    monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", "16")
+    monkeypatch.setenv("BAMSIGNALS_SCAN_HEAD_KB", "200")
+    monkeypatch.setenv("BSIG_DIAG_DECODE", "1")
+    stream = gzip.decompress(open(BAM, "rb").read())
+    files = [BAM]
+    for k, sizes in enumerate(([4000, 9001, 517, 65000], [65536], [30000])):
+        p = tmp_path / ("straddle%d.bam" % k)
+        p.write_bytes(_bgzf(stream, sizes))
+        _empty_bai(str(p) + ".bai", 3)
+        files.append(str(p))
+    for chunk in (None, "1"):
+        if chunk:
+            monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", chunk)
+        for f in files:
+            capfd.readouterr()
+            _, dev = _both_ways(ctx, f, monkeypatch)
+            assert dev.n_reads == 99000
+            assert "decode_share (head)" in capfd.readouterr().err, f      # the two-step route was taken
+            dev.close()
+    monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB")
+    cols = synth_reads(1_500_000, [900_000, 70_000, 0, 400_000], seed=14, paired=True)
+    path = str(tmp_path / "syn.bam")
+    write_columns_as_bam(path, ["a", "b", "empty", "c"], cols)
+    for head_kb in ("300", "700", "3000"):
+        monkeypatch.setenv("BAMSIGNALS_SCAN_HEAD_KB", head_kb)
+        capfd.readouterr()
+        _, dev = _both_ways(ctx, path, monkeypatch)
+        assert dev.n_reads == 1_500_000
+        assert "decode_share (head)" in capfd.readouterr().err, head_kb
+        dev.close()
+
+
 def test_damaged_files_report_the_cpu_paths_errors(ctx, tmp_path, monkeypatch):
     """a truncated last record and an unsorted file: the device path declines, the CPU path names
     the problem"""
