@@ -140,6 +140,7 @@ def load():
     lib.bsig_debug_scratch_allocs.restype = C.c_int64
     lib.bsig_effective_cpus.restype = C.c_int32
     lib.bsig_debug_block_table.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    lib.bsig_debug_block_table_progressive.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
     lib.bsig_segmap_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.bsig_segmap_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bsig_segmap_free.argtypes = [C.c_void_p]

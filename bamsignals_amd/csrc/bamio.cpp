@@ -738,7 +738,9 @@ struct PreadScan {
                     while (hops < kHops && q < f.size && parse_block_fd(r, q, b)) { q += b.csize; ++hops; }
                     if (hops == kHops || (hops > 0 && q == f.size)) { start = c + i; found = true; }
                 }
-                if (!found) return;
+                // no block begins in this segment (the window covered all of it): fine if the chain of the
+                // segments before it runs past this one -- stitch() checks that
+                if (!found) { if (got >= next_cut - c) ok[k] = 2; return; }
             }
             first[k] = start;
             uint64_t o = start;
@@ -759,6 +761,10 @@ struct PreadScan {
     bool stitch(size_t k0, size_t k1, uint64_t &at, std::vector<Block> &blocks)
     {
         for (size_t k = k0; k < k1; ++k) {
+            if (ok[k] == 2) {                              // a segment inside one block
+                if (at < cut(k + 1)) return false;
+                continue;
+            }
             if (!ok[k] || first[k] != at) return false;
             at = last_end[k];
         }

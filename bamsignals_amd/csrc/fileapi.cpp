@@ -1167,6 +1167,28 @@ int bsig_debug_block_table(const char *path, int64_t *n_blocks, uint64_t *checks
     return BSIG_OK;
 }
 
+int bsig_debug_block_table_progressive(const char *path, int64_t head_bytes, int64_t *n_head, int64_t *n_blocks, uint64_t *checksum)
+{
+    // the same table in two steps (BgzfFile::open_progressive): *n_head = blocks tabulated before the rest was
+    // waited for (== *n_blocks when the file was tabulated whole at once)
+    if (!path || !n_head || !n_blocks || !checksum || head_bytes <= 0) return fail(BSIG_ERR_ARG, "bad argument");
+    bsig::BgzfFile f;
+    int rc = f.open_progressive(path, (uint64_t)head_bytes);
+    if (rc) return rc;
+    *n_head = (int64_t)f.blocks().size();
+    rc = f.finish();
+    if (rc) return rc;
+    uint64_t h = 1469598103934665603ull;
+    for (const bsig::BgzfBlock &b : f.blocks())
+        for (uint64_t v : {(uint64_t)b.coff, (uint64_t)b.csize, (uint64_t)b.doff, (uint64_t)b.dlen, (uint64_t)b.isize, (uint64_t)b.crc}) {
+            h ^= v;
+            h *= 1099511628211ull;
+        }
+    *n_blocks = (int64_t)f.blocks().size();
+    *checksum = h;
+    return BSIG_OK;
+}
+
 int64_t bsig_debug_scratch_allocs(void)
 {
     // allocations made so far for the multi-GPU result path's cached buffers (tests: flat across resident calls)

@@ -313,6 +313,10 @@ int64_t bsig_debug_scratch_allocs(void);
 /* diagnostic: number and a checksum of the BGZF blocks of a file as the device-side decode tabulates them
  * (env BAMSIGNALS_SCAN=mmap: the walk through the mapped file; default: through pread())              */
 int bsig_debug_block_table(const char *path, int64_t *n_blocks, uint64_t *checksum);
+/* ... and in two steps, as the whole-file decode tabulates large files: the head first (*n_head blocks), the
+ * rest in the background                                                                             */
+int bsig_debug_block_table_progressive(const char *path, int64_t head_bytes, int64_t *n_head, int64_t *n_blocks,
+                                       uint64_t *checksum);
 /* how the calling thread's last file-level call was carried out, e.g.
  * "8 GPU slot(s); reads: sharded decode, columns over rccl; result: xgmi/rccl"                  */
 const char *bsig_last_call_route(void);

@@ -348,6 +348,22 @@ def test_block_table_through_pread_equals_the_mapped_walk(tmp_path, monkeypatch)
     assert want[0] > 500
     for kb in ("8", "64", "1024", None):
         assert table(p, "pread", kb) == want
+    # the table in two steps (head first, the rest in the background), segments smaller than a block included
+    def progressive(path, head, seg_kb):
+        monkeypatch.setenv("BAMSIGNALS_SCAN", "pread")
+        monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", seg_kb)
+        nh, n, h = C.c_int64(), C.c_int64(), C.c_uint64()
+        _lib.check(lib.bsig_debug_block_table_progressive(path.encode(), head, C.byref(nh), C.byref(n), C.byref(h)))
+        return nh.value, (n.value, h.value)
+    want_fx = table(BAM, "mmap")
+    for kb in ("8", "16", "100"):
+        nh, got = progressive(BAM, 300 << 10, kb)
+        assert got == want_fx and 8 < nh < want_fx[0]
+    for kb, head in (("8", 1 << 20), ("64", 2 << 20), ("1024", 2 << 20)):
+        nh, got = progressive(p, head, kb)
+        assert got == want and 8 < nh < want[0], (kb, head, nh)
+    nh, got = progressive(p, 1 << 30, "64")                 # a head larger than the file: all at once
+    assert got == want and nh == want[0]
     # a file cut in the middle of a block: both walks refuse it with the same message
     raw = open(p, "rb").read()
     q = str(tmp_path / "cut.bam")
