@@ -1183,7 +1183,16 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     ShareOut S, S2;
     bool two = false;
     if (!F.f.complete()) {
-        if (F.gpu_inflate && F.f.blocks().size() > 4 * kOverlapBlocks) {
+        // worth two steps?  What is hidden is the walk over the REST of the table, one small read per block: 0.05 s
+        // for the north star's 327,000 blocks, 0.01 s for a real-shaped file of the same size (its blocks hold
+        // four times the compressed bytes) -- and there the extra launch costs more: k_inflate lasts one block's
+        // latency however few blocks it holds (2e7 real-shaped reads: 0.081 s in one step, 0.114 s in two).
+        const std::vector<BgzfBlock> &hb = F.f.blocks();
+        const uint64_t seen = hb.back().coff + hb.back().csize;
+        const double est_blocks = (double)hb.size() * (double)F.f.size() / (double)std::max<uint64_t>(seen, 1);
+        double min_blocks = 150000.0;
+        if (const char *e = getenv("BAMSIGNALS_TWO_STEP_MIN_BLOCKS")) min_blocks = atof(e);
+        if (F.gpu_inflate && hb.size() > 4 * kOverlapBlocks && est_blocks >= min_blocks) {
             // the head share ends kOverlapBlocks before the end of what is tabulated: its last record may run on
             const size_t Bh = F.f.blocks().size() - kOverlapBlocks;
             rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, Bh, threads, true, S, true, true);

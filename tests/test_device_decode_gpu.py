@@ -314,6 +314,7 @@ def test_head_of_the_file_decoded_while_the_rest_is_tabulated(ctx, tmp_path, mon
     monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu")
     monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", "16")
     monkeypatch.setenv("BAMSIGNALS_SCAN_HEAD_KB", "400")
+    monkeypatch.setenv("BAMSIGNALS_TWO_STEP_MIN_BLOCKS", "1")
     monkeypatch.setenv("BSIG_DIAG_DECODE", "1")
     stream = gzip.decompress(open(BAM, "rb").read())
     files = [BAM]
