@@ -177,7 +177,9 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         call = dict(tlen_filter=args.get("tlen_filter", ()), mapqual=args.get("mapqual", 0), binsize=args.get("binsize", 1),
                     shift=args.get("shift", 0), ss=args.get("ss", False), requiredF=args.get("requiredF", 0),
                     filteredF=args.get("filteredF", -1), pe_mid=args.get("pe_mid", False), device=device)
-        arena_gb = max(8, int(os.path.getsize(bam) * 16 / 2**30))          # scratch + resident reads of this file
+        # (no arena: measured on the same file, scripts/cold_call_scan_ab.py, a 44-GB arena makes the call 0.04 s
+        # slower -- first touches of its memory -- and it is only insurance against rare allocation stalls)
+        arena_gb = 0
         child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device, arena_gb=arena_gb)
         t_cold, t_warm = child["calls"][0]["call_s"], child["calls"][1]["call_s"]
         stages = child["calls"][0]["stages_s"]
@@ -251,23 +253,23 @@ def end_to_end_realistic(seed, device, oracle_c):
         call = dict(tlen_filter=(), device=device)
         for eng in ("default", "gpu", "cpu"):
             env = {} if eng == "default" else {"BAMSIGNALS_INFLATE": eng}
-            child, flat = cold_call_in_fresh_process(d, "real_" + eng, bam, ["ref1"], rg, call, device, env=env, reps=1, arena_gb=16)
+            child, flat = cold_call_in_fresh_process(d, "real_" + eng, bam, ["ref1"], rg, call, device, env=env, reps=1)
             if not np.array_equal(flat, want):
                 raise SystemExit("file-level result on the real-shaped BAM differs from the oracle")
             c0 = child["calls"][0]
             out["cold_" + eng] = dict(call_s=c0["call_s"], Mbases_s=bases / c0["call_s"] / 1e6, stages_s=c0["stages_s"],
                                       decode_stages_s=c0["stages_s"]["decode_stages_s"], route=c0["route"])
         # the on-disk reads file: written by one cold call, loaded by the next process
-        child, flat = cold_call_in_fresh_process(d, "side_w", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1, arena_gb=16)
+        child, flat = cold_call_in_fresh_process(d, "side_w", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1)
         t_make = child["calls"][0]["call_s"]
-        child, flat = cold_call_in_fresh_process(d, "side_r", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1, arena_gb=16)
+        child, flat = cold_call_in_fresh_process(d, "side_r", bam, ["ref1"], rg, call, device, env={"BAMSIGNALS_SIDECAR_DIR": d}, reps=1)
         t_load = child["calls"][0]["call_s"]
         if not np.array_equal(flat, want) or "sidecar" not in child["calls"][0]["route"]:
             raise SystemExit("the call from the reads file differs from the oracle")
         side = [f for f in os.listdir(d) if f.endswith(".bsig")]
         out["sidecar"] = dict(bytes=os.path.getsize(os.path.join(d, side[0])), cold_call_writing_it_s=t_make,
                               cold_call_loading_it_s=t_load, Mbases_s=bases / t_load / 1e6)
-        out["measured_in"] = "fresh child processes with their HIP context up and a 16-GB arena (see cold_call_in_fresh_process)"
+        out["measured_in"] = "fresh child processes with their HIP context up (see cold_call_in_fresh_process)"
         del flat
         b = BamFile(bam)
         dec = b.decode(threads=1)

@@ -25,11 +25,13 @@ del cols
 bench._settle(bam)
 rg = synth_ranges(100_000, 2000, ref, seed=10)
 call = dict(tlen_filter=(), device=0)
+variants = [("pread", {"BAMSIGNALS_SCAN": "pread"}, 0), ("mmap", {"BAMSIGNALS_SCAN": "mmap"}, 0), ("pread + 44-GB arena", {"BAMSIGNALS_SCAN": "pread"}, 44)]
 for rnd in range(3):
-    for how in ("pread", "mmap"):
-        child, flat = bench.cold_call_in_fresh_process(d, "ab", bam, names, rg, call, 0, env={"BAMSIGNALS_SCAN": how}, reps=1)
+    for how, env, arena in variants:
+        child, flat = bench.cold_call_in_fresh_process(d, "ab", bam, names, rg, call, 0, env=env, reps=1, arena_gb=arena)
         c = child["calls"][0]
         dd = c["stages_s"]["decode_stages_s"]
-        print(how, rnd, "call %.3f s" % c["call_s"], {k: round(v, 3) for k, v in dd.items()}, flush=True)
+        print(how, rnd, "call %.3f s" % c["call_s"], "context %.2f s" % child["hip_context_s"], {k: round(v, 3) for k, v in dd.items()},
+              "plan+run+download %.3f" % c["stages_s"]["plan_run_download"], flush=True)
 import shutil  # noqa: E402
 shutil.rmtree(d, ignore_errors=True)
