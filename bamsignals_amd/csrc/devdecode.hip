@@ -311,16 +311,38 @@ __global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ view, 
     const InflateJob j = jobs[i];
     const uint8_t *p = view + j.out_off;
     uint32_t crc = 0xFFFFFFFFu;
-    uint32_t k = 0;
-    // the words of the next two steps are on their way while this step's eight lookups run
-    uint64_t w0 = j.isize >= 8 ? bsig_inflate::load64(p) : 0, w1 = j.isize >= 16 ? bsig_inflate::load64(p + 8) : 0;
-    for (; k + 8 <= j.isize; k += 8) {
-        const uint64_t w = w0;
-        w0 = w1;
-        w1 = k + 24 <= j.isize ? bsig_inflate::load64(p + k + 16) : 0;
-        const uint32_t lo = crc ^ (uint32_t)w, hi = (uint32_t)(w >> 32);
+    auto step = [&](uint32_t a, uint32_t b) {            // eight bytes: a = the first four, b = the next four
+        const uint32_t lo = crc ^ a, hi = b;
         crc = T[7][lo & 0xFFu] ^ T[6][(lo >> 8) & 0xFFu] ^ T[5][(lo >> 16) & 0xFFu] ^ T[4][lo >> 24] ^
               T[3][hi & 0xFFu] ^ T[2][(hi >> 8) & 0xFFu] ^ T[1][(hi >> 16) & 0xFFu] ^ T[0][hi >> 24];
+    };
+    // Every lane reads its own block, so each load of a wave touches 64 different cache lines and eight waves per
+    // CU keep more lines in play than the L1 holds: with 8-byte loads every line came up from L2 sixteen times.
+    // A lane now takes a whole 128-byte line into registers at once (eight 16-byte loads), the next line is in
+    // flight while this one is folded: k_crc32 4.1 -> 2.x ms per 2 GB (it is the long pole of a pass's walk phase).
+    constexpr int W = 8;
+    constexpr uint32_t kChunk = 16u * W;
+    uint4 cur[W], nxt[W];
+    auto load_chunk = [&](uint4 (&c)[W], uint32_t at) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) memcpy(&c[q], p + at + 16 * q, 16);
+    };
+    const uint32_t n_chunks = j.isize / kChunk;
+    if (n_chunks) load_chunk(cur, 0);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) load_chunk(nxt, (c + 1) * kChunk);
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            step(cur[q].x, cur[q].y);
+            step(cur[q].z, cur[q].w);
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) cur[q] = nxt[q];
+    }
+    uint32_t k = n_chunks * kChunk;
+    for (; k + 8 <= j.isize; k += 8) {
+        const uint64_t w = bsig_inflate::load64(p + k);
+        step((uint32_t)w, (uint32_t)(w >> 32));
     }
     for (; k < j.isize; ++k) crc = T[0][(crc ^ p[k]) & 0xFFu] ^ (crc >> 8);
     if ((crc ^ 0xFFFFFFFFu) != j.crc) atomicMax(status, kErrCrc);
