@@ -85,6 +85,15 @@ def _check_gr(gr):
 
 def _split(out, off, ss):
     out.setflags(write=False)          # the signals are views of this buffer: read-only container
+    n = len(off) - 1
+    if n > 64:
+        # ranges of one width (tilings, fixed windows around features): the rows of ONE reshaped view -- a million
+        # per-range views cost 0.16 s this way, 0.35 s sliced one by one
+        w = int(off[1] - off[0])
+        if w > 0 and int(off[-1]) == n * w and bool(np.all(np.diff(off) == w)):
+            if ss:
+                return list(out[:n * w].reshape(n, w // 2, 2).transpose(0, 2, 1))
+            return list(out[:n * w].reshape(n, w))
     off = off.tolist()
     if ss:
         return [out[a:b].reshape(-1, 2).T for a, b in zip(off[:-1], off[1:])]
