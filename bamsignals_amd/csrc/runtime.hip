@@ -199,16 +199,20 @@ void block_free(int device, void *p, size_t bytes)
         if (cur != device) (void)hipSetDevice(cur);
         return;
     }
-    const size_t limit = block_cache_limit();
+    const size_t limit = block_cache_limit();          // per device: every GPU has its own HBM
     std::vector<BlockCache::Blk> drop;
     {
         std::lock_guard<std::mutex> lk(g_blocks.mu);
         g_blocks.free_.push_back(BlockCache::Blk{device, p, bytes});
         g_blocks.cached += bytes;
-        while (g_blocks.cached > limit && !g_blocks.free_.empty()) {
-            size_t big = 0;
-            for (size_t k = 1; k < g_blocks.free_.size(); ++k)
-                if (g_blocks.free_[k].bytes > g_blocks.free_[big].bytes) big = k;
+        for (;;) {
+            size_t on_dev = 0, big = (size_t)-1;
+            for (size_t k = 0; k < g_blocks.free_.size(); ++k) {
+                if (g_blocks.free_[k].dev != device) continue;
+                on_dev += g_blocks.free_[k].bytes;
+                if (big == (size_t)-1 || g_blocks.free_[k].bytes > g_blocks.free_[big].bytes) big = k;
+            }
+            if (on_dev <= limit || big == (size_t)-1) break;
             drop.push_back(g_blocks.free_[big]);
             g_blocks.cached -= g_blocks.free_[big].bytes;
             g_blocks.free_.erase(g_blocks.free_.begin() + (long)big);

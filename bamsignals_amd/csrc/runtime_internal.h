@@ -28,7 +28,7 @@ namespace bsig {
 // handed back in bulk).  A decode of the north star's BAM allocates and frees 25 GB of scratch, so every third
 // cold decode of a session paid that.  Blocks of kBlockCacheMin bytes or more therefore come from, and
 // return to, a per-process cache of free blocks (best fit within `max_waste`), bounded by env
-// BAMSIGNALS_SCRATCH_CACHE_GB (default 48; above it the largest free blocks are released first);
+// BAMSIGNALS_SCRATCH_CACHE_GB per GPU (default 48; above it the largest free blocks are released first);
 // bsig_cache_clear() releases all of it.
 constexpr size_t kBlockCacheMin = (size_t)8 << 20;
 // *got receives the block's real size (>= bytes), which block_free wants back
