@@ -88,35 +88,54 @@ def _cold_call_child(spec_path):
                  strand=[{1: "+", -1: "-", 0: "*"}[int(x)] for x in z["strand"]])
     call = spec["call"]
     call["tlen_filter"] = tuple(call["tlen_filter"])
-    t0 = time.perf_counter(); Context(spec["device"]).close(); t_ctx = time.perf_counter() - t0      # the HIP context
+    t0 = time.perf_counter(); Context(max(spec["device"], 0)).close(); t_ctx = time.perf_counter() - t0      # the HIP context
     out = dict(hip_context_s=t_ctx, calls=[])
     flat = None
+    per_rep_env = spec.get("per_rep_env") or []
     for rep in range(spec.get("reps", 2)):
+        if rep < len(per_rep_env):
+            for k, v in per_rep_env[rep].items():
+                os.environ[k] = v
         t0 = time.perf_counter(); sig = pileup_core(spec["bam"], gr, **call); dt = time.perf_counter() - t0
         st = last_call_timing()
         if rep == 0:
             st["decode_stages_s"] = Reads.device_decode_timing()
         out["calls"].append(dict(call_s=dt, stages_s=st, route=last_call_route()))
-        if rep == 0:
-            flat = np.concatenate([np.asarray(m).T.reshape(-1) if call.get("ss") else np.asarray(m) for m in sig]) if len(sig) else np.zeros(0, np.int32)
+        cur = np.concatenate([np.asarray(m).T.reshape(-1) if call.get("ss") else np.asarray(m) for m in sig]) if len(sig) else np.zeros(0, np.int32)
         del sig
+        if rep == 0:
+            flat = cur
+        elif not np.array_equal(cur, flat):
+            raise SystemExit(f"call {rep} of the child differs from its first call")
+        del cur
     out["host_cpus_used"] = int(_lib.load().bsig_effective_cpus())
-    np.save(spec["result"], flat)
+    if spec.get("result"):
+        np.save(spec["result"], flat)
+    # (large results are compared by value count, sum and a position-weighted sum instead of travelling back)
+    out["result_cells"] = int(flat.size)
+    out["result_sum"] = int(flat.sum(dtype=np.int64))
+    out["result_wsum"] = int((flat.astype(np.int64) * (np.arange(flat.size, dtype=np.int64) % 1000003)).sum()) if flat.size else 0
     print(json.dumps(out), flush=True)
 
 
-def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=None, reps=2, arena_gb=0):
+def result_fingerprint(flat):
+    flat = np.asarray(flat)
+    return (int(flat.size), int(flat.sum(dtype=np.int64)),
+            int((flat.astype(np.int64) * (np.arange(flat.size, dtype=np.int64) % 1000003)).sum()) if flat.size else 0)
+
+
+def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=None, reps=2, arena_gb=0, per_rep_env=None,
+                               want_result=True, timeout=None):
     """The cold file-level call as a NEW session sees it.  Why a child process: on this platform a hipMalloc
     stalls for 2-3 s once about 70 GB have been freed since the last stall (plain HIP, scripts/hipmalloc_stalls.py),
     and by the time the end-to-end sections run this process has allocated and freed well over that -- the
     stall would land in the timed call at random (it did: 0.47-0.79 s from run to run in round 2).  A session
-    that opens its first BAM has no such debt.  Returns (child's JSON, flat result of the cold call)."""
+    that opens its first BAM has no such debt.  Returns (child's JSON, flat result of the cold call or None)."""
     import subprocess
     spec = dict(bam=bam, names=list(names), ranges=os.path.join(workdir, tag + "_ranges.npz"), call=dict(call), device=int(device),
-                env=dict(env or {}), result=os.path.join(workdir, tag + "_result.npy"), reps=reps)
+                env=dict(env or {}), result=os.path.join(workdir, tag + "_result.npy") if want_result else None, reps=reps,
+                per_rep_env=list(per_rep_env or []))
     if arena_gb and "BAMSIGNALS_ARENA_GB" not in os.environ:
-        # the session reserves its device memory with the context (one allocation; the call itself then makes
-        # none): trips into the driver are where a call's time goes astray on a shared host (DESIGN.md 3a)
         spec["env"]["BAMSIGNALS_ARENA_GB"] = str(int(arena_gb))
     spec["call"].pop("device", None)
     spec["call"]["device"] = int(device)
@@ -127,12 +146,15 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
     child_env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         child_env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-cold", sp], capture_output=True, text=True, env=child_env)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-cold", sp], capture_output=True, text=True, env=child_env,
+                       timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"cold-call child failed ({r.returncode}): {r.stderr[-800:]}")
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    flat = np.load(spec["result"])
-    os.remove(spec["result"])
+    flat = None
+    if want_result:
+        flat = np.load(spec["result"])
+        os.remove(spec["result"])
     return out, flat
 
 
@@ -623,16 +645,16 @@ def strong_block(a, rank, world, stream, ctx, reads, cols, use_dist, dist, cdev,
 def in_process_block(a, world, ngpu, cols, cfg, rg, want_flat):
     """ONE process, N GPU slots, the file-level call (what an R session with BAMSIGNALS_DEVICES=0..N-1 does):
     the strong block's reads written to local disk as a BAM, cold call (every GPU inflates and parses its
-    share, column all-gather over xGMI, one layout per GPU) and warm calls under each gather route."""
+    share, column all-gather over xGMI, one layout per GPU) and warm calls under each gather route.  The session
+    is a child process with a time limit: RCCL inside the library has never met N > 1 physical GPUs on the
+    builder's boxes, and a communicator that does not come up must cost this block, not the bench's line."""
     import shutil
+    import subprocess
     import tempfile
 
-    from bamsignals_amd import GRanges, _lib
     from bamsignals_amd.bamio import write_columns_as_bam
     from bamsignals_amd.synth import add_cigar
-    from bamsignals_amd.wrappers import last_call_route, last_call_timing, pileup_core
     d = tempfile.mkdtemp(prefix="bsig_bench_inproc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    keep = {k: os.environ.get(k) for k in ("BAMSIGNALS_DEVICES", "BAMSIGNALS_DECODE", "BAMSIGNALS_GATHER")}
     try:
         if "cigar" not in cols:
             add_cigar(cols)
@@ -640,38 +662,31 @@ def in_process_block(a, world, ngpu, cols, cfg, rg, want_flat):
         bam = os.path.join(d, "c5.bam")
         t0 = time.perf_counter(); write_columns_as_bam(bam, names, cols, level=1); t_write = time.perf_counter() - t0
         cols.pop("cigar"); cols.pop("cigar_off")
-        gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"],
-                     strand=[{1: "+", -1: "-", 0: "*"}[int(x)] for x in rg["strand"]])
+        _settle(bam)
         devices = ",".join(str(r % ngpu) for r in range(world))
-        os.environ["BAMSIGNALS_DEVICES"] = devices
-        os.environ["BAMSIGNALS_DECODE"] = "all"
         out = dict(devices=devices, bam_bytes=os.path.getsize(bam), write_bam_s=t_write, ranges=len(rg["rid"]),
-                   note="pileup_core(bampath, GRanges) from ONE process over all listed GPU slots; results in host memory "
-                        "(PCIe-inclusive); every call checked against the strong block's 1-GPU result")
+                   note="pileup_core(bampath, GRanges) from ONE process (a child of rank 0, 240-s limit) over all listed GPU "
+                        "slots; results in host memory (PCIe-inclusive); every call checked against the strong block's 1-GPU "
+                        "result (cell count, sum, position-weighted sum; the warm calls cell by cell against the cold one)")
         bases = int(rg["len"].astype(np.int64).sum())
-        first = True
-        for gather in ("xgmi", "direct", "pcie"):
-            os.environ["BAMSIGNALS_GATHER"] = gather
-            runs = []
-            if first:
-                _lib.load().bsig_cache_clear()
-            for rep in (("cold", "warm", "warm") if first else ("warm", "warm")):
-                t0 = time.perf_counter(); sig = pileup_core(bam, gr, (), device=-1); dt = time.perf_counter() - t0
-                flat = np.concatenate(sig)
-                if not np.array_equal(flat, want_flat):
-                    raise SystemExit(f"in-process call ({gather}, {rep}) differs from the 1-GPU result")
-                del sig, flat
-                runs.append(dict(kind=rep, call_s=dt, Mbases_s=bases / dt / 1e6, stages_s=last_call_timing(), route=last_call_route()))
-            out[gather] = runs
-            first = False
-        _lib.load().bsig_cache_clear()
+        want = result_fingerprint(want_flat)
+        call = dict(tlen_filter=(), device=-1)
+        env = {"BAMSIGNALS_DEVICES": devices, "BAMSIGNALS_DECODE": "all", "BAMSIGNALS_GATHER": "xgmi"}
+        kinds = ["cold", "warm", "warm", "warm", "warm", "warm", "warm"]
+        gathers = ["xgmi", "xgmi", "xgmi", "direct", "direct", "pcie", "pcie"]
+        try:
+            child, _ = cold_call_in_fresh_process(d, "inproc", bam, names, rg, call, -1, env=env, reps=len(kinds),
+                                                  per_rep_env=[{"BAMSIGNALS_GATHER": g} for g in gathers], want_result=False, timeout=240)
+        except subprocess.TimeoutExpired:
+            out["error"] = "the in-process session did not finish within 240 s and was stopped"
+            return out
+        if (child["result_cells"], child["result_sum"], child["result_wsum"]) != want:
+            raise SystemExit("in-process calls differ from the 1-GPU result")
+        for kind, g, c in zip(kinds, gathers, child["calls"]):
+            out.setdefault(g, []).append(dict(kind=kind, call_s=c["call_s"], Mbases_s=bases / c["call_s"] / 1e6, stages_s=c["stages_s"],
+                                              route=c["route"]))
         return out
     finally:
-        for k, v in keep.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
         shutil.rmtree(d, ignore_errors=True)
 
 
