@@ -282,6 +282,12 @@ static_assert(sizeof(LaneSlot) % 8 == 4, "LaneSlot must be an odd number of dwor
 #ifndef BSIG_INFLATE_WAVES
 #define BSIG_INFLATE_WAVES 3
 #endif
+#ifdef BSIG_INFLATE_PROF
+// diagnostic build: per-lane counters of the first launches' lanes (scripts/inflate_prof.py)
+constexpr int kProfLanes = 1 << 17;
+struct ProfRow { bsig_inflate::LaneProf p; uint64_t cycles; uint32_t isize, in_len; };
+__device__ ProfRow g_prof_rows[kProfLanes];
+#endif
 template <int LANES>
 __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(BSIG_INFLATE_WAVES, 8))) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
                                                    int64_t n, uint8_t *__restrict__ out, uint8_t *__restrict__ lens,
@@ -292,10 +298,27 @@ __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(BSIG_INFL
     const int64_t i = (int64_t)blockIdx.x * LANES + threadIdx.x;
     if (i >= n) return;
     const InflateJob j = jobs[i];
+#ifdef BSIG_INFLATE_PROF
+    bsig_inflate::LaneProf pf{};
+    const uint64_t t0 = clock64();
+    const int rc = bsig_inflate::inflate_block(comp + j.in_off, j.in_len, out + j.out_off, j.isize, slots[threadIdx.x].t,
+                                               lens + i * bsig_inflate::kLensBytes, &pf);
+    if (i < kProfLanes) g_prof_rows[i] = ProfRow{pf, (uint64_t)clock64() - t0, j.isize, j.in_len};
+#else
     const int rc = bsig_inflate::inflate_block(comp + j.in_off, j.in_len, out + j.out_off, j.isize, slots[threadIdx.x].t,
                                                lens + i * bsig_inflate::kLensBytes);
+#endif
     if (rc) atomicMax(status, rc);
 }
+#ifdef BSIG_INFLATE_PROF
+}  // namespace
+extern "C" int bsig_debug_inflate_prof(void *rows, int64_t max_rows)
+{
+    const int64_t n = std::min<int64_t>(max_rows, kProfLanes);
+    return (int)hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_prof_rows), (size_t)n * sizeof(ProfRow));
+}
+namespace {
+#endif
 
 // The CRC32 of every inflated block against its trailer (htslib checks it; so does the CPU path):
 // one lane per block, 8 bytes per step through the slicing-by-8 tables (8 KB, in LDS).
@@ -356,9 +379,9 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
                           int *crc_status = nullptr, hipEvent_t crc_done = nullptr)
 {
     if (n <= 0) return hipSuccess;
-    // resident lanes per CU = min(160 KB / 548 B of first-level tables = 298, 8 waves (182 VGPRs) x LANES) in
-    // whole workgroups: 32 lanes per wave -> eight 17.5-KB workgroups = 256 lanes (160 while the sorted symbols
-    // and the construction scratch lived in LDS too: 964 B per lane)
+    // resident lanes per CU = min(160 KB / 676 B of LaneSlot = 242, 12 waves (168 VGPRs) x LANES) in whole
+    // workgroups: 32 lanes per wave -> seven 21-KB workgroups = 224 lanes (160 while all sorted symbols and the
+    // construction scratch lived in LDS too: 964 B per lane)
     int lanes = 32;
     if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
     // (tuning: extra LDS bytes per lane that nobody uses, to run the kernel at a lower occupancy -- 416 gives

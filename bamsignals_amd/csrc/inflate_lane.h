@@ -3,10 +3,14 @@
 // inside a block, is where the parallelism is).  Written for lanes that march together:
 //
 //   * Huffman decoding: an 8-bit (literal/length, 16-bit entries) and a 5-bit (distance, byte
-//     entries) first-level table answer nearly every symbol with one lookup; longer codes fall back
-//     to the canonical walk over the code lengths (per length the NUMBER of codes, packed two per
-//     register, and the symbols sorted by (length, value): an unrolled compare chain, then one
-//     lookup).  964 bytes per lane (LDS on the device), where zlib-style two-level tables need 5.7 KB;
+//     entries) first-level table answer nearly every symbol with one lookup; longer codes take
+//     the canonical walk over the code lengths (per length the NUMBER of codes, packed two per
+//     register, and the symbols sorted by (length, value)) from the first length the table does not
+//     cover, as a chain of compares WITHOUT branches, then one lookup.  672 bytes of LDS per lane on
+//     the device, where zlib-style two-level tables need 5.7 KB;
+//   * memory is waited for ONCE per turn of the main loop (see BSIG_VM_DRAIN in inflate_block): the
+//     compiler's waits are all-or-nothing (s_waitcnt vmcnt(0)), so every load whose value is needed
+//     at once stalls the wave for a whole trip and drains what else is in flight;
 //   * per turn of the main loop one symbol (up to six if they are literals the first-level table
 //     knows) OR a slice of a pending match: a lane that copies a 258-byte match does not hold the
 //     other lanes of its wave for 258 turns;
@@ -37,12 +41,22 @@ constexpr int kLFast = BSIG_LFAST, kDFast = 5;   // first-level table bits (lite
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
-// per-lane working storage that nearly every symbol touches (LDS on the device): 544 bytes.  How many lanes
-// are resident is what sets the speed (every turn of a lane is a chain of dependent steps), and LDS is what
-// limits them: 160 lanes per CU with everything below in LDS (964 bytes), 256 with only these two tables.
+// per-lane working storage that nearly every symbol touches (LDS on the device): 672 bytes.  How many lanes
+// are resident matters (every turn of a lane is a chain of dependent steps), and LDS is what limits them:
+// 160 lanes per CU with everything below in LDS (964 bytes), 288 with only the two first-level tables
+// (544 bytes), 224 with the hot long-code symbols beside them.
+#ifndef BSIG_HOT_SYMS
+#define BSIG_HOT_SYMS 128
+#endif
+constexpr int kHotSyms = BSIG_HOT_SYMS;      // (a multiple of 64) literal/length symbols with codes longer than the first-level table kept in LDS
 struct LaneTables {
     uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
     uint8_t dfast[1 << kDFast];    // distance: (symbol << 3) | code length (<= 5), 0 = longer code
+    // the first kHotSyms sorted symbols whose codes are LONGER than the first-level table (the shortest of the
+    // long codes, i.e. the most frequent of the rare symbols): what the walk looks up.  With all sorted symbols
+    // in global memory nearly every turn of a wave waited for one such load (32 lanes x up to six literals: some
+    // lane meets a long code), and a load that must be waited for drains the deferred match stores with it.
+    uint8_t lsym_hot[kHotSyms];
 };
 // ... and what only the table construction and the walk for codes longer than the first-level tables
 // touch: it lives behind the code-length scratch (global memory on the device)
@@ -51,26 +65,77 @@ struct ColdTables {
     uint16_t offs[16];             // scratch of the table construction
     uint16_t next[16];             // scratch: next canonical code of every length
     uint8_t lsym[288];             // literal/length symbols sorted by (code length, symbol), low 8 bits
-    uint8_t dsym[32];              // distance symbols sorted likewise (30 used; also the code-length code's)
 };
 
-// the sorted symbols of a code: 9-bit literal/length symbols as a byte + a bit, the others as bytes
+// keeps the compiler from folding the two homes of a sorted symbol (LDS, global memory) into ONE load through a
+// generic pointer: such a load waits for LDS and memory alike, and with it for every store in flight
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSIG_KEEP_APART() asm volatile("" ::: "memory")
+#else
+#define BSIG_KEEP_APART() do { } while (0)
+#endif
+
+// the sorted symbols of the literal/length code: the low 8 bits as bytes, bit 8 as a bit
 struct LSyms {
-    uint8_t *lo;
+    uint8_t *lo;            // ColdTables::lsym / lhi: every sorted position outside the hot window
     uint32_t *hi;
-    BSIG_HD void clear() const { for (int k = 0; k < 9; ++k) hi[k] = 0; }
-    BSIG_HD void put(int idx, int s) const
+    uint8_t *hot;           // LaneTables::lsym_hot: sorted positions [base, base + kHotSyms)
+    uint64_t hot_hi[kHotSyms / 64];     // their bit 8 (registers)
+    int base;               // first sorted position whose code is longer than the first-level table
+    BSIG_HD void clear()
     {
+        for (int k = 0; k < 9; ++k) hi[k] = 0;
+        for (int k = 0; k < kHotSyms / 64; ++k) hot_hi[k] = 0;
+    }
+    BSIG_HD void begin_long(int first_long_idx) { base = first_long_idx; }
+    BSIG_HD void put(int idx, int s)
+    {
+        const unsigned h = (unsigned)(idx - base);
+        if (h < (unsigned)kHotSyms) {
+            hot[h] = (uint8_t)s;
+            const uint64_t bit = (uint64_t)(s >> 8) << (h & 63);
+            for (int k = 0; k < kHotSyms / 64; ++k) hot_hi[k] |= (int)(h >> 6) == k ? bit : 0ull;
+            return;
+        }
         lo[idx] = (uint8_t)s;
         if (s >> 8) hi[idx >> 5] |= 1u << (idx & 31);
     }
-    BSIG_HD int get(int idx) const { return (int)lo[idx] | (int)(((hi[idx >> 5] >> (idx & 31)) & 1u) << 8); }
+    BSIG_HD int get(int idx) const
+    {
+        const unsigned h = (unsigned)(idx - base);
+        int r;
+        if (h < (unsigned)kHotSyms) {
+            uint64_t w = hot_hi[0];
+            for (int k = 1; k < kHotSyms / 64; ++k) w = (int)(h >> 6) == k ? hot_hi[k] : w;
+            r = (int)hot[h] | (int)((w >> (h & 63)) & 1ull) << 8;
+        } else {
+            BSIG_KEEP_APART();
+            r = (int)lo[idx] | (int)(((hi[idx >> 5] >> (idx & 31)) & 1u) << 8);
+            BSIG_KEEP_APART();
+        }
+        return r;
+    }
 };
+// the sorted symbols of the distance code (30) and of the code-length code (19): 5 bits each, twelve per
+// 64-bit word -- registers, so a distance code longer than its first-level table costs no trip to memory
 struct DSyms {
-    uint8_t *v;
-    BSIG_HD void clear() const {}
-    BSIG_HD void put(int idx, int s) const { v[idx] = (uint8_t)s; }
-    BSIG_HD int get(int idx) const { return v[idx]; }
+    uint64_t w[3];
+    BSIG_HD void clear() { w[0] = w[1] = w[2] = 0; }
+    BSIG_HD void begin_long(int) {}
+    BSIG_HD void put(int idx, int s)
+    {
+        const int q = idx >= 24 ? 2 : idx >= 12 ? 1 : 0;
+        const uint64_t v = (uint64_t)(s & 31) << (5 * (idx - 12 * q));
+        w[0] |= q == 0 ? v : 0ull;
+        w[1] |= q == 1 ? v : 0ull;
+        w[2] |= q == 2 ? v : 0ull;
+    }
+    BSIG_HD int get(int idx) const
+    {
+        const int q = idx >= 24 ? 2 : idx >= 12 ? 1 : 0;
+        const uint64_t x = q == 0 ? w[0] : q == 1 ? w[1] : w[2];
+        return (int)((x >> (5 * (idx - 12 * q))) & 31ull);
+    }
 };
 
 // number of codes of every length 1..15, two 16-bit counts per word (index len >> 1)
@@ -83,6 +148,7 @@ struct BitIn {
     const uint8_t *end;    // end of this block's deflate data
     uint64_t buf;          // bit buffer, next bit = bit 0
     uint64_t ahead;        // the 8 bytes at p, loaded a turn before they are needed
+    uint64_t amask;        // ... and which of them lie inside the input
     int cnt;               // valid bits in buf
 };
 
@@ -103,18 +169,37 @@ BSIG_HD uint64_t peek64(const uint8_t *p, const uint8_t *end)
     return v;
 }
 
+// requests the 8 bytes at in.p for the NEXT refill.
+// On the device this is ONE unconditional load whose result nobody touches before that refill: the address is
+// clamped to `end` (the 8 bytes there are readable -- a BGZF block's trailer follows its deflate data, see
+// inflate_block) and the bytes behind the input are masked off when they are taken.  With peek64's two paths
+// (a whole word, or the last bytes one by one) the value went through a register copy where the paths join,
+// and the compiler waits for a load before it copies it: every refill waited for the load it had just issued
+// (r03: 9,500 cycles per turn of a wave, profiles/r03_inflate_prof.txt).
+BSIG_HD void request(BitIn &in)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint8_t *q = in.p < in.end ? in.p : in.end;
+    const uint32_t avail = (uint32_t)(in.end - q);
+    in.amask = avail >= 8u ? ~0ull : (1ull << (8u * avail)) - 1ull;
+    in.ahead = load64(q);
+#else
+    in.amask = ~0ull;
+    in.ahead = peek64(in.p, in.end);
+#endif
+}
+
 // at least 56 valid bits afterwards.  The bytes come from `ahead`, which was loaded when the
 // previous refill finished: the load of the next 8 bytes is issued here and has a whole turn of
 // the main loop to arrive.
 BSIG_HD void refill(BitIn &in)
 {
-    const int nb = (64 - in.cnt) >> 3;           // whole bytes that fit
-    if (nb <= 0) return;
-    const uint64_t take_bits = nb >= 8 ? in.ahead : in.ahead & ((1ull << (8 * nb)) - 1);
-    in.buf |= take_bits << in.cnt;
+    const int nb = (64 - in.cnt) >> 3;           // whole bytes that fit (0: the same bytes are requested again)
+    const uint64_t take_bits = in.ahead & in.amask & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull);
+    in.buf |= nb > 0 ? take_bits << in.cnt : 0ull;
     in.cnt += 8 * nb;
     in.p += nb;
-    in.ahead = peek64(in.p, in.end);
+    request(in);
 }
 
 BSIG_HD uint32_t take(BitIn &in, int n)
@@ -155,33 +240,6 @@ BSIG_HD int decode_walk(BitIn &in, const Counts &c, const Syms &sym)
     return -1;
 }
 
-template <int FAST, typename Syms>
-BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const Syms &sym)
-{
-    if (FAST == 0) return decode_walk(in, c, sym);
-    const uint32_t e = fast[in.buf & ((1u << FAST) - 1)];
-    if (e) {
-        const int len = (int)(e & 15u);
-        in.buf >>= len;
-        in.cnt -= len;
-        return (int)(e >> 4);
-    }
-    return decode_walk(in, c, sym);
-}
-
-// a distance symbol: the 8-bit first-level table, else the walk
-BSIG_HD int decode_dist(BitIn &in, const uint8_t *fast, const Counts &c, const DSyms &sym)
-{
-    const uint32_t e = fast[in.buf & ((1u << kDFast) - 1)];
-    if (e) {
-        const int len = (int)(e & 7u);
-        in.buf >>= len;
-        in.cnt -= len;
-        return (int)(e >> 3);
-    }
-    return decode_walk(in, c, sym);
-}
-
 BSIG_HD uint32_t bit_reverse(uint32_t v, int n)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -191,6 +249,81 @@ BSIG_HD uint32_t bit_reverse(uint32_t v, int n)
     for (int k = 0; k < n; ++k) r |= ((v >> k) & 1u) << (n - 1 - k);
     return r;
 #endif
+}
+
+// where the walk stands after the lengths the first-level table covers (1..FAST): a code that table does not
+// hold is longer, so its walk starts here
+struct WalkStart {
+    int first, index;
+};
+template <int FAST>
+BSIG_HD WalkStart walk_start(const Counts &c)
+{
+    WalkStart w{0, 0};
+    for (int len = 1; len <= FAST; ++len) {
+        const int count = count_of(c, len);
+        w.index += count;
+        w.first += count;
+        w.first <<= 1;
+    }
+    return w;
+}
+
+// a symbol whose code is longer than FAST bits: the walk of decode_walk from length FAST + 1 on, WITHOUT
+// branches -- the lanes of a wave meet codes of different lengths, and an exit per length made the wave run
+// the rest of the chain once per distinct length, each exit with its own symbol lookup -- and ONE lookup.
+template <int FAST, typename Syms>
+BSIG_HD int decode_long(BitIn &in, const Counts &c, const Syms &sym, const WalkStart &ws)
+{
+    int code = (int)(bit_reverse((uint32_t)in.buf & ((1u << FAST) - 1u), FAST) << 1);
+    int first = ws.first, index = ws.index;
+    uint32_t b = (uint32_t)(in.buf >> FAST);
+    int hit_len = 0, hit_idx = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int len = FAST + 1; len <= 15; ++len) {
+        code |= (int)(b & 1u);
+        b >>= 1;
+        const int count = count_of(c, len);
+        const bool hit = hit_len == 0 && code - count < first;
+        hit_idx = hit ? index + (code - first) : hit_idx;
+        hit_len = hit ? len : hit_len;
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    if (hit_len == 0) return -1;
+    in.buf >>= hit_len;
+    in.cnt -= hit_len;
+    return sym.get(hit_idx);
+}
+
+template <int FAST>
+BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const LSyms &sym, const WalkStart &ws)
+{
+    const uint32_t e = fast[in.buf & ((1u << FAST) - 1)];
+    if (e) {
+        const int len = (int)(e & 15u);
+        in.buf >>= len;
+        in.cnt -= len;
+        return (int)(e >> 4);
+    }
+    return decode_long<FAST>(in, c, sym, ws);
+}
+
+// a distance symbol: the 5-bit first-level table, else the walk
+BSIG_HD int decode_dist(BitIn &in, const uint8_t *fast, const Counts &c, const DSyms &sym, const WalkStart &ws)
+{
+    const uint32_t e = fast[in.buf & ((1u << kDFast) - 1)];
+    if (e) {
+        const int len = (int)(e & 7u);
+        in.buf >>= len;
+        in.cnt -= len;
+        return (int)(e >> 3);
+    }
+    return decode_long<kDFast>(in, c, sym, ws);
 }
 
 // counts + sorted symbols + first-level table from n code lengths (0: symbol unused).  Returns
@@ -210,7 +343,7 @@ struct Fast8 {
 };
 
 template <int FAST, typename FastT, typename Syms, typename LenAt>
-BSIG_HD bool construct(Counts &c, const FastT &fast, const Syms &sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
+BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
 {
     sym.clear();
     for (int k = 0; k < 16; ++k) offs[k] = 0;
@@ -235,6 +368,9 @@ BSIG_HD bool construct(Counts &c, const FastT &fast, const Syms &sym, uint16_t *
         acc += cnt;
     }
     const bool use_fast = FAST > 0 && fast.on();
+    // (sorted positions from here on belong to codes the first-level table does not hold: offs[FAST + 1] is where
+    // length FAST + 1 begins, the total if there is no longer code)
+    sym.begin_long(FAST > 0 && FAST < 15 ? (int)offs[FAST + 1] : acc);
     if (use_fast)
         for (uint32_t k = 0; k < (1u << FAST); ++k) fast.zero(k);
     for (int i = 0; i < n; ++i) {
@@ -259,7 +395,7 @@ BSIG_HD int cl_order(int k)
 }
 
 constexpr int kLensCodes = 352;   // scratch of inflate_block: 32 for the code-length code + 316 lengths
-constexpr int kLensBytes = 784;   // ... + ColdTables (420 bytes) behind it; the scratch must be 4-byte aligned
+constexpr int kLensBytes = 784;   // ... + ColdTables (388 bytes) behind it; the scratch must be 4-byte aligned
 static_assert(kLensCodes % 4 == 0 && kLensCodes + (int)sizeof(ColdTables) <= kLensBytes, "scratch layout");
 
 // true once more bits were consumed than the input holds
@@ -276,21 +412,54 @@ BSIG_HD int dist_base(int s)    // distance symbols 0..29
 }
 BSIG_HD int dist_extra(int s) { return s < 4 ? 0 : (s >> 1) - 1; }
 
+// (diagnostic build -DBSIG_INFLATE_PROF, scripts/inflate_prof.py: what a lane's time goes to)
+struct LaneProf {
+    uint32_t turns, hdrs, walks, match_turns, lit_turns, lits;
+    uint64_t hdr_cycles;
+    // sections of a turn: 0 refill + first symbol, 1 further literals (+ the symbol behind them), 2 length/distance
+    // of a match, 3 the deferred stores, 4 the literals' store, 5 the match's loads (or its direct copy), 6 the turn
+    uint64_t sec_cycles[7];
+    uint32_t sec_n[7];
+};
+// device: wait until every load and store this lane's wave has issued is done (s_waitcnt vmcnt(0), gfx9 encoding)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSIG_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define BSIG_VM_DRAIN() do { } while (0)
+#endif
+#if defined(BSIG_INFLATE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define BSIG_PROF(x) do { if (prof) { x; } } while (0)
+#define BSIG_PROF_CLOCK() ((uint64_t)clock64())
+#define BSIG_SEC_BEGIN(k) const uint64_t sec_t##k = prof ? (uint64_t)clock64() : 0ull
+#define BSIG_SEC_END(k) do { if (prof) { prof->sec_cycles[k] += (uint64_t)clock64() - sec_t##k; prof->sec_n[k]++; } } while (0)
+#else
+#define BSIG_SEC_BEGIN(k) do { } while (0)
+#define BSIG_SEC_END(k) do { } while (0)
+#define BSIG_PROF(x) do { } while (0)
+#define BSIG_PROF_CLOCK() 0ull
+#endif
+
 // Inflates one raw DEFLATE stream of in_len bytes into exactly out_len bytes (nothing behind
 // out + out_len is touched).  lens: kLensBytes of scratch, 4-byte aligned (global memory on the device).
+// On the device the 8 bytes behind in_p + in_len must be readable (never used: see request()); the host build
+// reads nothing behind the input (tests/asan checks that).
 // Returns OK or an ERR_ code.
 BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, uint32_t out_len, LaneTables &T,
-                          uint8_t *lens)
+                          uint8_t *lens, LaneProf *prof = nullptr)
 {
+    (void)prof;
     BitIn in;
     in.p = in_p; in.end = in_p + in_len; in.buf = 0; in.cnt = 0;
-    in.ahead = peek64(in.p, in.end);
+    request(in);
     uint32_t op = 0;
     Counts lc, dc;
     ColdTables &Cd = *reinterpret_cast<ColdTables *>(lens + kLensCodes);
-    const LSyms ls{Cd.lsym, Cd.lhi};
-    const DSyms ds{Cd.dsym};
+    LSyms ls{Cd.lsym, Cd.lhi, T.lsym_hot, {}, 0};
+    DSyms ds;
+    ds.clear();
     for (;;) {
+        const uint64_t prof_t0 = BSIG_PROF_CLOCK();
+        (void)prof_t0;
         refill(in);
         const uint32_t last = take(in, 1);
         const uint32_t type = take(in, 2);
@@ -307,7 +476,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
             for (uint32_t k = 0; k < len; ++k) out[op + k] = src[k];
             op += len;
             in.p = src + len; in.buf = 0; in.cnt = 0;
-            in.ahead = peek64(in.p, in.end);
+            request(in);
         } else if (type == 3) {
             return ERR_CODE;
         } else {
@@ -363,18 +532,35 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
             // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
             // The bytes of a match are LOADED in the turn that meets it and STORED in the next one,
             // behind that turn's symbol decode: the trip to memory runs beside the decode. ----
+            const WalkStart lws = walk_start<kLFast>(lc), dws = walk_start<kDFast>(dc);
+            BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
             uint32_t pend = 0, pdist = 0;
             uint32_t dn = 0, dpos = 0;          // deferred stores: dn bytes (in 8-byte moves) at out + dpos
             uint64_t v[kTurn / 8];
             for (uint32_t k = 0; k < kTurn / 8; ++k) v[k] = 0;
             int err = OK;
+            // The compiler waits for memory with s_waitcnt vmcnt(0) wherever a loaded value is first used -- the
+            // exact counts are beyond it in a loop whose loads and stores sit under lane-dependent branches -- and
+            // that wait drains EVERYTHING in flight.  A turn's first use was the refill at its top, a few
+            // instructions behind the match loads the previous turn ends with: every turn stood still for one trip
+            // to memory (2,800 of its 8,900 cycles, profiles/r03_inflate_prof.txt).  The turn now waits ONCE, in
+            // its middle, where it needs the previous turn's match words: by then those loads have had the symbol
+            // decode to arrive in, and the input word requested at the top is as old.  The refill at the top then
+            // finds its word ready (the compiler sees the drain between the request and the use) and the loads the
+            // turn ends with are not waited for until the middle of the next one.
+            BSIG_VM_DRAIN();
             for (;;) {
                 uint64_t lit = 0;
                 uint32_t nlit = 0;
                 bool stop = false;
+                BSIG_PROF(prof->turns++; if (pend) prof->match_turns++);
+                BSIG_SEC_BEGIN(6);
                 if (pend == 0) {
+                    BSIG_SEC_BEGIN(0);
                     refill(in);
-                    int s = decode<kLFast>(in, T.lfast, lc, ls);
+                    BSIG_PROF(if (T.lfast[in.buf & ((1u << kLFast) - 1)] == 0) prof->walks++);
+                    int s = decode<kLFast>(in, T.lfast, lc, ls, lws);
+                    BSIG_SEC_END(0);
                     uint32_t opx = op;                 // where the next symbol's bytes will go
                     if (s < 256) {
                         if (s < 0) { err = ERR_CODE; stop = true; }
@@ -385,6 +571,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                             lit = (uint64_t)s;
                             nlit = 1;
                             s = -2;                    // nothing more this turn, unless a match follows
+                            BSIG_SEC_BEGIN(1);
                             if (kLFast > 0 && kMultiLit) {
 #if defined(__HIPCC__)
 #pragma unroll
@@ -404,13 +591,15 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                                     const uint32_t e = T.lfast[in.buf & ((1u << kLFast) - 1)];
                                     if (e && (e >> 4) > 256u) {
                                         refill(in);
-                                        s = decode<kLFast>(in, T.lfast, lc, ls);
+                                        s = decode<kLFast>(in, T.lfast, lc, ls, lws);
                                     }
                                 }
                             }
+                            BSIG_SEC_END(1);
                             opx = op + nlit;
                         }
                     }
+                    BSIG_SEC_BEGIN(2);
                     if (s == 256) {
                         stop = true;
                     } else if (s > 256) {
@@ -418,7 +607,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         if (s >= 29) { err = ERR_CODE; stop = true; }
                         else {
                             const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
-                            const int d = decode_dist(in, T.dfast, dc, ds);             // <= 20 + 28 of the 56 bits
+                            const int d = decode_dist(in, T.dfast, dc, ds, dws);             // <= 20 + 28 of the 56 bits
                             if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
                             else {
                                 const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
@@ -428,9 +617,12 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                                 else { pend = len; pdist = dist; }
                             }
                         }
+                        BSIG_SEC_END(2);
                     }
                 }
                 // the previous turn's match bytes
+                BSIG_VM_DRAIN();
+                BSIG_SEC_BEGIN(3);
                 if (dn) {
 #if defined(__HIPCC__)
 #pragma unroll
@@ -438,8 +630,11 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     for (uint32_t k = 0; k < kTurn / 8; ++k)
                         if (8 * k < dn) store64(out + dpos + 8 * k, v[k]);
                     dn = 0;
+                    BSIG_SEC_END(3);
                 }
                 if (stop) break;
+                BSIG_PROF(if (nlit) { prof->lit_turns++; prof->lits += nlit; });
+                BSIG_SEC_BEGIN(4);
                 if (nlit) {
                     if (op + 8 <= out_len) {
                         store64(out + op, lit);      // (what lies behind the literals is overwritten by what follows)
@@ -447,7 +642,9 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         for (uint32_t q = 0; q < nlit; ++q) out[op + q] = (uint8_t)(lit >> (8 * q));
                     }
                     op += nlit;
+                    BSIG_SEC_END(4);
                 }
+                BSIG_SEC_BEGIN(5);
                 if (pend) {
                     // up to kTurn bytes of the match per turn, in 8-byte moves.  A move may write up to 7
                     // bytes past the match (inside this block's own area: the next symbols overwrite
@@ -493,7 +690,9 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     }
                     op += n;
                     pend -= n;
+                    BSIG_SEC_END(5);
                 }
+                BSIG_SEC_END(6);
             }
             if (err) return err;
         }

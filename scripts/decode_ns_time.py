@@ -14,9 +14,11 @@ from bamsignals_amd.synth import synth_reads  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
 bam = "/tmp/ns_synth.bam"
-t = time.time(); cols = synth_reads(n, [250_000_000] * 10, seed=9); print("generate", round(time.time() - t, 1), flush=True)
-t = time.time(); write_columns_as_bam(bam, ["c%d" % i for i in range(10)], cols, level=1); print("write", round(time.time() - t, 1), os.path.getsize(bam), flush=True)
-del cols
+keep = os.environ.get("BSIG_KEEP_BAM") == "1"            # (A/B runs: several processes over the same file)
+if not (keep and os.path.exists(bam) and os.path.exists(bam + ".bai")):
+    t = time.time(); cols = synth_reads(n, [250_000_000] * 10, seed=9); print("generate", round(time.time() - t, 1), flush=True)
+    t = time.time(); write_columns_as_bam(bam, ["c%d" % i for i in range(10)], cols, level=1); print("write", round(time.time() - t, 1), os.path.getsize(bam), flush=True)
+    del cols
 ctx = Context(0)
 b = BamFile(bam)
 os.environ["BSIG_DIAG_DECODE"] = "1"
@@ -25,4 +27,5 @@ for rep in range(reps):
     t = time.time(); r = Reads.from_bam(ctx, b); dt = time.time() - t
     print("decode", rep, round(dt, 3), {k: round(v, 3) for k, v in Reads.device_decode_timing().items()}, flush=True)
     t = time.time(); r.close(); print("  free of the resident reads", round((time.time() - t) * 1e3, 1), "ms", flush=True)
-os.remove(bam); os.remove(bam + ".bai")
+if not keep:
+    os.remove(bam); os.remove(bam + ".bai")
