@@ -30,11 +30,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "bamio.h"
@@ -371,6 +373,54 @@ __global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ view, 
     if ((crc ^ 0xFFFFFFFFu) != j.crc) atomicMax(status, kErrCrc);
 }
 
+// blocks per wave and unused LDS bytes per lane of k_inflate (tuning knobs)
+int inflate_lanes_per_wave()
+{
+    int lanes = 32;
+    if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
+    return lanes == 64 || lanes == 32 || lanes == 16 || lanes == 4 ? lanes : 8;
+}
+size_t inflate_lds_pad()
+{
+    // (extra LDS bytes per lane that nobody uses, to run the kernel at a lower occupancy -- 340 gives the 160
+    // lanes per CU of the layout that kept the sorted symbols in LDS)
+    const char *e = getenv("BAMSIGNALS_INFLATE_LDS_PAD");
+    return e ? (size_t)std::max(0, atoi(e)) : 0;
+}
+
+// How many blocks k_inflate works on at once: the lanes the device keeps resident.  A launch lasts one block's
+// latency per ROUND of that many blocks, however full the last round is (r03, north star: 14.5 ms per round of
+// 57,344 -- passes of 72,882 / 41,133 / 82,266 / 130,881 blocks took 2 + 1 + 2 + 3 rounds where 6 would do), so
+// the passes of a decode are cut at multiples of it.
+size_t inflate_round_blocks(int device)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, std::pair<int, size_t>>, size_t> known;
+    const int lanes = inflate_lanes_per_wave();
+    const size_t pad = inflate_lds_pad();
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(device, std::make_pair(lanes, pad));
+    auto it = known.find(key);
+    if (it != known.end()) return it->second;
+    int cus = 0, wgs = 0;
+    const size_t lds = (size_t)lanes * (sizeof(LaneSlot) + pad);
+    hipError_t e = hipSetDevice(device);                    // (the occupancy query speaks of the current device)
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e == hipSuccess) {
+        switch (lanes) {
+        case 64: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<64>, 64, lds); break;
+        case 32: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<32>, 32, lds); break;
+        case 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<16>, 16, lds); break;
+        case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<4>, 4, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<8>, 8, lds); break;
+        }
+    }
+    const size_t c = e == hipSuccess && cus > 0 && wgs > 0 ? (size_t)cus * (size_t)wgs * (size_t)lanes : 0;
+    (void)hipGetLastError();
+    known[key] = c;
+    return c;
+}
+
 // crc_st != nullptr: the CRC kernel runs there, behind `inflated` (an event the caller owns), beside
 // whatever the caller queues on st next -- it keeps two waves per CU busy and so does the record walk;
 // its verdict lands in `crc_status`, which the caller reads once crc_st has drained.
@@ -382,12 +432,8 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
     // resident lanes per CU = min(160 KB / 676 B of LaneSlot = 242, 12 waves (168 VGPRs) x LANES) in whole
     // workgroups: 32 lanes per wave -> seven 21-KB workgroups = 224 lanes (160 while all sorted symbols and the
     // construction scratch lived in LDS too: 964 B per lane)
-    int lanes = 32;
-    if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
-    // (tuning: extra LDS bytes per lane that nobody uses, to run the kernel at a lower occupancy -- 416 gives
-    // the 160 lanes per CU of the layout that kept the sorted symbols in LDS)
-    size_t lds_pad = 0;
-    if (const char *e = getenv("BAMSIGNALS_INFLATE_LDS_PAD")) lds_pad = (size_t)std::max(0, atoi(e));
+    const int lanes = inflate_lanes_per_wave();
+    const size_t lds_pad = inflate_lds_pad();
     switch (lanes) {
     case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
     case 32: hipLaunchKernelGGL(k_inflate<32>, dim3((unsigned)((n + 31) / 32)), dim3(32), 32 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
@@ -708,12 +754,18 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         if (v > 0) batch_bytes = (size_t)v * 65536u;
     }
     // With the GPU inflating, nothing can overlap the trip of the FIRST pass's compressed bytes to HBM, so the
-    // first pass is one round of resident inflate lanes (40,960 blocks, 2.5 GiB of stream), the second two,
-    // and only then the full chunk: the head of the pipeline waits for 0.3 GB instead of 1 GB of copies
-    // (env BAMSIGNALS_FIRST_PASS_MB, 0 = no ramp).
+    // first pass is one round of resident inflate lanes (57,344 blocks, 3.5 GiB of stream), the second two,
+    // and only then the full chunk: the head of the pipeline waits for 0.4 GB instead of 1 GB of copies
+    // (env BAMSIGNALS_FIRST_PASS_MB: another first pass, 0 = no ramp).  Every pass that is not the share's last
+    // is a whole number of rounds (inflate_round_blocks).
     const char *ramp_env = getenv("BAMSIGNALS_FIRST_PASS_MB");
+    const size_t round_blocks = gpu_inflate ? inflate_round_blocks(ctx->device) : 0;
     // (the head share of a two-step decode IS the first pass: no ramp inside it)
-    const uint64_t ramp0 = !gpu_inflate || no_ramp || (ramp_env && atoll(ramp_env) <= 0) ? 0 : env_mb("BAMSIGNALS_FIRST_PASS_MB", 2560);
+    // (a share of up to two rounds: two passes of half of it each -- the first copy is what nothing hides)
+    const size_t share_blocks = Bend - Bbeg;
+    const size_t first_blocks = share_blocks > round_blocks ? std::min(round_blocks, (share_blocks + 1) / 2) : share_blocks;
+    const uint64_t ramp0 = !gpu_inflate || no_ramp || (ramp_env && atoll(ramp_env) <= 0) ? 0
+                           : ramp_env || !round_blocks ? env_mb("BAMSIGNALS_FIRST_PASS_MB", 2560) : (uint64_t)first_blocks << 16;
     // (a share that fits its first pass needs no room for a record carried from pass to pass)
     const uint64_t carry_cap = share_bytes <= (ramp0 ? std::min(chunk_cap, ramp0) : chunk_cap) ? 0 : env_mb("BAMSIGNALS_DEVICE_DECODE_CARRY_MB", 64);
     auto cap_at = [&](size_t b0) -> uint64_t {
@@ -727,6 +779,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         uint64_t bytes = 0;
         const uint64_t cap = cap_at(b0);
         while (b1 < Bend && (b1 == b0 || bytes + blocks[b1].isize <= cap)) bytes += blocks[b1++].isize;
+        if (b1 < Bend && round_blocks && b1 - b0 > round_blocks) b1 = b0 + (b1 - b0) / round_blocks * round_blocks;
         return b1;
     };
     auto view_end = [&](size_t b1) { return (b1 == Bend && !last_share) ? std::min(nb, Bend + kOverlapBlocks) : b1; };
@@ -1239,7 +1292,10 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
         if (const char *e = getenv("BAMSIGNALS_TWO_STEP_MIN_BLOCKS")) min_blocks = atof(e);
         if (F.gpu_inflate && hb.size() > 4 * kOverlapBlocks && est_blocks >= min_blocks) {
             // the head share ends kOverlapBlocks before the end of what is tabulated: its last record may run on
-            const size_t Bh = F.f.blocks().size() - kOverlapBlocks;
+            // ... and holds whole rounds of inflate lanes (the blocks behind them go with the rest)
+            size_t Bh = F.f.blocks().size() - kOverlapBlocks;
+            const size_t round_blocks = inflate_round_blocks(ctx->device);
+            if (round_blocks && Bh + kOverlapBlocks > round_blocks) Bh = (Bh + kOverlapBlocks) / round_blocks * round_blocks - kOverlapBlocks;
             rc = decode_share(ctx, F.f, F.hdr, F.uoff, 0, Bh, threads, true, S, true, true);
             diag_mark("decode_share (head)");
             const double tw = now_s();

@@ -41,10 +41,13 @@ constexpr int kLFast = BSIG_LFAST, kDFast = 5;   // first-level table bits (lite
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
-// per-lane working storage that nearly every symbol touches (LDS on the device): 672 bytes.  How many lanes
-// are resident matters (every turn of a lane is a chain of dependent steps), and LDS is what limits them:
-// 160 lanes per CU with everything below in LDS (964 bytes), 288 with only the two first-level tables
-// (544 bytes), 224 with the hot long-code symbols beside them.
+// per-lane working storage that nearly every symbol touches (LDS on the device): 672 bytes = 224 lanes per CU
+// (160 with the cold tables in LDS as well).  More would not help a big file: a lane's turn takes 6,000-7,000
+// cycles however many waves share its SIMD, but each resident lane also keeps three or four 128-byte lines live in
+// L2 (the output line it is writing, its input line, the line its matches copy from) and 4 MB per XCD is 32,768
+// lines: from ~160 lanes per CU on the L2 evicts half-written lines (r03 counters at 285 lanes per CU: TCC busy all
+// the time, one HBM write per two stores), and 12-bit first-level entries + 64 hot symbols (480 bytes, 320 lanes)
+// decoded the north star's file no faster and a small file 7 % slower.
 #ifndef BSIG_HOT_SYMS
 #define BSIG_HOT_SYMS 128
 #endif
@@ -300,10 +303,16 @@ BSIG_HD int decode_long(BitIn &in, const Counts &c, const Syms &sym, const WalkS
     return sym.get(hit_idx);
 }
 
-template <int FAST>
-BSIG_HD int decode(BitIn &in, const uint16_t *fast, const Counts &c, const LSyms &sym, const WalkStart &ws)
+// first-level entry of the literal/length code for the next bits: (symbol << 4) | code length, 0 = longer code
+BSIG_HD uint32_t lfast_at(const LaneTables &T, uint64_t buf)
 {
-    const uint32_t e = fast[in.buf & ((1u << FAST) - 1)];
+    return T.lfast[(uint32_t)buf & ((1u << kLFast) - 1u)];
+}
+
+template <int FAST>
+BSIG_HD int decode(BitIn &in, const LaneTables &T, const Counts &c, const LSyms &sym, const WalkStart &ws)
+{
+    const uint32_t e = lfast_at(T, in.buf);
     if (e) {
         const int len = (int)(e & 15u);
         in.buf >>= len;
@@ -418,8 +427,11 @@ struct LaneProf {
     uint64_t hdr_cycles;
     // sections of a turn: 0 refill + first symbol, 1 further literals (+ the symbol behind them), 2 length/distance
     // of a match, 3 the deferred stores, 4 the literals' store, 5 the match's loads (or its direct copy), 6 the turn
-    uint64_t sec_cycles[7];
-    uint32_t sec_n[7];
+    uint64_t sec_cycles[8];     // (7: the wait in the middle of the turn)
+    uint32_t sec_n[8];
+    uint32_t short_period;      // matches with a distance below 8
+    uint32_t long_dist;         // distance codes longer than the first-level table
+    uint32_t pad_[2];
 };
 // device: wait until every load and store this lane's wave has issued is done (s_waitcnt vmcnt(0), gfx9 encoding)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -535,6 +547,9 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
             const WalkStart lws = walk_start<kLFast>(lc), dws = walk_start<kDFast>(dc);
             BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
             uint32_t pend = 0, pdist = 0;
+            uint32_t pper = 0, pdone = 0;      // the match's period (its distance as coded) and how much of it is out
+            uint64_t wpat = 0;                 // short period: the bytes before the match, asked for a turn ahead
+            uint32_t pp = 0;                   // ... and whether they were
             uint32_t dn = 0, dpos = 0;          // deferred stores: dn bytes (in 8-byte moves) at out + dpos
             uint64_t v[kTurn / 8];
             for (uint32_t k = 0; k < kTurn / 8; ++k) v[k] = 0;
@@ -558,8 +573,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 if (pend == 0) {
                     BSIG_SEC_BEGIN(0);
                     refill(in);
-                    BSIG_PROF(if (T.lfast[in.buf & ((1u << kLFast) - 1)] == 0) prof->walks++);
-                    int s = decode<kLFast>(in, T.lfast, lc, ls, lws);
+                    BSIG_PROF(if (lfast_at(T, in.buf) == 0) prof->walks++);
+                    int s = decode<kLFast>(in, T, lc, ls, lws);
                     BSIG_SEC_END(0);
                     uint32_t opx = op;                 // where the next symbol's bytes will go
                     if (s < 256) {
@@ -577,7 +592,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
 #pragma unroll
 #endif
                                 for (int q = 1; q < 6; ++q) {
-                                    const uint32_t e = T.lfast[in.buf & ((1u << kLFast) - 1)];
+                                    const uint32_t e = lfast_at(T, in.buf);
                                     if (e == 0 || (e >> 4) >= 256u || in.cnt < 2 * kLFast || op + (uint32_t)q >= out_len) break;
                                     const int len = (int)(e & 15u);
                                     in.buf >>= len;
@@ -588,10 +603,10 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                                 // a match right behind the literals rides in the same turn (its bits come
                                 // with a second refill; the words it needs were requested a turn ago)
                                 if (in.cnt >= kLFast) {
-                                    const uint32_t e = T.lfast[in.buf & ((1u << kLFast) - 1)];
+                                    const uint32_t e = lfast_at(T, in.buf);
                                     if (e && (e >> 4) > 256u) {
                                         refill(in);
-                                        s = decode<kLFast>(in, T.lfast, lc, ls, lws);
+                                        s = decode<kLFast>(in, T, lc, ls, lws);
                                     }
                                 }
                             }
@@ -607,6 +622,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         if (s >= 29) { err = ERR_CODE; stop = true; }
                         else {
                             const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
+                            BSIG_PROF(if (T.dfast[in.buf & ((1u << kDFast) - 1)] == 0) prof->long_dist++);
                             const int d = decode_dist(in, T.dfast, dc, ds, dws);             // <= 20 + 28 of the 56 bits
                             if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
                             else {
@@ -614,14 +630,16 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                                 if (dist > opx) { err = ERR_DIST; stop = true; }
                                 else if (opx + len > out_len) { err = ERR_OUTPUT; stop = true; }
                                 else if (overrun(in)) { err = ERR_INPUT; stop = true; }
-                                else { pend = len; pdist = dist; }
+                                else { pend = len; pdist = dist; pper = dist; pdone = 0; }
                             }
                         }
                         BSIG_SEC_END(2);
                     }
                 }
                 // the previous turn's match bytes
+                BSIG_SEC_BEGIN(7);
                 BSIG_VM_DRAIN();
+                BSIG_SEC_END(7);
                 BSIG_SEC_BEGIN(3);
                 if (dn) {
 #if defined(__HIPCC__)
@@ -654,40 +672,70 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         if (pdist < 8) {
                             // short period (runs, 2- and 3-byte patterns): the first 8 bytes come from a
                             // pattern built in registers; behind them the same bytes repeat at a distance
-                            // that is a multiple of the period and >= 8, so the rest is ordinary moves
-                            const uint64_t w = load64(out + op - pdist);      // its low `pdist` bytes are valid
-                            uint64_t pat = 0;
-                            uint32_t j = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                            for (int i = 0; i < 8; ++i) {
-                                pat |= ((w >> (8 * j)) & 0xFFull) << (8 * i);
-                                j = j + 1 == pdist ? 0 : j + 1;
+                            // that is a multiple of the period and >= 8, so the rest is ordinary moves.
+                            // The period's bytes are the literals of this very turn if there are enough of
+                            // them (a run starts as "one literal, then the match at distance 1"); else they
+                            // are ASKED for now and the pattern is built next turn -- waiting for them here
+                            // would drain the stores this turn has just issued (r03: 5 % of the north
+                            // star's matches are of this kind, so some lane of a wave met one in four turns
+                            // out of five, 900 cycles each).
+                            uint64_t w = wpat;                                // its low `pdist` bytes are valid
+                            bool have = pp != 0;
+                            pp = 0;
+                            if (!have && pdist <= nlit) {
+                                w = lit >> (8u * (nlit - pdist));
+                                have = true;
                             }
-                            store64(out + op, pat);
-                            const uint32_t m = n < 8u ? n : 8u;
-                            op += m; pend -= m; n -= m;
-                            pdist *= (7u + pdist) / pdist;                    // smallest multiple of the period >= 8
-                        }
-                        const uint8_t *from = out + op - pdist;
-                        if (pdist >= ((n + 7u) & ~7u)) {
-                            // the source lies wholly behind the destination: all loads now, the stores in
-                            // the next turn
+                            // (the pattern first, the request behind it: a request issued BEFORE the other
+                            // lanes read `wpat` would make them wait for it)
+                            const bool ask = !have;
+                            if (have) {
+                                uint64_t pat = 0;
+                                uint32_t j = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-                            for (uint32_t k = 0; k < kTurn / 8; ++k)
-                                if (8 * k < n) v[k] = load64(from + 8 * k);
-                            dn = n;
-                            dpos = op;
-                        } else {
-                            for (uint32_t k = 0; k < n; k += 8) store64(out + op + k, load64(from + k));
+                                for (int i = 0; i < 8; ++i) {
+                                    pat |= ((w >> (8 * j)) & 0xFFull) << (8 * i);
+                                    j = j + 1 == pdist ? 0 : j + 1;
+                                }
+                                store64(out + op, pat);
+                                const uint32_t m = n < 8u ? n : 8u;
+                                op += m; pend -= m; n -= m;
+                                // smallest multiple of the period >= 8 (periods 1..7: 8 8 9 8 10 12 14)
+                                pdist = (0xECA8988u >> (4u * (pdist - 1u))) & 15u;
+                                pper = pdist;
+                                pdone = 0;
+                            }
+                            if (ask) {
+                                BSIG_PROF(prof->short_period++);
+                                wpat = load64(out + op - pdist);
+                                pp = 1;
+                                n = 0;
+                            }
                         }
+                        // a source that overlaps the destination (period < the slice): the bytes repeat with
+                        // that period, so once enough of them are out the SAME bytes lie further back as
+                        // well -- the distance doubles (it stays a multiple of the period) -- and until then
+                        // the slice stops where the source would run into it.  Every slice is then loads
+                        // from bytes that are all there, stored next turn: no load-wait-store chain, which
+                        // for the bare reads of the north star's file (a 36-byte record repeats most of the
+                        // previous one: distances below 64 are the rule) was a quarter of a turn.
+                        if (pdist < kTurn && pdone + pper >= 2u * pdist) pdist *= 2u;
+                        if (pdist < ((n + 7u) & ~7u)) n = pdist & ~7u;               // (>= 8: pdist >= 8 here)
+                        const uint8_t *from = out + op - pdist;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                        for (uint32_t k = 0; k < kTurn / 8; ++k)
+                            if (8 * k < n) v[k] = load64(from + 8 * k);
+                        dn = n;
+                        dpos = op;
                     } else {
                         const uint8_t *from = out + op - pdist;
                         for (uint32_t k = 0; k < n; ++k) out[op + k] = from[k];      // byte by byte: overlaps repeat
                     }
+                    pdone += n;
                     op += n;
                     pend -= n;
                     BSIG_SEC_END(5);

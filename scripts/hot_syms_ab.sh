@@ -1,4 +1,4 @@
-# Diagnostic: k_inflate with 64 / 128 of the long-code symbols in LDS (inflate_lane.h kHotSyms; 256 / 224
+# Diagnostic: k_inflate with 128 (default) / 64 of the long-code symbols in LDS (inflate_lane.h kHotSyms; 224 / 256
 # resident lanes per CU), on the real-shaped file and on the north star's.  Needs
 #   (cd bamsignals_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
 #     -mllvm -amdgpu-kernarg-preload-count=8 -DBSIG_HOT_SYMS=64 -shared -o ../libbamsignals_hip_hot64.so \

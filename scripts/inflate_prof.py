@@ -45,9 +45,9 @@ for rep in range(2):
     print({k: round(v, 4) for k, v in Reads.device_decode_timing().items()}, flush=True)
     r.close()
 row = np.dtype([("turns", "<u4"), ("hdrs", "<u4"), ("walks", "<u4"), ("match_turns", "<u4"), ("lit_turns", "<u4"), ("lits", "<u4"),
-                ("hdr_cycles", "<u8"), ("sec_cycles", "<u8", (7,)), ("sec_n", "<u4", (7,)), ("pad", "<u4"),
-                ("cycles", "<u8"), ("isize", "<u4"), ("in_len", "<u4")])
-assert row.itemsize == 136
+                ("hdr_cycles", "<u8"), ("sec_cycles", "<u8", (8,)), ("sec_n", "<u4", (8,)), ("short_period", "<u4"),
+                ("long_dist", "<u4"), ("pad", "<u4", (2,)), ("cycles", "<u8"), ("isize", "<u4"), ("in_len", "<u4")])
+assert row.itemsize == 160
 n = 1 << 17
 rows = np.zeros(n, dtype=row)
 lib = _lib.load()
@@ -60,7 +60,8 @@ full = rows[: len(rows) // lanes * lanes].reshape(-1, lanes)
 f = lambda a: "%.4g" % float(np.mean(a))
 print("per lane: isize", f(rows["isize"]), "in_len", f(rows["in_len"]), "deflate blocks", f(rows["hdrs"]), "turns", f(rows["turns"]),
       "literal turns", f(rows["lit_turns"]), "literals", f(rows["lits"]), "match-slice turns", f(rows["match_turns"]),
-      "first-level misses", f(rows["walks"]))
+      "first-level misses", f(rows["walks"]), "matches at a distance below 8", f(rows["short_period"]),
+      "distance codes beyond their first-level table", f(rows["long_dist"]))
 print("per lane: cycles", f(rows["cycles"]), "cycles before the first symbol of its deflate blocks", f(rows["hdr_cycles"]),
       "= %.3f of the lane's time; per deflate block %.4g cycles" % (rows["hdr_cycles"].sum() / rows["cycles"].sum(), rows["hdr_cycles"].sum() / max(1, rows["hdrs"].sum())))
 wc = full["cycles"].max(axis=1).astype(np.float64)
@@ -70,7 +71,7 @@ print("per wave (%d lanes): cycles" % lanes, f(wc), "; longest lane's turns", f(
 print("per wave: turns in which SOME lane missed the first-level table: at most", f(np.minimum(full["walks"].sum(axis=1), full["turns"].max(axis=1))),
       "of", f(full["turns"].max(axis=1)))
 names = ["refill + first symbol", "further literals (+ symbol behind them)", "length/distance of a match", "deferred stores",
-         "literals' store", "match loads / direct copy", "whole turn"]
+         "literals' store", "match loads / direct copy", "whole turn", "the wait for memory (between 2 and 3)"]
 turn = rows["sec_cycles"][:, 6].sum() / rows["sec_n"][:, 6].sum()
 for k, nm in enumerate(names):
     nk = rows["sec_n"][:, k].sum()

@@ -54,8 +54,8 @@ def test_fixture_bam_blocks(lane):
 def test_levels_strategies_and_data_kinds(lane):
     rng = np.random.default_rng(1)
     stream = gzip.decompress(open(BAM, "rb").read())
-    for trial in range(60):
-        kind = trial % 6
+    for trial in range(96):
+        kind = trial % 8
         sz = int(rng.integers(0, 65536))
         if kind == 0:
             data = bytes(rng.integers(0, 256, sz).astype(np.uint8))          # incompressible: stored / long codes
@@ -68,8 +68,21 @@ def test_levels_strategies_and_data_kinds(lane):
             data = bytes([int(rng.integers(0, 256))]) * sz                   # one run: distance 1, length 258
         elif kind == 4:
             data = (b"ACGT" * 20000)[:sz]                                    # period 4
-        else:
+        elif kind == 5:
             data = (bytes(rng.integers(0, 256, 7).astype(np.uint8)) * 10000)[:sz]   # period 7
+        elif kind == 6:
+            # periods 8..70: a match whose source overlaps its destination by less than a slice (the
+            # distance-doubling path of inflate_block), the way one bare BAM record repeats the previous one
+            per = int(rng.integers(8, 71))
+            data = (bytes(rng.integers(0, 256, per).astype(np.uint8)) * (65536 // per + 1))[:sz]
+        else:
+            # ... and records that repeat with a few bytes changed each time
+            per = int(rng.integers(9, 64))
+            rec = rng.integers(0, 256, per).astype(np.uint8)
+            rows = np.tile(rec, (65536 // per + 1, 1))
+            rows[:, int(rng.integers(0, per))] = rng.integers(0, 256, len(rows))
+            rows[::7, int(rng.integers(0, per))] += 1
+            data = rows.tobytes()[:sz]
         for level, strategy in ((0, 0), (1, 0), (6, 0), (9, 0), (6, 4), (6, 2), (6, 3), (1, 1)):
             co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
             raw = co.compress(data) + co.flush()
