@@ -597,19 +597,21 @@ int copy_deflate_data(Staging &S, const bsig::BgzfFile &f, const bsig::BgzfBlock
 
 namespace bsig {
 
-// Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so.  Both engines'
-// times follow the COMPRESSED size (the number of Huffman symbols): the CPU pool needs 0.13-0.2 ms per
-// MB with 32 threads (libdeflate; 300 MB of 52-byte records and 315 MB of sequence-bearing records
-// both take ~41 ms), k_inflate 1.2-2.3 ms per KB of the average block per round of 73,728 resident
-// lanes -- every lane walks its block's symbols one after the other -- plus the trip of the
-// compressed bytes.  Few or badly compressible blocks: CPU; many: GPU.
-inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, int threads)
+// Where the BGZF blocks are inflated unless BAMSIGNALS_INFLATE=gpu|cpu says so.  The CPU pool's time follows
+// the COMPRESSED size: 0.13-0.2 ms per MB with 32 threads (libdeflate; 300 MB of 52-byte records and 315 MB of
+// sequence-bearing records both take ~41 ms).  k_inflate's is one block's latency per ROUND of resident lanes
+// (57,344 blocks), and a block's latency follows what it puts out more than what it reads -- every lane walks
+// its block's symbols one after the other: 18 ms for the 64-KB blocks of bare records (9 KB compressed), 23 ms
+// for real-shaped ones (33 KB) -- plus the trip of the compressed bytes.  Few or badly compressible blocks: CPU;
+// many: GPU.
+inline bool gpu_inflate_pays(size_t n_blocks, uint64_t comp_bytes, uint64_t uncomp_bytes, int threads)
 {
     if (n_blocks == 0) return false;
     const double comp_mb = (double)comp_bytes / (1 << 20);
     const double t_cpu = comp_mb * 0.15 * 32.0 / (double)std::max(1, bsig::decode_threads(threads));
-    const double rounds = (double)((n_blocks + 73727) / 73728);
-    const double t_gpu = rounds * ((double)comp_bytes / (double)n_blocks / 1024.0) * 2.4 + comp_mb * 0.03 + 0.3;
+    const double rounds = (double)((n_blocks + 57343) / 57344);
+    const double per_round = 16.0 * ((double)uncomp_bytes / (double)n_blocks / 65280.0) + 0.21 * ((double)comp_bytes / (double)n_blocks / 1024.0);
+    const double t_gpu = rounds * per_round + comp_mb * 0.03 + 0.3;
     return t_gpu < t_cpu;
 }
 
@@ -1223,9 +1225,10 @@ int tabulate(const std::string &path, int threads, FileScan &F)
         n_est = (size_t)((double)nb * scale);
         comp_total = (uint64_t)((double)comp_total * scale);
     }
+    const uint64_t uncomp_est = (uint64_t)((double)F.uoff[nb] * ((double)n_est / (double)nb));
     // where the blocks are inflated: on the GPU, one block per lane (k_inflate), or by the CPU pool
     const char *eng = getenv("BAMSIGNALS_INFLATE");
-    F.gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_est, comp_total, threads);
+    F.gpu_inflate = eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_est, comp_total, uncomp_est, threads);
     (void)path;
     return BSIG_OK;
 }
@@ -1890,13 +1893,13 @@ int decode_islands(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const
 bool islands_gpu_inflate(const std::vector<Island> &isl, int threads)
 {
     size_t n_blocks = 0;
-    uint64_t comp_total = 0;
+    uint64_t comp_total = 0, uncomp_total = 0;
     for (const Island &I : isl) {
         n_blocks += I.blocks.size();
-        for (const BgzfBlock &b : I.blocks) comp_total += b.dlen;
+        for (const BgzfBlock &b : I.blocks) { comp_total += b.dlen; uncomp_total += b.isize; }
     }
     const char *eng = getenv("BAMSIGNALS_INFLATE");
-    return eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_blocks, comp_total, threads);
+    return eng ? !strcmp(eng, "gpu") : gpu_inflate_pays(n_blocks, comp_total, uncomp_total, threads);
 }
 
 }  // namespace

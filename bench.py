@@ -150,6 +150,8 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
                        timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"cold-call child failed ({r.returncode}): {r.stderr[-800:]}")
+    if os.environ.get("BSIG_DIAG_DECODE"):                    # (diagnostic: the child's stage marks)
+        sys.stderr.write(f"[bench] child {tag}:\n{r.stderr}\n")
     out = json.loads(r.stdout.strip().splitlines()[-1])
     flat = None
     if want_result:
