@@ -52,6 +52,7 @@ const bsig::BaiIndex *bsig_bam_index(const bsig_bam *bam);
 namespace {
 
 constexpr int kMaxRecPerSeg = 1824;          // a record is >= 36 bytes, a block <= 65536
+static_assert(kMaxRecPerSeg % 4 == 0, "k_bam_walk stores four 16-bit offsets at a time");
 constexpr uint32_t kFlagBad = 1u;            // malformed / truncated / too many records
 constexpr uint32_t kFlagUnsorted = 2u;
 constexpr uint32_t kFlagIncomplete = 8u;     // the record at `end` runs past this chunk of the stream
@@ -150,28 +151,41 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ str
     const uint64_t first = o;
     uint16_t *mine = off16 + s * kMaxRecPerSeg;
     uint32_t np = 0, nu = 0, flags = 0;
+    uint64_t pack = 0;
     int32_t frid = -1, fpos = -1, prid = -1, ppos = -1;
     while (o < limit) {
         const uint32_t cut = is_last ? kFlagBad : kFlagIncomplete;     // the record is cut off by the view
         if (o + 36 > total) { flags |= cut; break; }
-        const int32_t bs = (int32_t)ld32(stream + o);
+        // the record's first 20 bytes in two loads (the fields were five loads under five conditions, and every
+        // lane of the wave reads a line of its own: the kernel is bound by the number of requests)
+        uint32_t h[4];
+        __builtin_memcpy(h, stream + o, 16);
+        const uint32_t h4 = ld32(stream + o + 16);
+        const int32_t bs = (int32_t)h[0];
         if (bs < 32) { flags |= kFlagBad; break; }
         const uint64_t next = o + 4 + (uint64_t)bs;
         if (next > total) { flags |= cut; break; }
-        const int32_t rid = (int32_t)ld32(stream + o + 4);
+        const int32_t rid = (int32_t)h[1];
         if (rid < 0) { ++nu; o = next; continue; }                   // unplaced: skipped
         if (rid >= n_ref) { flags |= kFlagBad; break; }
-        const int32_t pos = (int32_t)ld32(stream + o + 8);
-        const uint32_t l_name = ld32(stream + o + 12) & 0xFFu;
-        const uint32_t n_cig = ld32(stream + o + 16) & 0xFFFFu;
+        const int32_t pos = (int32_t)h[2];
+        const uint32_t l_name = h[3] & 0xFFu;
+        const uint32_t n_cig = h4 & 0xFFFFu;
         if (36 + (uint64_t)l_name + 4 * (uint64_t)n_cig > 4 + (uint64_t)bs) { flags |= kFlagBad; break; }
         if (np == 0) { frid = rid; fpos = pos; }
         else if (rid < prid || (rid == prid && pos < ppos)) flags |= kFlagUnsorted;
         if (np >= (uint32_t)kMaxRecPerSeg) { flags |= kFlagBad; break; }
-        mine[np++] = (uint16_t)(o - base);
+        // four offsets per store (kMaxRecPerSeg is a multiple of 4: every segment's list is 8-byte aligned)
+        pack |= (uint64_t)(uint16_t)(o - base) << (16u * (np & 3u));
+        if ((np & 3u) == 3u) {
+            __builtin_memcpy(mine + (np - 3u), &pack, 8);
+            pack = 0;
+        }
+        ++np;
         prid = rid; ppos = pos;
         o = next;
     }
+    for (uint32_t k = np & ~3u; k < np; ++k) mine[k] = (uint16_t)(pack >> (16u * (k & 3u)));
     SegSummary r;
     r.first = first;
     r.end = o; r.n_placed = np; r.n_unplaced = nu;

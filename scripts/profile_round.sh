@@ -39,6 +39,10 @@ for c in $CASES; do
         timeout 900 python3 $R/scripts/decode_realshaped_device_time.py > "$OUT/${TAG}_decodereal_plain.txt" 2>&1 || exit 1
         timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decodereal_trace" -- python3 $R/scripts/decode_realshaped_device_time.py > "$OUT/${TAG}_decodereal_trace.log" 2>&1 || exit 1
         echo "[decodereal] trace done" ;;
+    decodens)
+        # the north star's file (5e8 bare reads, 3 GB, 327,000 blocks): three decodes in a row
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decodens_trace" -- python3 $R/scripts/decode_ns_time.py 500000000 3 > "$OUT/${TAG}_decodens_trace.log" 2>&1 || exit 1
+        echo "[decodens] trace done" ;;
     esac
 done
 ls "$OUT" | grep "${TAG}_" | head -50
