@@ -160,6 +160,11 @@ enum { OK = 0, ERR_INPUT = 1, ERR_CODE = 2, ERR_OUTPUT = 3, ERR_DIST = 4, ERR_ST
 BSIG_HD uint32_t load32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 BSIG_HD uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 BSIG_HD void store64(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }
+struct W16 {
+    uint64_t a, b;
+};
+BSIG_HD W16 load128(const uint8_t *p) { W16 v; memcpy(&v, p, 16); return v; }
+BSIG_HD void store128(uint8_t *p, const W16 &v) { memcpy(p, &v, 16); }
 
 // the 8 input bytes at p; zeros behind the end of the input (a well-formed stream never consumes
 // them, a damaged one runs into ERR_INPUT)
@@ -551,8 +556,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
             uint64_t wpat = 0;                 // short period: the bytes before the match, asked for a turn ahead
             uint32_t pp = 0;                   // ... and whether they were
             uint32_t dn = 0, dpos = 0;          // deferred stores: dn bytes (in 8-byte moves) at out + dpos
-            uint64_t v[kTurn / 8];
-            for (uint32_t k = 0; k < kTurn / 8; ++k) v[k] = 0;
+            W16 v[kTurn / 16];
+            for (uint32_t k = 0; k < kTurn / 16; ++k) v[k] = W16{0, 0};
             int err = OK;
             // The compiler waits for memory with s_waitcnt vmcnt(0) wherever a loaded value is first used -- the
             // exact counts are beyond it in a loop whose loads and stores sit under lane-dependent branches -- and
@@ -645,8 +650,8 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-                    for (uint32_t k = 0; k < kTurn / 8; ++k)
-                        if (8 * k < dn) store64(out + dpos + 8 * k, v[k]);
+                    for (uint32_t k = 0; k < kTurn / 16; ++k)
+                        if (16 * k < dn) store128(out + dpos + 16 * k, v[k]);
                     dn = 0;
                     BSIG_SEC_END(3);
                 }
@@ -664,11 +669,12 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 }
                 BSIG_SEC_BEGIN(5);
                 if (pend) {
-                    // up to kTurn bytes of the match per turn, in 8-byte moves.  A move may write up to 7
-                    // bytes past the match (inside this block's own area: the next symbols overwrite
-                    // them); only the last bytes of a block are moved one by one.
+                    // up to kTurn bytes of the match per turn, in 16-byte moves (every lane's move is a
+                    // request of its own to the memory system: half as many as with 8 bytes).  A move may
+                    // write up to 15 bytes past the match (inside this block's own area: the next symbols
+                    // overwrite them); only the last bytes of a block are moved one by one.
                     uint32_t n = pend < kTurn ? pend : kTurn;
-                    if (op + ((n + 7u) & ~7u) <= out_len) {
+                    if (op + ((n + 15u) & ~15u) <= out_len) {
                         if (pdist < 8) {
                             // short period (runs, 2- and 3-byte patterns): the first 8 bytes come from a
                             // pattern built in registers; behind them the same bytes repeat at a distance
@@ -722,13 +728,14 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         // for the bare reads of the north star's file (a 36-byte record repeats most of the
                         // previous one: distances below 64 are the rule) was a quarter of a turn.
                         if (pdist < kTurn && pdone + pper >= 2u * pdist) pdist *= 2u;
-                        if (pdist < ((n + 7u) & ~7u)) n = pdist & ~7u;               // (>= 8: pdist >= 8 here)
+                        // (what a move reads past the slice may not be written yet: it lands past the slice)
+                        if (pdist < n) n = pdist;                                    // (>= 8: pdist >= 8 here)
                         const uint8_t *from = out + op - pdist;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-                        for (uint32_t k = 0; k < kTurn / 8; ++k)
-                            if (8 * k < n) v[k] = load64(from + 8 * k);
+                        for (uint32_t k = 0; k < kTurn / 16; ++k)
+                            if (16 * k < n) v[k] = load128(from + 16 * k);
                         dn = n;
                         dpos = op;
                     } else {
