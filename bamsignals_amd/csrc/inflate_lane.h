@@ -74,8 +74,10 @@ struct ColdTables {
 // generic pointer: such a load waits for LDS and memory alike, and with it for every store in flight
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BSIG_KEEP_APART() asm volatile("" ::: "memory")
+#define BSIG_ALL_LANES(c) __all(c)          // true for every lane of the wave that is here
 #else
 #define BSIG_KEEP_APART() do { } while (0)
+#define BSIG_ALL_LANES(c) (c)
 #endif
 
 // the sorted symbols of the literal/length code: the low 8 bits as bytes, bit 8 as a bit
@@ -301,6 +303,8 @@ BSIG_HD int decode_long(BitIn &in, const Counts &c, const Syms &sym, const WalkS
         first += count;
         first <<= 1;
         code <<= 1;
+        // (codes of 13-15 bits are rare: once every lane that is here has its symbol the rest of the chain is skipped)
+        if (BSIG_ALL_LANES(hit_len != 0)) break;
     }
     if (hit_len == 0) return -1;
     in.buf >>= hit_len;
