@@ -238,9 +238,11 @@ __global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
     const int64_t base = seg_base[s];
     for (uint32_t k = threadIdx.x; k < n; k += kExtractThreads) {
         const uint8_t *r = seg + offs[k];
-        const int32_t rid = (int32_t)ld32(r + 4);
-        const int32_t p = (int32_t)ld32(r + 8);
-        const uint32_t w12 = ld32(r + 12), w16 = ld32(r + 16);
+        uint32_t h[4];                                  // refID, pos, l_read_name|mapq|bin, n_cigar_op|flag: one load
+        __builtin_memcpy(h, r + 4, 16);
+        const int32_t rid = (int32_t)h[0];
+        const int32_t p = (int32_t)h[1];
+        const uint32_t w12 = h[2], w16 = h[3];
         const uint32_t l_name = w12 & 0xFFu, n_cig = w16 & 0xFFFFu, fl = w16 >> 16;
         // bam_endpos - 1: M(0) D(2) N(3) =(7) X(8) consume the reference; 0x4 or nothing -> 1 base
         int64_t rlen = 0;
@@ -270,7 +272,10 @@ __global__ __launch_bounds__(kExtractThreads) void k_bam_extract(
         mapq[i] = (uint8_t)((w12 >> 8) & 0xFFu);
         tlen[i] = (int32_t)ld32(r + 32);
         end[i] = (int32_t)(p + rlen - 1);
-        const int32_t prev = k ? (int32_t)ld32(seg + offs[k - 1] + 4) : seg_prev_rid[s];
+        // the reference of the record before: the neighbouring lane has it (its k is this lane's k - 1), except for
+        // a wave's first lane
+        const int32_t up = __shfl_up(rid, 1);
+        const int32_t prev = (threadIdx.x & 63u) ? up : k ? (int32_t)ld32(seg + offs[k - 1] + 4) : seg_prev_rid[s];
         for (int32_t q = prev + 1; q <= rid; ++q) ref_first[q] = index0 + i;     // each q is written once
     }
 }
