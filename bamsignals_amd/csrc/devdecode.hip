@@ -1105,6 +1105,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         if (first_chunk && first_share && header_end < 0) return decline();      // header larger than a chunk
 
         // ---- segments of the view [tail | chunk]: from where the chain stands, then one per block --
+        diag_mark("    pass: bytes + inflate");
         const double t0 = now_s();
         const uint8_t *d_stream = d_data - tail;
         const uint64_t own = tail + own_bytes;                 // records that start before this belong to the pass
@@ -1128,6 +1129,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             DD_TRY(hipMemcpyAsync(sum.data(), d_sum, (size_t)n_seg * sizeof(SegSummary), hipMemcpyDeviceToHost, st));
         }
         DD_TRY(hipStreamSynchronize(st));
+        diag_mark("    pass: walk + summaries to the host");
 
         // ---- host: the chain of records must run through every block's proposed first record ------
         // (this is what proves the starts the lanes chose: a walk that always arrives exactly at the
@@ -1177,6 +1179,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             if (new_tail > carry_cap || (new_tail && o < tail)) return decline(); // a record larger than the carry
         }
 
+        diag_mark("    pass: chain check on the host");
         // ---- this chunk's columns -------------------------------------------------------------------
         if (n_chunk > 0) {
             R.pieces.emplace_back(new Piece);
@@ -1195,6 +1198,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         if (new_tail) DD_TRY(hipMemcpyAsync(d_next - new_tail, d_stream + o, (size_t)new_tail, hipMemcpyDeviceToDevice, st));
         // the host arrays of this chunk are reused: the copies above must have left them
         DD_TRY(hipStreamSynchronize(st));
+        diag_mark("    pass: extraction");
         if (crc_pending) {
             // the blocks' CRCs were checked meanwhile: a mismatch sends the call down the CPU path, which
             // reports it (nothing of this share is used then)
@@ -1204,6 +1208,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             DD_TRY(hipStreamSynchronize(st));
             if (bad) return decline();
             crc_pending = false;
+            diag_mark("    pass: CRC verdict");
         }
         tail = new_tail;
         first_chunk = false;
