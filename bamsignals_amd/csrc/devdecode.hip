@@ -413,6 +413,8 @@ size_t inflate_lds_pad()
 // the passes of a decode are cut at multiples of it.
 size_t inflate_round_blocks(int device)
 {
+    if (const char *e = getenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS"))      // (tests: rounds of a few blocks)
+        if (atol(e) > 0) return (size_t)atol(e);
     static std::mutex mu;
     static std::map<std::pair<int, std::pair<int, size_t>>, size_t> known;
     const int lanes = inflate_lanes_per_wave();

@@ -345,6 +345,61 @@ def test_head_of_the_file_decoded_while_the_rest_is_tabulated(ctx, tmp_path, mon
         dev.close()
 
 
+def test_passes_are_whole_rounds_of_inflate_lanes(ctx, tmp_path, monkeypatch, capfd):
+    """A k_inflate launch lasts one block's latency per round of resident lanes, so every pass of a decode that is
+    not its share's last holds a whole number of rounds (57,344 blocks on an MI355X: only the bench's files are
+    that large, so the round is set to a few blocks here): first pass one round -- or half the share if that is
+    less --, second two, then what the chunk allows; the head share of a two-step decode too."""
+    import re
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu")
+    monkeypatch.setenv("BSIG_DIAG_DECODE", "1")
+    cols = synth_reads(2_000_000, [900_000, 70_000, 0, 400_000], seed=15, paired=True)
+    path = str(tmp_path / "syn.bam")
+    write_columns_as_bam(path, ["a", "b", "empty", "c"], cols)                # ~1,600 blocks
+    stream = gzip.decompress(open(BAM, "rb").read())
+    straddle = tmp_path / "straddle.bam"
+    straddle.write_bytes(_bgzf(stream, [4000, 9001, 517, 65000]))
+    _empty_bai(str(straddle) + ".bai", 3)
+    for f, n_reads in ((path, 2_000_000), (BAM, 99000), (str(straddle), 99000)):
+        for rnd, chunk_mb, two_step in ((7, "1", False), (64, "16", False), (5, "1", True), (100, None, True)):
+            monkeypatch.setenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS", str(rnd))
+            if chunk_mb:
+                monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", chunk_mb)
+            else:
+                monkeypatch.delenv("BAMSIGNALS_DEVICE_DECODE_CHUNK_MB", raising=False)
+            if two_step:
+                monkeypatch.setenv("BAMSIGNALS_SCAN_SEGMENT_KB", "16")
+                monkeypatch.setenv("BAMSIGNALS_SCAN_HEAD_KB", "600")
+                monkeypatch.setenv("BAMSIGNALS_TWO_STEP_MIN_BLOCKS", "1")
+            else:
+                for k in ("BAMSIGNALS_SCAN_SEGMENT_KB", "BAMSIGNALS_SCAN_HEAD_KB", "BAMSIGNALS_TWO_STEP_MIN_BLOCKS"):
+                    monkeypatch.delenv(k, raising=False)
+            capfd.readouterr()
+            _, dev = _both_ways(ctx, f, monkeypatch)
+            assert dev.n_reads == n_reads
+            dev.close()
+            err = capfd.readouterr().err
+            # the device decode's launches (the CPU decode of _both_ways prints none), share by share
+            shares, cur = [], []
+            for line in err.splitlines():
+                m = re.match(r"pass (\d+): waited .* for k_inflate of (\d+) blocks", line)
+                if m:
+                    if int(m.group(1)) == 0 and cur:
+                        shares.append(cur); cur = []
+                    cur.append(int(m.group(2)))
+            if cur:
+                shares.append(cur)
+            assert shares, err[-400:]
+            assert (len(shares) == 2) == (two_step and "decode_share (head)" in err), (f, rnd, shares)
+            for sh in shares:
+                for n in sh[:-1]:
+                    assert n <= rnd or n % rnd == 0, (f, rnd, chunk_mb, two_step, shares)
+            if f == path and not two_step:
+                assert len(shares[0]) >= 3 and shares[0][0] == rnd and shares[0][1] == 2 * rnd, (rnd, shares)
+
+
 def test_damaged_files_report_the_cpu_paths_errors(ctx, tmp_path, monkeypatch):
     """a truncated last record and an unsorted file: the device path declines, the CPU path names
     the problem"""
