@@ -204,12 +204,23 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         # (no arena: measured on the same file, scripts/cold_call_scan_ab.py, a 44-GB arena makes the call 0.04 s
         # slower -- first touches of its memory -- and it is only insurance against rare allocation stalls)
         arena_gb = 0
+        # three sessions, the median one reported: a session's first call now and then catches an allocation stall
+        # of the driver (r03: one run in three to five, 0.5 s instead of 0.28 s) -- all three are listed
         child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device, arena_gb=arena_gb)
-        t_cold, t_warm = child["calls"][0]["call_s"], child["calls"][1]["call_s"]
-        stages = child["calls"][0]["stages_s"]
         if not np.array_equal(flat, want_flat):
             raise SystemExit("file-level result differs from the resident-column result")
+        fp = result_fingerprint(flat)
         del flat
+        sessions = [child]
+        for k in (1, 2):
+            c, _ = cold_call_in_fresh_process(d, "ns%d" % k, bam, names, rg, call, device, arena_gb=arena_gb, want_result=False)
+            if (c["result_cells"], c["result_sum"], c["result_wsum"]) != fp:
+                raise SystemExit("file-level result of a repeated session differs")
+            sessions.append(c)
+        cold_samples = [c["calls"][0]["call_s"] for c in sessions]
+        child = sorted(sessions, key=lambda c: c["calls"][0]["call_s"])[1]
+        t_cold, t_warm = child["calls"][0]["call_s"], child["calls"][1]["call_s"]
+        stages = child["calls"][0]["stages_s"]
         log(f"end_to_end: cold {t_cold:.3f} s, warm {t_warm:.3f} s; now the 1-thread CPU path on the same BAM")
         b = BamFile(bam)
         dec = b.decode(threads=1)
@@ -226,12 +237,13 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         bases = int(rg["len"].astype(np.int64).sum())
         dd = stages["decode_stages_s"]
         gpu = dict(bam_bytes=os.path.getsize(bam), write_bam_s=t_write,
-                   cold_call_s=t_cold, cold_call_stages_s=stages, warm_call_s=t_warm,
+                   cold_call_s=t_cold, cold_call_sessions_s=cold_samples, cold_call_stages_s=stages, warm_call_s=t_warm,
                    # the compressed file's trip into HBM: what the call waited for it, and the file size over the
                    # whole decode (block scan + copies + inflate + parse), i.e. the ingest rate the cold call sees
                    copy_wait_s=dd.get("copy_wait"), decode_ingest_GBps=os.path.getsize(bam) / max(dd.get("total") or 1e-9, 1e-9) / 1e9,
                    host_cpus_used=child["host_cpus_used"], hip_context_s=child["hip_context_s"], route=child["calls"][0]["route"],
-                   measured_in="a fresh child process with its HIP context up (a new session's first BAM; see cold_call_in_fresh_process)",
+                   measured_in="fresh child processes with their HIP context up (a new session's first BAM; see cold_call_in_fresh_process): "
+                               "three sessions, the median one's call and stages reported, all three cold calls listed",
                    arena_gb=arena_gb,
                    cold_Mbases_s=bases / t_cold / 1e6, warm_Mbases_s=bases / t_warm / 1e6,
                    vs_cpu_path_cold=(t_dec1 + t_orc) / t_cold, vs_cpu_path_warm=(t_dec1 + t_orc) / t_warm,
