@@ -153,6 +153,8 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
     if os.environ.get("BSIG_DIAG_DECODE"):                    # (diagnostic: the child's stage marks)
         sys.stderr.write(f"[bench] child {tag}:\n{r.stderr}\n")
     out = json.loads(r.stdout.strip().splitlines()[-1])
+    if os.environ.get("BSIG_DIAG_DECODE"):
+        out["stderr"] = r.stderr
     flat = None
     if want_result:
         flat = np.load(spec["result"])

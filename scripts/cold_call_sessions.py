@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Diagnostic: the cold file-level call of the north star's BAM in N fresh sessions (bench.py's
+cold_call_in_fresh_process), each with the decode's stage marks; prints every session's time and, for the ones
+well above the median, where the time went -- what does a session's first call catch now and then?"""
+import os
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["BSIG_DIAG_DECODE"] = "1"
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402
+from bamsignals_amd.bamio import write_columns_as_bam  # noqa: E402
+from bamsignals_amd.synth import synth_ranges, synth_reads  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
+sessions = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+ref = [250_000_000] * 10
+cols = synth_reads(n, ref, seed=9)
+d = tempfile.mkdtemp(prefix="bsig_sessions_", dir="/tmp")
+bam = os.path.join(d, "ns.bam")
+names = ["c%d" % i for i in range(10)]
+write_columns_as_bam(bam, names, cols, level=1)
+del cols
+bench._settle(bam)
+rg = synth_ranges(100_000, 2000, ref, seed=10)
+call = dict(tlen_filter=(), device=0)
+runs = []
+_real_stderr = sys.stderr
+for k in range(sessions):
+    sys.stderr = open(os.devnull, "w")            # (cold_call_in_fresh_process echoes the child's marks)
+    try:
+        child, _ = bench.cold_call_in_fresh_process(d, "s", bam, names, rg, call, 0, reps=1, want_result=False)
+    finally:
+        sys.stderr.close()
+        sys.stderr = _real_stderr
+    c = child["calls"][0]
+    runs.append((c["call_s"], c["stages_s"], child.get("stderr", "")))
+    print("session %d: call %.3f s, decode %.3f s (its timed stages %.3f s), plan + run + download %.3f s" % (
+        k, c["call_s"], c["stages_s"]["decode"], sum(v for kk, v in c["stages_s"]["decode_stages_s"].items() if kk not in ("total",)),
+        c["stages_s"]["plan_run_download"]), flush=True)
+med = float(np.median([r[0] for r in runs]))
+print("median %.3f s, min %.3f, max %.3f" % (med, min(r[0] for r in runs), max(r[0] for r in runs)))
+for k, (t, st, err) in enumerate(runs):
+    if t > 1.25 * med:
+        print("\n== session %d (%.3f s): stage marks" % (k, t))
+        print("\n".join(l for l in err.splitlines() if "[decode]" in l or l.startswith("pass ")))
+shutil.rmtree(d, ignore_errors=True)
