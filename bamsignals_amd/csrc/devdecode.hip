@@ -491,6 +491,22 @@ struct Staging {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int *h_flags = nullptr;      // a few page-locked words: status read-backs that must not block the host (a
                                  // device-to-host copy into pageable memory waits for everything queued before it)
+    // the streams a GPU-inflate decode works on beside the context's own (compressed bytes, k_inflate, CRC) and
+    // their events: made once per device -- a stream is a hardware queue, and a decode of the north star's file
+    // made and destroyed six of them (two shares x three)
+    hipStream_t s_copy = nullptr, s_inflate = nullptr, s_crc = nullptr;
+    hipEvent_t ev_inflated[2] = {nullptr, nullptr}, ev_crc_done[2] = {nullptr, nullptr};
+    int ensure_streams()
+    {
+        if (!s_copy) HIP_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+        if (!s_inflate) HIP_TRY(hipStreamCreateWithFlags(&s_inflate, hipStreamNonBlocking));
+        if (!s_crc) HIP_TRY(hipStreamCreateWithFlags(&s_crc, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            if (!ev_inflated[k]) HIP_TRY(hipEventCreateWithFlags(&ev_inflated[k], hipEventDisableTiming));
+            if (!ev_crc_done[k]) HIP_TRY(hipEventCreateWithFlags(&ev_crc_done[k], hipEventDisableTiming));
+        }
+        return BSIG_OK;
+    }
     int ensure(size_t bytes)
     {
         if (!h_flags) HIP_TRY(hipHostMalloc((void **)&h_flags, 16 * sizeof(int), hipHostMallocDefault));
@@ -519,6 +535,40 @@ Staging &staging_for(int device)
         if (kv.first == device) return *kv.second;
     all.emplace_back(device, std::unique_ptr<Staging>(new Staging));
     return *all.back().second;
+}
+
+// A process's first decode on a device pins the staging halves (5 ms) and makes its three streams and four
+// events (17 ms in a fresh process: a stream is a hardware queue).  Neither needs anything the decode learns
+// first, so a whole-file decode starts them on a thread of their own BEFORE it walks the head of the block
+// table (11-19 ms of host work during which the runtime would sit idle); decode_share finds them ready, or
+// waits on S.mu for the rest.  The thread is joined by the next preparation or when the library is unloaded.
+void prepare_staging_async(int device, size_t bytes)
+{
+    struct Jobs {
+        std::mutex mu;
+        std::vector<std::thread> th;
+        ~Jobs() { for (auto &t : th) if (t.joinable()) t.join(); }
+    };
+    static Jobs jobs;
+    Staging &S = staging_for(device);
+    {
+        std::unique_lock<std::mutex> probe(S.mu, std::try_to_lock);
+        if (!probe.owns_lock()) return;                    // somebody is at it (a decode, or an earlier preparation)
+        if (S.cap >= bytes && S.s_copy && S.s_inflate && S.s_crc && S.ev_inflated[1] && S.ev_crc_done[1]) return;
+    }
+    std::lock_guard<std::mutex> lk(jobs.mu);
+    for (auto &t : jobs.th) if (t.joinable()) t.join();
+    jobs.th.clear();
+    try {
+        jobs.th.emplace_back([device, bytes] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            Staging &S2 = staging_for(device);
+            std::lock_guard<std::mutex> lock(S2.mu);
+            (void)S2.ensure(bytes);                        // (a failure here shows again, and is reported, in the decode)
+            (void)S2.ensure_streams();
+        });
+    } catch (const std::system_error &) {
+    }
 }
 
 thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
@@ -895,10 +945,14 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         ~Prefetch()
         {
             join();
-            if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+            if (cs) (void)hipStreamSynchronize(cs);       // (the stream is the staging area's: it stays)
         }
     } pf;
-    if (gpu_inflate) HIP_TRY(hipStreamCreateWithFlags(&pf.cs, hipStreamNonBlocking));
+    if (gpu_inflate) {
+        rc = S.ensure_streams();
+        if (rc) return rc;
+        pf.cs = S.s_copy;
+    }
     // the CRC check of a pass runs on its own stream beside the record walk and extraction of that pass
     struct CrcSide {
         hipStream_t st = nullptr;
@@ -906,22 +960,19 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         hipEvent_t inflated[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
         ~CrcSide()
         {
-            if (inf) { (void)hipStreamSynchronize(inf); (void)hipStreamDestroy(inf); }
-            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-            for (int k = 0; k < 2; ++k) {
-                if (inflated[k]) (void)hipEventDestroy(inflated[k]);
-                if (done[k]) (void)hipEventDestroy(done[k]);
-            }
+            if (inf) (void)hipStreamSynchronize(inf);     // (streams and events are the staging area's: they stay)
+            if (st) (void)hipStreamSynchronize(st);
         }
     } crc;
-    if (gpu_inflate) HIP_TRY(hipStreamCreateWithFlags(&crc.inf, hipStreamNonBlocking));
+    if (gpu_inflate) crc.inf = S.s_inflate;
     if (gpu_inflate && d_crc_tables) {
-        HIP_TRY(hipStreamCreateWithFlags(&crc.st, hipStreamNonBlocking));
+        crc.st = S.s_crc;
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipEventCreateWithFlags(&crc.inflated[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&crc.done[k], hipEventDisableTiming));
+            crc.inflated[k] = S.ev_inflated[k];
+            crc.done[k] = S.ev_crc_done[k];
         }
     }
+    diag_mark("  streams + events");
     bool crc_pending = false;
     int pass = 0;
     auto start_prefetch = [&](size_t b0, int which) {
@@ -1007,6 +1058,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
                 }
                 if (header_end < 0) return decline();
                 std::vector<uint8_t>().swap(head);
+                diag_mark("    pass: BAM header on the host");
             }
             // The pipeline: pass j is inflated on its own stream, walked and extracted on `st`, while pass j + 1's
             // compressed bytes cross PCIe (helper thread); with two views (see above) pass j + 1 is also inflated,
@@ -1044,6 +1096,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             if (pass == 0) {
                 // (the set-up copies and fills queued on `st` above must have landed before another stream reads them)
                 DD_TRY(hipStreamSynchronize(st));
+                diag_mark("    pass: set-up copies landed");
                 rc = join_bytes(B0, Bv, 0);
                 if (rc == kNeedsCpuPath) return decline();
                 if (rc) { (void)decline(); return rc; }
@@ -1296,6 +1349,7 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     *out = nullptr;
     FileScan F;
     diag_mark(nullptr);
+    prepare_staging_async(ctx->device, 32u << 20);
     uint64_t head_bytes = env_mb("BAMSIGNALS_SCAN_HEAD_MB", 640);
     {
         const char *e = getenv("BAMSIGNALS_SCAN_HEAD_MB");
