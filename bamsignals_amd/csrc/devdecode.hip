@@ -537,40 +537,6 @@ Staging &staging_for(int device)
     return *all.back().second;
 }
 
-// A process's first decode on a device pins the staging halves (5 ms) and makes its three streams and four
-// events (17 ms in a fresh process: a stream is a hardware queue).  Neither needs anything the decode learns
-// first, so a whole-file decode starts them on a thread of their own BEFORE it walks the head of the block
-// table (11-19 ms of host work during which the runtime would sit idle); decode_share finds them ready, or
-// waits on S.mu for the rest.  The thread is joined by the next preparation or when the library is unloaded.
-void prepare_staging_async(int device, size_t bytes)
-{
-    struct Jobs {
-        std::mutex mu;
-        std::vector<std::thread> th;
-        ~Jobs() { for (auto &t : th) if (t.joinable()) t.join(); }
-    };
-    static Jobs jobs;
-    Staging &S = staging_for(device);
-    {
-        std::unique_lock<std::mutex> probe(S.mu, std::try_to_lock);
-        if (!probe.owns_lock()) return;                    // somebody is at it (a decode, or an earlier preparation)
-        if (S.cap >= bytes && S.s_copy && S.s_inflate && S.s_crc && S.ev_inflated[1] && S.ev_crc_done[1]) return;
-    }
-    std::lock_guard<std::mutex> lk(jobs.mu);
-    for (auto &t : jobs.th) if (t.joinable()) t.join();
-    jobs.th.clear();
-    try {
-        jobs.th.emplace_back([device, bytes] {
-            if (hipSetDevice(device) != hipSuccess) return;
-            Staging &S2 = staging_for(device);
-            std::lock_guard<std::mutex> lock(S2.mu);
-            (void)S2.ensure(bytes);                        // (a failure here shows again, and is reported, in the decode)
-            (void)S2.ensure_streams();
-        });
-    } catch (const std::system_error &) {
-    }
-}
-
 thread_local double g_dev_decode_timing[6] = {0, 0, 0, 0, 0, 0};
 
 // The decode's device scratch (the view of the uncompressed stream, the compressed bytes, record
@@ -1349,7 +1315,6 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     *out = nullptr;
     FileScan F;
     diag_mark(nullptr);
-    prepare_staging_async(ctx->device, 32u << 20);
     uint64_t head_bytes = env_mb("BAMSIGNALS_SCAN_HEAD_MB", 640);
     {
         const char *e = getenv("BAMSIGNALS_SCAN_HEAD_MB");

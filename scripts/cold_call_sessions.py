@@ -30,20 +30,25 @@ rg = synth_ranges(100_000, 2000, ref, seed=10)
 call = dict(tlen_filter=(), device=0)
 runs = []
 _real_stderr = sys.stderr
+# (A/B: `VARIANTS="BAMSIGNALS_STAGING_AHEAD=0;BAMSIGNALS_STAGING_AHEAD=1"` alternates the sessions between environments)
+variants = [dict(kv.split("=", 1) for kv in v.split(",") if kv) for v in os.environ.get("VARIANTS", "").split(";")] if os.environ.get("VARIANTS") else [{}]
 for k in range(sessions):
     sys.stderr = open(os.devnull, "w")            # (cold_call_in_fresh_process echoes the child's marks)
     try:
-        child, _ = bench.cold_call_in_fresh_process(d, "s", bam, names, rg, call, 0, reps=1, want_result=False)
+        child, _ = bench.cold_call_in_fresh_process(d, "s", bam, names, rg, call, 0, env=variants[k % len(variants)], reps=1, want_result=False)
     finally:
         sys.stderr.close()
         sys.stderr = _real_stderr
     c = child["calls"][0]
     runs.append((c["call_s"], c["stages_s"], child.get("stderr", "")))
-    print("session %d: call %.3f s, decode %.3f s (its timed stages %.3f s), plan + run + download %.3f s" % (
+    print(variants[k % len(variants)] or "", "session %d: call %.3f s, decode %.3f s (its timed stages %.3f s), plan + run + download %.3f s" % (
         k, c["call_s"], c["stages_s"]["decode"], sum(v for kk, v in c["stages_s"]["decode_stages_s"].items() if kk not in ("total",)),
         c["stages_s"]["plan_run_download"]), flush=True)
 med = float(np.median([r[0] for r in runs]))
 print("median %.3f s, min %.3f, max %.3f" % (med, min(r[0] for r in runs), max(r[0] for r in runs)))
+if len(variants) > 1:
+    for v in range(len(variants)):
+        print(variants[v], "median %.3f s" % float(np.median([r[0] for r in runs[v::len(variants)]])))
 for k, (t, st, err) in enumerate(runs):
     if t > 1.25 * med:
         print("\n== session %d (%.3f s): stage marks" % (k, t))
