@@ -450,8 +450,8 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
                           int *crc_status = nullptr, hipEvent_t crc_done = nullptr)
 {
     if (n <= 0) return hipSuccess;
-    // resident lanes per CU = min(160 KB / 676 B of LaneSlot = 242, 12 waves (168 VGPRs) x LANES) in whole
-    // workgroups: 32 lanes per wave -> seven 21-KB workgroups = 224 lanes (160 while all sorted symbols and the
+    // resident lanes per CU = min(160 KB / 708 B of LaneSlot = 231, 12 waves (168 VGPRs) x LANES) in whole
+    // workgroups: 32 lanes per wave -> seven 22-KB workgroups = 224 lanes (160 while all sorted symbols and the
     // construction scratch lived in LDS too: 964 B per lane)
     const int lanes = inflate_lanes_per_wave();
     const size_t lds_pad = inflate_lds_pad();

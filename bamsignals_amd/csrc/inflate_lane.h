@@ -2,12 +2,13 @@
 // BGZF block (a BAM holds tens of thousands of independent blocks of <= 64 KiB: that, not the bits
 // inside a block, is where the parallelism is).  Written for lanes that march together:
 //
-//   * Huffman decoding: an 8-bit (literal/length, 16-bit entries) and a 5-bit (distance, byte
+//   * Huffman decoding: an 8-bit (literal/length, 16-bit entries) and a 6-bit (distance, byte
 //     entries) first-level table answer nearly every symbol with one lookup; longer codes take
 //     the canonical walk over the code lengths (per length the NUMBER of codes, packed two per
 //     register, and the symbols sorted by (length, value)) from the first length the table does not
 //     cover, as a chain of compares WITHOUT branches, then one lookup.  672 bytes of LDS per lane on
-//     the device, where zlib-style two-level tables need 5.7 KB;
+//     the device (704: 6 bits of distance table cost no resident lane and save 2 % on literal-heavy blocks),
+//     where zlib-style two-level tables need 5.7 KB;
 //   * memory is waited for ONCE per turn of the main loop (see BSIG_VM_DRAIN in inflate_block): the
 //     compiler's waits are all-or-nothing (s_waitcnt vmcnt(0)), so every load whose value is needed
 //     at once stalls the wave for a whole trip and drains what else is in flight;
@@ -34,14 +35,17 @@ namespace bsig_inflate {
 #ifndef BSIG_LFAST
 #define BSIG_LFAST 8
 #endif
-constexpr int kLFast = BSIG_LFAST, kDFast = 5;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit)
+#ifndef BSIG_DFAST
+#define BSIG_DFAST 6
+#endif
+constexpr int kLFast = BSIG_LFAST, kDFast = BSIG_DFAST;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit, <= 7 bits)
 #ifndef BSIG_MULTI_LIT
 #define BSIG_MULTI_LIT 1
 #endif
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 
-// per-lane working storage that nearly every symbol touches (LDS on the device): 672 bytes = 224 lanes per CU
+// per-lane working storage that nearly every symbol touches (LDS on the device): 704 bytes = 224 lanes per CU
 // (160 with the cold tables in LDS as well).  More would not help a big file: a lane's turn takes 6,000-7,000
 // cycles however many waves share its SIMD, but each resident lane also keeps three or four 128-byte lines live in
 // L2 (the output line it is writing, its input line, the line its matches copy from) and 4 MB per XCD is 32,768
@@ -54,7 +58,7 @@ constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn o
 constexpr int kHotSyms = BSIG_HOT_SYMS;      // (a multiple of 64) literal/length symbols with codes longer than the first-level table kept in LDS
 struct LaneTables {
     uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
-    uint8_t dfast[1 << kDFast];    // distance: (symbol << 3) | code length (<= 5), 0 = longer code
+    uint8_t dfast[1 << kDFast];    // distance: (symbol << 3) | code length (<= kDFast), 0 = longer code
     // the first kHotSyms sorted symbols whose codes are LONGER than the first-level table (the shortest of the
     // long codes, i.e. the most frequent of the rare symbols): what the walk looks up.  With all sorted symbols
     // in global memory nearly every turn of a wave waited for one such load (32 lanes x up to six literals: some
@@ -331,7 +335,7 @@ BSIG_HD int decode(BitIn &in, const LaneTables &T, const Counts &c, const LSyms 
     return decode_long<FAST>(in, c, sym, ws);
 }
 
-// a distance symbol: the 5-bit first-level table, else the walk
+// a distance symbol: the first-level table, else the walk
 BSIG_HD int decode_dist(BitIn &in, const uint8_t *fast, const Counts &c, const DSyms &sym, const WalkStart &ws)
 {
     const uint32_t e = fast[in.buf & ((1u << kDFast) - 1)];

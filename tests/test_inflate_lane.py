@@ -20,8 +20,9 @@ BAM = os.path.join(GOLDEN, "randomBam.bam")
 @pytest.fixture(scope="module")
 def lane(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("inflate") / "libinflate_lane_host.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", so,
-                           os.path.join(ROOT, "tests", "inflate_lane_host.cpp")])
+    # (BSIG_LANE_CXXFLAGS: the decoder's compile-time variants, e.g. -DBSIG_DFAST=6)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", *os.environ.get("BSIG_LANE_CXXFLAGS", "").split(),
+                           "-o", so, os.path.join(ROOT, "tests", "inflate_lane_host.cpp")])
     lib = ctypes.CDLL(so)
     lib.inflate_lane_host.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
 
