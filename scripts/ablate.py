@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tile-cells", type=int, default=0)
     ap.add_argument("--batches", type=int, default=8)
+    ap.add_argument("--refs", type=int, default=1, help="references of 250 Mbp (the north star: 10, with --reads 500000000 --ranges 100000)")
     a = ap.parse_args()
     import torch
 
@@ -24,7 +25,7 @@ def main():
     from bamsignals_amd.device import Context, Plan, Reads, make_params
     from bamsignals_amd.synth import synth_ranges, synth_reads
 
-    ref_len = [250_000_000]
+    ref_len = [250_000_000] * a.refs
     cols = synth_reads(a.reads, ref_len, with_cigar=False)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
