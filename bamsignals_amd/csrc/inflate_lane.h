@@ -6,8 +6,8 @@
 //     entries) first-level table answer nearly every symbol with one lookup; longer codes take
 //     the canonical walk over the code lengths (per length the NUMBER of codes, packed two per
 //     register, and the symbols sorted by (length, value)) from the first length the table does not
-//     cover, as a chain of compares WITHOUT branches, then one lookup.  672 bytes of LDS per lane on
-//     the device (704: 6 bits of distance table cost no resident lane and save 2 % on literal-heavy blocks),
+//     cover, as a chain of compares WITHOUT branches, then one lookup.  704 bytes of LDS per lane on
+//     the device (6 bits of distance table cost no resident lane and save 2 % on literal-heavy blocks),
 //     where zlib-style two-level tables need 5.7 KB;
 //   * memory is waited for ONCE per turn of the main loop (see BSIG_VM_DRAIN in inflate_block): the
 //     compiler's waits are all-or-nothing (s_waitcnt vmcnt(0)), so every load whose value is needed
