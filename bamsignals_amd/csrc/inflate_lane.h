@@ -69,8 +69,6 @@ struct LaneTables {
 // touch: it lives behind the code-length scratch (global memory on the device)
 struct ColdTables {
     uint32_t lhi[9];               // bit 8 of the literal/length symbols below
-    uint16_t offs[16];             // scratch of the table construction
-    uint16_t next[16];             // scratch: next canonical code of every length
     uint8_t lsym[288];             // literal/length symbols sorted by (code length, symbol), low 8 bits
 };
 
@@ -99,6 +97,7 @@ struct LSyms {
     BSIG_HD void begin_long(int first_long_idx) { base = first_long_idx; }
     BSIG_HD void put(int idx, int s)
     {
+        if (idx < base) return;             // a code the first-level table holds: nobody looks its symbol up here
         const unsigned h = (unsigned)(idx - base);
         if (h < (unsigned)kHotSyms) {
             hot[h] = (uint8_t)s;
@@ -364,42 +363,86 @@ struct Fast8 {
     BSIG_HD void zero(uint32_t k) const { t[k] = 0; }
 };
 
+// sixteen 16-bit slots in eight registers (the per-length offsets and next codes of a table under construction:
+// they used to live in the lane's global scratch, where every `slot[len]++` was a load, a wait that drained every
+// store in flight, and a store -- two trips to memory per symbol, 1.6 million cycles per code table, a tenth of a
+// lane's time on blocks that hold six deflate blocks (zlib level 6) and a third of its wave's, because the lanes
+// of a wave reach their tables at different times)
+struct Slots16 {
+    uint32_t w[8];
+    BSIG_HD void clear() { for (int k = 0; k < 8; ++k) w[k] = 0; }
+    BSIG_HD uint32_t get(int l) const
+    {
+        uint32_t x = w[0];
+        for (int k = 1; k < 8; ++k) x = (l >> 1) == k ? w[k] : x;
+        return (x >> ((l & 1) * 16)) & 0xFFFFu;
+    }
+    BSIG_HD void add(int l, uint32_t d)                    // (values stay below 65,536: no carry into the neighbour)
+    {
+        const uint32_t v = d << ((l & 1) * 16);
+        for (int k = 0; k < 8; ++k) w[k] += (l >> 1) == k ? v : 0u;
+    }
+    BSIG_HD void set(int l, uint32_t val)
+    {
+        const int sh = (l & 1) * 16;
+        for (int k = 0; k < 8; ++k)
+            if ((l >> 1) == k) w[k] = (w[k] & ~(0xFFFFu << sh)) | ((val & 0xFFFFu) << sh);
+    }
+};
+
+// the code lengths a dynamic block's header left in the scratch, read eight at a time
+struct LenReader {
+    const uint8_t *p;
+    int base;
+    uint64_t w;
+    BSIG_HD explicit LenReader(const uint8_t *q) : p(q), base(-8), w(0) {}
+    BSIG_HD int operator()(int i)
+    {
+        const int b = i & ~7;
+        if (b != base) { base = b; w = load64(p + b); }
+        return (int)((w >> (8 * (i & 7))) & 0xFFu);
+    }
+};
+
 template <int FAST, typename FastT, typename Syms, typename LenAt>
-BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, uint16_t *offs, uint16_t *next, int n, LenAt len_at)
+BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len_at)
 {
     sym.clear();
-    for (int k = 0; k < 16; ++k) offs[k] = 0;
-    for (int i = 0; i < n; ++i) offs[len_at(i)] = (uint16_t)(offs[len_at(i)] + 1);      // offs = counts for now
+    Slots16 offs, next;
+    offs.clear();
+    next.clear();
+    for (int i = 0; i < n; ++i) offs.add(len_at(i), 1u);                  // offs = counts for now (slot 0: unused symbols)
     for (int k = 0; k < 8; ++k) c.w[k] = 0;
-    int left = 1;
-    uint32_t code = 0;
-    offs[0] = 0;
+    int left = 1, acc = 0;
+    uint32_t code = 0, shorter = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
     for (int len = 1; len <= 15; ++len) {
+        const uint32_t cnt = offs.get(len);
         left <<= 1;
-        left -= offs[len];
+        left -= (int)cnt;
         if (left < 0) return false;
-        c.w[len >> 1] |= (uint32_t)offs[len] << ((len & 1) * 16);
-        code = (code + offs[len - 1]) << 1;          // first canonical code of this length
-        next[len] = (uint16_t)code;
-    }
-    // offsets of every length in the sorted symbol array
-    int acc = 0;
-    for (int len = 1; len <= 15; ++len) {
-        const int cnt = offs[len];
-        offs[len] = (uint16_t)acc;
-        acc += cnt;
+        c.w[len >> 1] |= cnt << ((len & 1) * 16);
+        code = (code + shorter) << 1;                // first canonical code of this length
+        next.set(len, code);
+        shorter = cnt;
+        offs.set(len, (uint32_t)acc);                // ... and where its symbols begin in the sorted array
+        acc += (int)cnt;
     }
     const bool use_fast = FAST > 0 && fast.on();
     // (sorted positions from here on belong to codes the first-level table does not hold: offs[FAST + 1] is where
     // length FAST + 1 begins, the total if there is no longer code)
-    sym.begin_long(FAST > 0 && FAST < 15 ? (int)offs[FAST + 1] : acc);
+    sym.begin_long(FAST > 0 && FAST < 15 ? (int)offs.get(FAST + 1) : acc);
     if (use_fast)
         for (uint32_t k = 0; k < (1u << FAST); ++k) fast.zero(k);
     for (int i = 0; i < n; ++i) {
         const int l = len_at(i);
         if (!l) continue;
-        sym.put(offs[l]++, i);
-        const uint32_t cd = next[l]++;
+        sym.put((int)offs.get(l), i);
+        offs.add(l, 1u);
+        const uint32_t cd = next.get(l);
+        next.add(l, 1u);
         if (use_fast && l <= FAST)
             for (uint32_t k = bit_reverse(cd, l); k < (1u << FAST); k += 1u << l) fast.put(k, i, l);
     }
@@ -417,7 +460,7 @@ BSIG_HD int cl_order(int k)
 }
 
 constexpr int kLensCodes = 352;   // scratch of inflate_block: 32 for the code-length code + 316 lengths
-constexpr int kLensBytes = 784;   // ... + ColdTables (388 bytes) behind it; the scratch must be 4-byte aligned
+constexpr int kLensBytes = 784;   // ... + ColdTables (324 bytes) behind it; the scratch must be 8-byte aligned
 static_assert(kLensCodes % 4 == 0 && kLensCodes + (int)sizeof(ColdTables) <= kLensBytes, "scratch layout");
 
 // true once more bits were consumed than the input holds
@@ -509,35 +552,53 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
                 auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
                 auto fd = [](int) { return 5; };
-                construct<kLFast>(lc, Fast16{T.lfast}, ls, Cd.offs, Cd.next, 288, fl);
-                construct<kDFast>(dc, Fast8{T.dfast}, ds, Cd.offs, Cd.next, 30, fd);
+                construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl);
+                construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
             } else {
                 const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
                 if (nlen > 286 || ndist > 30) return ERR_TABLE;
-                // the code-length code: its 19 lengths in the order of RFC 1951, 3.2.7
-                for (int k = 0; k < 19; ++k) lens[k] = 0;
+                // the code-length code: its 19 lengths (3 bits each, in the order of RFC 1951, 3.2.7) in one register
+                uint64_t clw = 0;
                 for (int k = 0; k < ncode; ++k) {
-                    refill(in);
-                    lens[cl_order(k)] = (uint8_t)take(in, 3);
+                    if (in.cnt < 8) refill(in);
+                    clw |= (uint64_t)take(in, 3) << (3 * cl_order(k));
                 }
                 Counts cc;
-                // the code-length symbols are sorted into dsym (free until the distance code is built)
-                if (!construct<0>(cc, Fast8{nullptr}, ds, Cd.offs, Cd.next, 19, [&](int i) { return (int)lens[i]; }))
+                // Its codes are at most 7 bits long, so a 7-bit table answers every one of them: it is built in the
+                // hot symbols' LDS (128 bytes, rewritten with the literal/length table below).  (The symbols are
+                // sorted into ds as well -- free until the distance code is built -- for builds with fewer hot symbols.)
+                constexpr bool kClTable = kHotSyms >= 128;
+                if (!construct<kClTable ? 7 : 0>(cc, Fast8{kClTable ? T.lsym_hot : nullptr}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); }))
                     return ERR_TABLE;
-                // literal/length + distance code lengths, run-length coded
-                int idx = 0;
+                // literal/length + distance code lengths, run-length coded.  They are collected in the first-level
+                // literal table's LDS (free until that table is rebuilt below) and copied to the scratch in one go:
+                // a store per length to global memory made every wait of this loop -- each refill's -- a wait for
+                // the stores before it (2,000 cycles per code length: 630,000 of a header's 1.2 million).
+                int idx = 0, prev_len = 0;
                 uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
+                uint8_t *ll_near = reinterpret_cast<uint8_t *>(T.lfast);
+                static_assert(sizeof(T.lfast) >= 320, "the code lengths are staged in the literal table's storage");
                 while (idx < nlen + ndist) {
-                    refill(in);
-                    const int s = decode_walk(in, cc, ds);
+                    if (in.cnt < 24) refill(in);                  // 15 bits of code + 7 of repeat count
+                    int s;
+                    if (kClTable) {
+                        const uint32_t e = T.lsym_hot[in.buf & 127u];
+                        if (!e) return ERR_CODE;
+                        in.buf >>= (e & 7u);
+                        in.cnt -= (int)(e & 7u);
+                        s = (int)(e >> 3);
+                    } else {
+                        s = decode_walk(in, cc, ds);
+                    }
                     if (s < 0) return ERR_CODE;
                     if (s < 16) {
-                        ll[idx++] = (uint8_t)s;
+                        ll_near[idx++] = (uint8_t)s;
+                        prev_len = s;
                     } else {
                         int prev = 0, rep;
                         if (s == 16) {
                             if (idx == 0) return ERR_TABLE;
-                            prev = ll[idx - 1];
+                            prev = prev_len;
                             rep = 3 + (int)take(in, 2);
                         } else if (s == 17) {
                             rep = 3 + (int)take(in, 3);
@@ -545,14 +606,18 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                             rep = 11 + (int)take(in, 7);
                         }
                         if (idx + rep > nlen + ndist) return ERR_TABLE;
-                        while (rep--) ll[idx++] = (uint8_t)prev;
+                        while (rep--) ll_near[idx++] = (uint8_t)prev;
+                        prev_len = prev;
                     }
                     if (overrun(in)) return ERR_INPUT;
                 }
-                if (ll[256] == 0) return ERR_TABLE;               // no end-of-block code
-                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, Cd.offs, Cd.next, nlen, [&](int i) { return (int)ll[i]; })) return ERR_TABLE;
-                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, Cd.offs, Cd.next, ndist, [&](int i) { return (int)ll[nlen + i]; }))
-                    return ERR_TABLE;
+                for (int k = 0; k < nlen + ndist; k += 8) store64(ll + k, load64(ll_near + k));      // (<= 320 bytes either side)
+                {
+                    LenReader eob(ll + 256);
+                    if (eob(0) == 0) return ERR_TABLE;            // no end-of-block code
+                }
+                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll))) return ERR_TABLE;
+                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) return ERR_TABLE;
             }
             // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
             // The bytes of a match are LOADED in the turn that meets it and STORED in the next one,

@@ -23,11 +23,12 @@ from bamsignals_amd.device import Context, Reads  # noqa: E402
 from bamsignals_amd.synth import synth_reads  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "real"
-if kind == "real":
-    bam = "/tmp/dd_real.bam"
+if kind in ("real", "real6"):
+    # (real6: the same records written at zlib level 6, htslib's default: shorter literal runs, more matches)
+    bam = "/tmp/dd_real.bam" if kind == "real" else "/tmp/dd_real6.bam"
     if not os.path.exists(bam):
         cols = synth_reads(20_000_000, [250_000_000], seed=12)
-        write_columns_as_bam(bam, ["chr1"], cols, level=1, l_seq=100, seed=3)
+        write_columns_as_bam(bam, ["chr1"], cols, level=1 if kind == "real" else 6, l_seq=100, seed=3)
         del cols
 else:
     bam = "/tmp/ns_small.bam"
