@@ -38,7 +38,7 @@ namespace bsig_inflate {
 #ifndef BSIG_DFAST
 #define BSIG_DFAST 6
 #endif
-constexpr int kLFast = BSIG_LFAST, kDFast = BSIG_DFAST;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit, <= 7 bits)
+constexpr int kLFast = BSIG_LFAST, kDFast = BSIG_DFAST;   // first-level table bits (literal/length: 16-bit entries; distance: 8-bit, 6 or 7 bits)
 #ifndef BSIG_MULTI_LIT
 #define BSIG_MULTI_LIT 1
 #endif
@@ -56,7 +56,7 @@ constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn o
 #define BSIG_HOT_SYMS 128
 #endif
 constexpr int kHotSyms = BSIG_HOT_SYMS;      // (a multiple of 64) literal/length symbols with codes longer than the first-level table kept in LDS
-struct LaneTables {
+struct alignas(4) LaneTables {
     uint16_t lfast[1 << kLFast];   // literal/length: (symbol << 4) | code length, 0 = longer code
     uint8_t dfast[1 << kDFast];    // distance: (symbol << 3) | code length (<= kDFast), 0 = longer code
     // the first kHotSyms sorted symbols whose codes are LONGER than the first-level table (the shortest of the
@@ -390,6 +390,16 @@ struct Slots16 {
     }
 };
 
+// ... or in sixteen 16-bit words of LDS that nobody else needs meanwhile (the distance table's, while the
+// literal/length table is built: a slot is then one read and one write instead of two dozen selects)
+struct SlotsMem {
+    uint16_t *p;
+    BSIG_HD void clear() { for (int k = 0; k < 16; ++k) p[k] = 0; }
+    BSIG_HD uint32_t get(int l) const { return p[l]; }
+    BSIG_HD void add(int l, uint32_t d) { p[l] = (uint16_t)(p[l] + d); }
+    BSIG_HD void set(int l, uint32_t val) { p[l] = (uint16_t)val; }
+};
+
 // the code lengths a dynamic block's header left in the scratch, read eight at a time
 struct LenReader {
     const uint8_t *p;
@@ -404,11 +414,10 @@ struct LenReader {
     }
 };
 
-template <int FAST, typename FastT, typename Syms, typename LenAt>
-BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len_at)
+template <int FAST, typename FastT, typename Syms, typename LenAt, typename Slots>
+BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len_at, Slots offs, Slots next)
 {
     sym.clear();
-    Slots16 offs, next;
     offs.clear();
     next.clear();
     for (int i = 0; i < n; ++i) offs.add(len_at(i), 1u);                  // offs = counts for now (slot 0: unused symbols)
@@ -447,6 +456,12 @@ BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len
             for (uint32_t k = bit_reverse(cd, l); k < (1u << FAST); k += 1u << l) fast.put(k, i, l);
     }
     return true;
+}
+
+template <int FAST, typename FastT, typename Syms, typename LenAt>
+BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len_at)
+{
+    return construct<FAST>(c, fast, sym, n, len_at, Slots16{}, Slots16{});
 }
 
 // position k of the code-length code's lengths in the stream -> symbol (RFC 1951, 3.2.7:
@@ -523,6 +538,9 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
     Counts lc, dc;
     ColdTables &Cd = *reinterpret_cast<ColdTables *>(lens + kLensCodes);
     LSyms ls{Cd.lsym, Cd.lhi, T.lsym_hot, {}, 0};
+    // (the slots of the literal/length table's construction: the distance table's 64 bytes, rebuilt right after it)
+    static_assert(sizeof(T.dfast) >= 64, "the distance table's LDS doubles as the literal table's construction slots");
+    const SlotsMem lit_offs{reinterpret_cast<uint16_t *>(T.dfast)}, lit_next{reinterpret_cast<uint16_t *>(T.dfast) + 16};
     DSyms ds;
     ds.clear();
     for (;;) {
@@ -552,7 +570,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
                 auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
                 auto fd = [](int) { return 5; };
-                construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl);
+                construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl, lit_offs, lit_next);
                 construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
             } else {
                 const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
@@ -578,6 +596,9 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
                 uint8_t *ll_near = reinterpret_cast<uint8_t *>(T.lfast);
                 static_assert(sizeof(T.lfast) >= 320, "the code lengths are staged in the literal table's storage");
+                // (zeroed first: the runs of unused symbols -- codes 17 and 18, up to 138 lengths each, and every
+                // lane of a wave waits for the longest -- then only move the index)
+                for (int k = 0; k < 320 / 4; ++k) reinterpret_cast<uint32_t *>(T.lfast)[k] = 0;
                 while (idx < nlen + ndist) {
                     if (in.cnt < 24) refill(in);                  // 15 bits of code + 7 of repeat count
                     int s;
@@ -606,7 +627,11 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                             rep = 11 + (int)take(in, 7);
                         }
                         if (idx + rep > nlen + ndist) return ERR_TABLE;
-                        while (rep--) ll_near[idx++] = (uint8_t)prev;
+                        if (prev) {
+                            while (rep--) ll_near[idx++] = (uint8_t)prev;      // (code 16: at most six)
+                        } else {
+                            idx += rep;
+                        }
                         prev_len = prev;
                     }
                     if (overrun(in)) return ERR_INPUT;
@@ -616,7 +641,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     LenReader eob(ll + 256);
                     if (eob(0) == 0) return ERR_TABLE;            // no end-of-block code
                 }
-                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll))) return ERR_TABLE;
+                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next)) return ERR_TABLE;
                 if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) return ERR_TABLE;
             }
             // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
