@@ -266,7 +266,8 @@ def end_to_end_realistic(seed, device, oracle_c):
     reads on 250 Mbp WITH read names, bases, qualities and an NM tag (204-byte records, 4 GB of stream
     that compresses about 1.9 : 1), 10k x 2 kb ranges -- under both inflate engines, next to the same
     single-thread CPU path as above.  The bench's own BAM carries bare 52-byte records (SURVEY 8d);
-    this is what the decode stage costs on literal-heavy DEFLATE blocks."""
+    this is what the decode stage costs on literal-heavy DEFLATE blocks.  The file is written at zlib level 1,
+    like the bench's own; one more cold call runs on the same records at level 6, htslib's default."""
     import shutil
     import tempfile
 
@@ -309,6 +310,20 @@ def end_to_end_realistic(seed, device, oracle_c):
                               cold_call_loading_it_s=t_load, Mbases_s=bases / t_load / 1e6)
         out["measured_in"] = "fresh child processes with their HIP context up (see cold_call_in_fresh_process)"
         del flat
+        # the same records at zlib level 6, htslib's default (the files above are level 1, like the bench's own BAM):
+        # shorter literal runs, more matches and several deflate blocks -- code tables -- per BGZF block
+        bam6 = os.path.join(d, "real6.bam")
+        t0 = time.perf_counter(); write_columns_as_bam(bam6, ["ref1"], cols, level=6, l_seq=l_seq, seed=seed); t_write6 = time.perf_counter() - t0
+        _settle(bam6)
+        child, flat = cold_call_in_fresh_process(d, "real6", bam6, ["ref1"], rg, call, device, reps=1)
+        if not np.array_equal(flat, want):
+            raise SystemExit("file-level result on the level-6 real-shaped BAM differs from the oracle")
+        del flat
+        c0 = child["calls"][0]
+        out["cold_default_zlib_level_6"] = dict(bam_bytes=os.path.getsize(bam6), write_bam_s=t_write6, call_s=c0["call_s"],
+                                                Mbases_s=bases / c0["call_s"] / 1e6, decode_stages_s=c0["stages_s"]["decode_stages_s"],
+                                                route=c0["route"])
+        os.remove(bam6); os.remove(bam6 + ".bai")
         b = BamFile(bam)
         dec = b.decode(threads=1)
         t_dec1 = b.decode_timing()["total"]
