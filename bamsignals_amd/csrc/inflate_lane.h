@@ -368,25 +368,34 @@ struct Fast8 {
 // store in flight, and a store -- two trips to memory per symbol, 1.6 million cycles per code table, a tenth of a
 // lane's time on blocks that hold six deflate blocks (zlib level 6) and a third of its wave's, because the lanes
 // of a wave reach their tables at different times)
+// (every loop over the words is unrolled by hand: left to itself the compiler kept `w` in scratch memory and indexed
+// it there -- a trip to memory per access, which is what the registers were for)
 struct Slots16 {
-    uint32_t w[8];
-    BSIG_HD void clear() { for (int k = 0; k < 8; ++k) w[k] = 0; }
+    uint32_t w0, w1, w2, w3, w4, w5, w6, w7;
+    // all-ones if word k is the one slot l lives in (masks and ORs, not selects: a chain of selects over the
+    // eight words is what the compiler turns back into an array in scratch memory)
+    static BSIG_HD uint32_t is(int l, int k) { return 0u - (uint32_t)((l >> 1) == k); }
+    BSIG_HD void clear() { w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = 0; }
     BSIG_HD uint32_t get(int l) const
     {
-        uint32_t x = w[0];
-        for (int k = 1; k < 8; ++k) x = (l >> 1) == k ? w[k] : x;
+        const uint32_t x = (w0 & is(l, 0)) | (w1 & is(l, 1)) | (w2 & is(l, 2)) | (w3 & is(l, 3)) |
+                           (w4 & is(l, 4)) | (w5 & is(l, 5)) | (w6 & is(l, 6)) | (w7 & is(l, 7));
         return (x >> ((l & 1) * 16)) & 0xFFFFu;
     }
     BSIG_HD void add(int l, uint32_t d)                    // (values stay below 65,536: no carry into the neighbour)
     {
         const uint32_t v = d << ((l & 1) * 16);
-        for (int k = 0; k < 8; ++k) w[k] += (l >> 1) == k ? v : 0u;
+        w0 += v & is(l, 0); w1 += v & is(l, 1); w2 += v & is(l, 2); w3 += v & is(l, 3);
+        w4 += v & is(l, 4); w5 += v & is(l, 5); w6 += v & is(l, 6); w7 += v & is(l, 7);
     }
     BSIG_HD void set(int l, uint32_t val)
     {
         const int sh = (l & 1) * 16;
-        for (int k = 0; k < 8; ++k)
-            if ((l >> 1) == k) w[k] = (w[k] & ~(0xFFFFu << sh)) | ((val & 0xFFFFu) << sh);
+        const uint32_t field = 0xFFFFu << sh, put = (val & 0xFFFFu) << sh;
+        w0 = (w0 & ~(field & is(l, 0))) | (put & is(l, 0)); w1 = (w1 & ~(field & is(l, 1))) | (put & is(l, 1));
+        w2 = (w2 & ~(field & is(l, 2))) | (put & is(l, 2)); w3 = (w3 & ~(field & is(l, 3))) | (put & is(l, 3));
+        w4 = (w4 & ~(field & is(l, 4))) | (put & is(l, 4)); w5 = (w5 & ~(field & is(l, 5))) | (put & is(l, 5));
+        w6 = (w6 & ~(field & is(l, 6))) | (put & is(l, 6)); w7 = (w7 & ~(field & is(l, 7))) | (put & is(l, 7));
     }
 };
 
@@ -461,7 +470,10 @@ BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len
 template <int FAST, typename FastT, typename Syms, typename LenAt>
 BSIG_HD bool construct(Counts &c, const FastT &fast, Syms &sym, int n, LenAt len_at)
 {
-    return construct<FAST>(c, fast, sym, n, len_at, Slots16{}, Slots16{});
+    Slots16 a, b;
+    a.clear();
+    b.clear();
+    return construct<FAST>(c, fast, sym, n, len_at, a, b);
 }
 
 // position k of the code-length code's lengths in the stream -> symbol (RFC 1951, 3.2.7:
