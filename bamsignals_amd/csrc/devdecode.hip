@@ -442,6 +442,21 @@ size_t inflate_round_blocks(int device)
     return c;
 }
 
+}  // namespace
+// (debug: what the compiler made of k_inflate -- registers per lane, scratch bytes per lane (spills or arrays it
+// moved to memory: there must be none), the round of resident lanes; tests/test_device_decode_gpu.py)
+extern "C" int bsig_debug_inflate_attrs(int device, int *vgprs, int *scratch_bytes, int64_t *round_blocks)
+{
+    hipFuncAttributes a;
+    if (hipSetDevice(device) != hipSuccess) return 1;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_inflate<32>)) != hipSuccess) return 2;
+    if (vgprs) *vgprs = a.numRegs;
+    if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
+    if (round_blocks) *round_blocks = (int64_t)inflate_round_blocks(device);
+    return 0;
+}
+namespace {
+
 // crc_st != nullptr: the CRC kernel runs there, behind `inflated` (an event the caller owns), beside
 // whatever the caller queues on st next -- it keeps two waves per CU busy and so does the record walk;
 // its verdict lands in `crc_status`, which the caller reads once crc_st has drained.

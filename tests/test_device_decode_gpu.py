@@ -345,6 +345,23 @@ def test_head_of_the_file_decoded_while_the_rest_is_tabulated(ctx, tmp_path, mon
         dev.close()
 
 
+def test_inflate_kernel_keeps_its_state_in_registers(ctx):
+    """k_inflate's per-lane state -- bit buffer, code counts, construction slots, deferred match words -- lives in
+    registers and LDS.  Twice in round 3 a harmless-looking change (a select chain over eight words, a local array
+    indexed by a loop) made the compiler move it to scratch memory: a trip to memory per access.  And the occupancy
+    the decode's passes are cut for (seven 32-lane workgroups per CU) depends on the register and LDS budget."""
+    import ctypes
+    from bamsignals_amd import _lib
+    lib = _lib.load()
+    fn = lib.bsig_debug_inflate_attrs
+    fn.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]
+    regs, scratch, rnd = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int64(0)
+    assert fn(0, ctypes.byref(regs), ctypes.byref(scratch), ctypes.byref(rnd)) == 0
+    assert scratch.value == 0, scratch.value
+    assert 0 < regs.value <= 168, regs.value                       # three waves per SIMD
+    assert rnd.value >= 256 * 7 * 32, rnd.value                    # at least seven workgroups of 32 lanes per CU
+
+
 def test_passes_are_whole_rounds_of_inflate_lanes(ctx, tmp_path, monkeypatch, capfd):
     """A k_inflate launch lasts one block's latency per round of resident lanes, so every pass of a decode that is
     not its share's last holds a whole number of rounds (57,344 blocks on an MI355X: only the bench's files are
