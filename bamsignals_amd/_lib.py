@@ -34,9 +34,10 @@ class Columns(C.Structure):
 
 
 class ReadsInfo(C.Structure):
-    _fields_ = [("n_reads", C.c_int64), ("hbm_bytes", C.c_int64), ("n_classes", C.c_int32),
-                ("class_n", C.c_int64 * 4), ("class_maxspan", C.c_int32 * 4),
-                ("class_bucket_shift", C.c_int32 * 4)]
+    # classes 0..3 by span, 4 = the packed class (include/bamsignals_abi.h: BSIG_N_CLASSES)
+    _fields_ = [("n_reads", C.c_int64), ("hbm_bytes", C.c_int64), ("n_classes", C.c_int32), ("n_codes", C.c_int32),
+                ("class_n", C.c_int64 * 5), ("class_maxspan", C.c_int32 * 5),
+                ("class_bucket_shift", C.c_int32 * 5)]
 
 
 class Params(C.Structure):
@@ -51,7 +52,8 @@ class PlanStats(C.Structure):
     _fields_ = [("n_ranges", C.c_int64), ("n_items", C.c_int64), ("cells", C.c_int64),
                 ("visits", C.c_int64), ("visits_short", C.c_int64), ("streamed", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("bytes_per_visit_short", C.c_int32),
-                ("bytes_per_visit_long", C.c_int32)]
+                ("bytes_per_visit_long", C.c_int32), ("visits_packed", C.c_int64),
+                ("bytes_per_visit_packed", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

@@ -1,9 +1,18 @@
 // Structures shared by the host runtime and the gfx950 kernels.
 //
 // HBM layout of the reads (built once per BAM by the prep kernels):
-//   * reads are split by reference span into up to BSIG_MAX_CLASSES "span classes"
-//     (span <= 256 | <= 4096 | <= 65536 | longer).  Inside a class they keep BAM order
-//     (sorted by reference id, then pos).  A class has four 32-bit columns
+//   * reads are split by reference span into "span classes" (span <= 256 | <= 4096 | <= 65536 |
+//     longer = classes 0..3), and the short ones (span <= 256) once more: those whose (flag, mapq)
+//     pair is one of the file's BSIG_PACK_CODES most frequent pairs form the PACKED class
+//     (BSIG_CLASS_PACKED), ONE 32-bit word per read
+//        word : pos & 0x7FFF | (span - 1) << 15 | code << 23
+//     -- a read window is narrower than 32,768 bases (wider ones are walked in chunks of that
+//     width), so the low 15 bits of pos and the window's start give pos back; `code` indexes the
+//     file's pair table fmtab[code] = flag | mapq << 16.  The filter on flag and mapq
+//     (src/bamsignals.cpp:328-331) is evaluated once per code and launch, not once per read.
+//     Short reads with a rarer pair, with flag bits above the 12 SAM defines or with pos outside
+//     their reference stay in class 0.  Inside a class reads keep BAM order
+//     (sorted by reference id, then pos).  Classes 0..3 have 32-bit columns
 //        pos  : 0-based leftmost position                         (core.pos)
 //        end  : bam_endpos - 1, inclusive                         (src/bamsignals.cpp:16-18)
 //               -- classes 2..3 only; classes 0 and 1 keep span - 1 inside fm
@@ -22,7 +31,11 @@
 #define BSIG_TYPES_H
 #include <stdint.h>
 
-#define BSIG_MAX_CLASSES 4
+#define BSIG_MAX_CLASSES 5
+#define BSIG_SPAN_CLASSES 4      // classes 0..3: by span
+#define BSIG_CLASS_PACKED 4      // span <= 256 and a frequent (flag, mapq) pair: one word per read (in .fm)
+#define BSIG_PACK_POS_BITS 15    // low bits of pos kept in a packed word = log2 of a window chunk
+#define BSIG_PACK_CODES 512      // entries of the pair table (9-bit codes)
 #define BSIG_REF_UNIT_SHIFT 16   // references are laid out in units of 65536 bp
 
 struct BsigClassCols {
@@ -38,6 +51,8 @@ struct BsigClassCols {
 
 struct BsigReadsDev {
     BsigClassCols cls[BSIG_MAX_CLASSES];
+    const uint32_t *fmtab;   // BSIG_PACK_CODES entries: flag | mapq << 16 of a packed word's code (zero-padded)
+    int32_t n_codes;         // codes in use
 };
 
 // One unit of GPU work: a tile of at most `tile_cells` output cells of one range
@@ -57,6 +72,13 @@ struct BsigWorkItem {
 #define BSIG_ITEM_NEG (1u << 30)           // range is on the '-' strand
 #define BSIG_ITEM_ATOMIC (1u << 31)        // count mode: add with a global atomic (range was split)
 
+// What the index says about one tile (k_resolve_tiles -> the pileup kernels of a large launch): the read
+// windows of the five classes, and the packed class's first chunk
+struct BsigResolved {
+    uint32_t win[2 * BSIG_MAX_CLASSES];   // [j_lo, j_hi) per class
+    int32_t pbase, pchunks;
+};
+
 struct BsigKParams {
     int32_t mapqual;
     uint32_t requiredF;
@@ -75,6 +97,9 @@ struct BsigKParams {
     int32_t tile_cells;     // output cells per tile (sizes the dynamic LDS image)
     int32_t accumulate;     // 1: add the tile image into the result with integer atomics (slices of
                             // a heavy tile) instead of storing it
+    int32_t resolved;       // 1: `windows` holds one BsigResolved per tile, written by k_resolve_tiles in
+                            // front of this launch (large launches: the tile's item and its windows then
+                            // arrive in ONE memory round trip instead of two dependent ones)
 };
 
 #endif

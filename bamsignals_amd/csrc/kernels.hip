@@ -47,18 +47,47 @@ constexpr int kWave = 64;
 // shared device helpers
 // ------------------------------------------------------------------------------------------
 
-// The filter of Pileupper::setRead (src/bamsignals.cpp:328-333) == Coverager::setRead (:394-399).
-__device__ __forceinline__ bool read_rejected(const BsigKParams &P, uint32_t fm, int32_t tl)
+// The filter of Pileupper::setRead (src/bamsignals.cpp:328-333) == Coverager::setRead (:394-399), in two parts:
+// what only reads flag and mapq (:328-331) -- a property of the (flag, mapq) pair, evaluated per read for the
+// span classes and once per code and launch for the packed class (build_ptab) -- ...
+__device__ __forceinline__ bool fm_rejected(const BsigKParams &P, uint32_t fm)
 {
     const uint32_t nf = ~(fm & 0xFFFFu);                 // ~flag after int promotion
     const int mapq = (int)((fm >> 16) & 0xFFu);
-    bool rej = (mapq < P.mapqual) | ((P.requiredF & nf) != 0u) | ((P.filteredF & nf) == 0u);
-    if (P.has_tlen_filter) {
-        const int a = tl < 0 ? -tl : tl;
-        rej |= (a < P.tf0) | (a > P.tf1);
-    }
-    return rej;
+    return (mapq < P.mapqual) | ((P.requiredF & nf) != 0u) | ((P.filteredF & nf) == 0u);
 }
+// ... and what reads the template length (:332-333)
+__device__ __forceinline__ bool tlen_rejected(const BsigKParams &P, int32_t tl)
+{
+    if (!P.has_tlen_filter) return false;
+    const int a = tl < 0 ? -tl : tl;
+    return (a < P.tf0) | (a > P.tf1);
+}
+
+constexpr int kPackChunk = 1 << BSIG_PACK_POS_BITS;        // bases a packed word's position bits span
+constexpr uint32_t kPackPosMask = (uint32_t)kPackChunk - 1u;
+
+// Per launch and workgroup: what the flag/mapq filter says about every code of the packed class, one byte per
+// code in LDS (bit 0: rejected, bit 1: reverse strand).  The pair table is 2 KB and stays in L2.
+template <int NT>
+__device__ __forceinline__ void build_ptab(uint8_t *ptab, const BsigReadsDev &R, const BsigKParams &P, int tid)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(R.fmtab);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(ptab);
+    for (int v = tid; 4 * v < R.n_codes; v += NT) {
+        const uint4 f = src[v];
+        auto b = [&](uint32_t fm) { return (uint32_t)fm_rejected(P, fm) | ((fm >> 3) & 2u); };     // 0x10 >> 3
+        dst[v] = b(f.x) | b(f.y) << 8 | b(f.z) << 16 | b(f.w) << 24;
+    }
+}
+
+// The packed class's window of a tile: the reads whose pos lies in the bucket-rounded window [rlo, rhi) of the
+// reference, walked in chunks of kPackChunk bases (nearly always one): inside a chunk that starts at `base`,
+// pos = base + ((word - base) & kPackPosMask).
+struct PackedWin {
+    int base;          // start of the first chunk (reference coordinate, a multiple of the bucket width)
+    int n_chunks;      // 0: nothing to read
+};
 
 // Reads of class C that can touch the genomic interval [tlo, thi) lie in [j_lo, j_hi).
 // pos in [tlo - ext - maxspan + 1, thi + ext), rounded outwards to index buckets.
@@ -156,17 +185,17 @@ __device__ __forceinline__ void item_interval(const BsigWorkItem &w, const BsigK
     else tile_interval(w, mode == BSIG_MODE_COVERAGE ? 1 : P.binsize, neg_range, tlo, thi);
 }
 
-// Index lookup for every (tile, span class): windows[4*t + c] = [j_lo, j_hi) of class c's reads
+// Index lookup for every (tile, class): windows[BSIG_MAX_CLASSES*t + c] = [j_lo, j_hi) of class c's reads
 // that can touch tile t.  The device-side counterpart of bam_itr_queryi (src/bamsignals.cpp:267).
-// It runs in front of the pileup kernel on every bsig_plan_run(), so that the pileup workgroups,
-// which hold LDS, start with their windows known instead of chasing item -> index -> columns.
+// Runs once per plan (bsig_plan_create probes the window sizes for heavy tiles); the pileup kernels look
+// their windows up themselves (load_windows).
 __global__ void k_resolve(const BsigReadsDev R, const BsigKParams P, int mode,
                           const BsigWorkItem *__restrict__ items, int64_t n_items,
                           uint2 *__restrict__ windows)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t t = g >> 2;
-    const int c = (int)(g & 3);
+    const int64_t t = g / BSIG_MAX_CLASSES;
+    const int c = (int)(g - t * BSIG_MAX_CLASSES);
     if (t >= n_items) return;
     const BsigWorkItem w = items[t];
     int64_t tlo, thi;
@@ -192,96 +221,127 @@ __global__ void k_count_heavy(const uint2 *__restrict__ windows, int64_t n_items
     if (total > heavy_reads) atomicAdd(count, 1ull);
 }
 
-// class 1's word (flag (12 bits) | mapq << 12 | (span - 1) << 20, see span_class below) in the layout the
+// class 1's word (flag (12 bits) | mapq << 12 | (span - 1) << 20, see read_class below) in the layout the
 // filters read: flag | mapq << 16
 __device__ __forceinline__ uint32_t fm_of_class1(uint32_t w) { return (w & 0xFFFu) | ((w >> 12) & 0xFFu) << 16; }
 
-// Stream the reads of all span-class windows of one tile through `one(pos, end, fm, tlen, valid)`.
-// Everything a typical tile needs is requested before anything is consumed, so the workgroup pays
-// ONE memory round trip for its reads: the first kPre0 passes (kPre0 * 4 * NT reads) of class 0,
-// where nearly all reads live, and the first pass of class 1.  Longer windows and the two
-// long-span classes continue in plain loops.
-template <int NT, int kPre0 = 4, typename F>
-__device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
-                                              const uint2 (&win)[BSIG_MAX_CLASSES], int tid, F &&one)
+// four consecutive packed words (one lane's 16-B load) of a chunk that starts at `base`
+template <typename F>
+__device__ __forceinline__ void four_packed(const uint4 &w, const int4 &t, uint32_t j, uint32_t j_lo, uint32_t nj, int base,
+                                            const uint8_t *__restrict__ ptab, F &&one)
 {
-    int4 p0[kPre0], t0[kPre0], p1, t1 = make_int4(0, 0, 0, 0);
-    uint4 f0[kPre0], f1;
-    const uint32_t jb0 = (win[0].x & ~3u) + 4u * tid;
+    // the four table bytes are requested before the first one is used
+    const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
+    const uint32_t dj = j - j_lo;
+    auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
+        const int pos = base + (int)((x - (uint32_t)base) & kPackPosMask);
+        one(pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid);
+    };
+    dec(w.x, b0, t.x, dj < nj);
+    dec(w.y, b1, t.y, dj + 1u < nj);
+    dec(w.z, b2, t.z, dj + 2u < nj);
+    dec(w.w, b3, t.w, dj + 3u < nj);
+}
+
+// Stream the reads of all class windows of one tile through `one(pos, end, neg, rejected, tlen, valid)`
+// (`rejected`: by the flag/mapq part of the filter).  Everything a typical tile needs is requested before
+// anything is consumed, so the workgroup pays ONE memory round trip for its reads: the first kPre passes
+// (kPre * 4 * NT reads) of the packed class, where nearly all reads live, and the first pass of classes 0
+// and 1.  Longer windows and the two long-span classes continue in plain loops.
+// (The packed class's later chunks -- windows wider than kPackChunk bases -- are walked by packed_later_chunks.)
+template <int NT, int kPre = 4, typename F>
+__device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
+                                              const uint2 (&win)[BSIG_MAX_CLASSES], int pbase,
+                                              const uint8_t *__restrict__ ptab, int tid, F &&one)
+{
+    uint4 w0[kPre];
+    int4 t0[kPre];
+    const BsigClassCols &CP = R.cls[BSIG_CLASS_PACKED];
+    const uint32_t jbp = (win[BSIG_CLASS_PACKED].x & ~3u) + 4u * tid;
 #pragma unroll
-    for (int k = 0; k < kPre0; ++k) {
-        const uint32_t j = jb0 + 4u * NT * k;
+    for (int k = 0; k < kPre; ++k) {
+        const uint32_t j = jbp + 4u * NT * k;
         t0[k] = make_int4(0, 0, 0, 0);
-        if (j < win[0].y) {
-            p0[k] = *reinterpret_cast<const int4 *>(R.cls[0].pos + j);
-            f0[k] = *reinterpret_cast<const uint4 *>(R.cls[0].fm + j);
-            if (P.use_tlen) t0[k] = *reinterpret_cast<const int4 *>(R.cls[0].tlen + j);
+        if (j < win[BSIG_CLASS_PACKED].y) {
+            w0[k] = *reinterpret_cast<const uint4 *>(CP.fm + j);
+            if (P.use_tlen) t0[k] = *reinterpret_cast<const int4 *>(CP.tlen + j);
         }
+    }
+    int4 pa = make_int4(0, 0, 0, 0), ta = make_int4(0, 0, 0, 0), pb = make_int4(0, 0, 0, 0), tb = make_int4(0, 0, 0, 0);
+    uint4 fa = make_uint4(0, 0, 0, 0), fb = make_uint4(0, 0, 0, 0);
+    const uint32_t jb0 = (win[0].x & ~3u) + 4u * tid;
+    if (jb0 < win[0].y) {
+        pa = *reinterpret_cast<const int4 *>(R.cls[0].pos + jb0);
+        fa = *reinterpret_cast<const uint4 *>(R.cls[0].fm + jb0);
+        if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(R.cls[0].tlen + jb0);
     }
     const uint32_t jb1 = (win[1].x & ~3u) + 4u * tid;
     if (jb1 < win[1].y) {
-        p1 = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
-        f1 = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
-        if (P.use_tlen) t1 = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
+        pb = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
+        fb = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
+        if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
     }
     // The 16-B aligned loads may start before j_lo (possibly on the previous reference) and end
     // after j_hi: only reads in [j_lo, j_hi) count -> `dj < nj` with unsigned wrap-around.
-    {   // ---- class 0 (span <= 256): no end column, end = pos + (fm >> 24) ------------------------
-        const BsigClassCols &C = R.cls[0];
-        const uint32_t j_lo = win[0].x, j_hi = win[0].y, nj = j_hi - j_lo;
-        auto four = [&](const int4 &p, const uint4 &f, const int4 &t, uint32_t j) {
-            const uint32_t dj = j - j_lo;
-            one(p.x, p.x + (int)(f.x >> 24), f.x, t.x, dj < nj);
-            one(p.y, p.y + (int)(f.y >> 24), f.y, t.y, dj + 1u < nj);
-            one(p.z, p.z + (int)(f.z >> 24), f.z, t.z, dj + 2u < nj);
-            one(p.w, p.w + (int)(f.w >> 24), f.w, t.w, dj + 3u < nj);
-        };
+    {   // ---- packed class (span <= 256, a frequent flag/mapq pair): one word per read -------------------
+        const uint32_t j_lo = win[BSIG_CLASS_PACKED].x, j_hi = win[BSIG_CLASS_PACKED].y, nj = j_hi - j_lo;
 #pragma unroll
-        for (int k = 0; k < kPre0; ++k) {
-            const uint32_t j = jb0 + 4u * NT * k;
-            if (j < j_hi) four(p0[k], f0[k], t0[k], j);
+        for (int k = 0; k < kPre; ++k) {
+            const uint32_t j = jbp + 4u * NT * k;
+            if (j < j_hi) four_packed(w0[k], t0[k], j, j_lo, nj, pbase, ptab, one);
         }
         // deeper windows: two passes per trip, both requested before either is consumed
-        for (uint32_t j = jb0 + 4u * NT * kPre0; j < j_hi; j += 8u * NT) {
+        for (uint32_t j = jbp + 4u * NT * kPre; j < j_hi; j += 8u * NT) {
             const uint32_t j2 = j + 4u * NT;
-            const int4 pa = *reinterpret_cast<const int4 *>(C.pos + j);
-            const uint4 fa = *reinterpret_cast<const uint4 *>(C.fm + j);
-            int4 ta = make_int4(0, 0, 0, 0), tb = make_int4(0, 0, 0, 0), pb = make_int4(0, 0, 0, 0);
-            uint4 fb = make_uint4(0, 0, 0, 0);
-            if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(C.tlen + j);
+            const uint4 wa = *reinterpret_cast<const uint4 *>(CP.fm + j);
+            int4 xa = make_int4(0, 0, 0, 0), xb = make_int4(0, 0, 0, 0);
+            uint4 wb = make_uint4(0, 0, 0, 0);
+            if (P.use_tlen) xa = *reinterpret_cast<const int4 *>(CP.tlen + j);
             if (j2 < j_hi) {
-                pb = *reinterpret_cast<const int4 *>(C.pos + j2);
-                fb = *reinterpret_cast<const uint4 *>(C.fm + j2);
-                if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(C.tlen + j2);
+                wb = *reinterpret_cast<const uint4 *>(CP.fm + j2);
+                if (P.use_tlen) xb = *reinterpret_cast<const int4 *>(CP.tlen + j2);
             }
-            four(pa, fa, ta, j);
-            if (j2 < j_hi) four(pb, fb, tb, j2);
+            four_packed(wa, xa, j, j_lo, nj, pbase, ptab, one);
+            if (j2 < j_hi) four_packed(wb, xb, j2, j_lo, nj, pbase, ptab, one);
+        }
+    }
+    {   // ---- class 0 (span <= 256, a rare pair): no end column, end = pos + (fm >> 24) ------------------
+        const BsigClassCols &C = R.cls[0];
+        const uint32_t j_lo = win[0].x, j_hi = win[0].y, nj = j_hi - j_lo;
+        for (uint32_t j = jb0; j < j_hi;) {
+            const uint32_t dj = j - j_lo;
+            one(pa.x, pa.x + (int)(fa.x >> 24), (fa.x & 0x10u) != 0u, fm_rejected(P, fa.x), ta.x, dj < nj);
+            one(pa.y, pa.y + (int)(fa.y >> 24), (fa.y & 0x10u) != 0u, fm_rejected(P, fa.y), ta.y, dj + 1u < nj);
+            one(pa.z, pa.z + (int)(fa.z >> 24), (fa.z & 0x10u) != 0u, fm_rejected(P, fa.z), ta.z, dj + 2u < nj);
+            one(pa.w, pa.w + (int)(fa.w >> 24), (fa.w & 0x10u) != 0u, fm_rejected(P, fa.w), ta.w, dj + 3u < nj);
+            j += 4u * NT;
+            if (j < j_hi) {
+                pa = *reinterpret_cast<const int4 *>(C.pos + j);
+                fa = *reinterpret_cast<const uint4 *>(C.fm + j);
+                if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(C.tlen + j);
+            }
         }
     }
     {   // ---- class 1 (span <= 4096, 12-bit flags): no end column either, end = pos + (word >> 20) -----------
         const BsigClassCols &C = R.cls[1];
         const uint32_t j_lo = win[1].x, j_hi = win[1].y, nj = j_hi - j_lo;
-        auto four1 = [&](const int4 &p, const uint4 &f, const int4 &t, uint32_t j) {
+        for (uint32_t j = jb1; j < j_hi;) {
             const uint32_t dj = j - j_lo;
-            one(p.x, p.x + (int)(f.x >> 20), fm_of_class1(f.x), t.x, dj < nj);
-            one(p.y, p.y + (int)(f.y >> 20), fm_of_class1(f.y), t.y, dj + 1u < nj);
-            one(p.z, p.z + (int)(f.z >> 20), fm_of_class1(f.z), t.z, dj + 2u < nj);
-            one(p.w, p.w + (int)(f.w >> 20), fm_of_class1(f.w), t.w, dj + 3u < nj);
-        };
-        uint32_t j = jb1;
-        if (j < j_hi) {
-            four1(p1, f1, t1, j);
-            for (j += 4u * NT; j < j_hi; j += 4u * NT) {
-                const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
-                const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
-                int4 t = make_int4(0, 0, 0, 0);
-                if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
-                four1(p, f, t, j);
+            const uint32_t gx = fm_of_class1(fb.x), gy = fm_of_class1(fb.y), gz = fm_of_class1(fb.z), gw = fm_of_class1(fb.w);
+            one(pb.x, pb.x + (int)(fb.x >> 20), (gx & 0x10u) != 0u, fm_rejected(P, gx), tb.x, dj < nj);
+            one(pb.y, pb.y + (int)(fb.y >> 20), (gy & 0x10u) != 0u, fm_rejected(P, gy), tb.y, dj + 1u < nj);
+            one(pb.z, pb.z + (int)(fb.z >> 20), (gz & 0x10u) != 0u, fm_rejected(P, gz), tb.z, dj + 2u < nj);
+            one(pb.w, pb.w + (int)(fb.w >> 20), (gw & 0x10u) != 0u, fm_rejected(P, gw), tb.w, dj + 3u < nj);
+            j += 4u * NT;
+            if (j < j_hi) {
+                pb = *reinterpret_cast<const int4 *>(C.pos + j);
+                fb = *reinterpret_cast<const uint4 *>(C.fm + j);
+                if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(C.tlen + j);
             }
         }
     }
 #pragma unroll
-    for (int c = 2; c < BSIG_MAX_CLASSES; ++c) {   // ---- classes 2-3: pos, end, fm columns ---------
+    for (int c = 2; c < BSIG_SPAN_CLASSES; ++c) {   // ---- classes 2-3: pos, end, fm columns ---------
         const BsigClassCols &C = R.cls[c];
         const uint32_t j_lo = win[c].x, j_hi = win[c].y, nj = j_hi - j_lo;
         for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
@@ -291,30 +351,76 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
             int4 t = make_int4(0, 0, 0, 0);
             if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
             const uint32_t dj = j - j_lo;
-            one(p.x, e.x, f.x, t.x, dj < nj);
-            one(p.y, e.y, f.y, t.y, dj + 1u < nj);
-            one(p.z, e.z, f.z, t.z, dj + 2u < nj);
-            one(p.w, e.w, f.w, t.w, dj + 3u < nj);
+            one(p.x, e.x, (f.x & 0x10u) != 0u, fm_rejected(P, f.x), t.x, dj < nj);
+            one(p.y, e.y, (f.y & 0x10u) != 0u, fm_rejected(P, f.y), t.y, dj + 1u < nj);
+            one(p.z, e.z, (f.z & 0x10u) != 0u, fm_rejected(P, f.z), t.z, dj + 2u < nj);
+            one(p.w, e.w, (f.w & 0x10u) != 0u, fm_rejected(P, f.w), t.w, dj + 3u < nj);
         }
     }
 }
 
-// The read windows of a tile: taken from k_resolve's output, or (windows == nullptr, the fused
-// form) looked up here with the index loads of all classes issued back to back.
+// the bucket-rounded window [rlo, rhi) of the packed class for the genomic interval [tlo, thi) of an item
+__device__ __forceinline__ bool packed_window(const BsigClassCols &C, const BsigWorkItem &w, int64_t tlo, int64_t thi, int ext,
+                                              int64_t &rlo, int64_t &rhi)
+{
+    int64_t wlo = tlo - ext - C.maxspan + 1, whi = thi + ext;
+    const int64_t ref_bp = (int64_t)(w.units_strand & BSIG_ITEM_UNITS_MASK) << BSIG_REF_UNIT_SHIFT;
+    if (wlo < 0) wlo = 0;
+    if (whi > ref_bp) whi = ref_bp;
+    rlo = (wlo >> C.kshift) << C.kshift;
+    rhi = whi > 0 ? (((whi - 1) >> C.kshift) + 1) << C.kshift : 0;
+    return C.n != 0 && wlo < whi;
+}
+
+// The packed class's chunks behind the first (a window wider than kPackChunk bases: a shift or a template
+// length filter of tens of kilobases -- rare, so plain loops): every chunk is looked up in the index by
+// itself and clipped to `clip` (the read range of a slice of a heavy tile; everything otherwise).
+template <int NT, typename F>
+__device__ __forceinline__ void packed_later_chunks(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem &w,
+                                                    int n_chunks, uint2 clip, const uint8_t *__restrict__ ptab, int tid, F &&one)
+{
+    const BsigClassCols &C = R.cls[BSIG_CLASS_PACKED];
+    int64_t tlo, thi, rlo, rhi;
+    item_interval(w, P, mode, tlo, thi);
+    if (!packed_window(C, w, tlo, thi, P.ext, rlo, rhi)) return;
+    const uint64_t g0 = (uint64_t)w.ref_unit0 << BSIG_REF_UNIT_SHIFT;
+    for (int c = 1; c < n_chunks; ++c) {
+        const int64_t a = rlo + (int64_t)c * kPackChunk;
+        const int64_t b = a + kPackChunk < rhi ? a + kPackChunk : rhi;
+        uint32_t j_lo = C.idx[(g0 + (uint64_t)a) >> C.kshift], j_hi = C.idx[(g0 + (uint64_t)b) >> C.kshift];
+        j_lo = j_lo > clip.x ? j_lo : clip.x;
+        j_hi = j_hi < clip.y ? j_hi : clip.y;
+        if (j_lo >= j_hi) continue;
+        const uint32_t nj = j_hi - j_lo;
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
+            four_packed(x, t, j, j_lo, nj, (int)a, ptab, one);
+        }
+    }
+}
+
+// The read windows of a tile, looked up here with the index loads of all classes issued back to back.
+// `windows` (slices of heavy tiles): fixed read ranges instead -- for the span classes as they are, for the
+// packed class as a clip of what the index says (the chunk's start is needed as well).
+// P.resolved (large launches): the windows as k_resolve_tiles wrote them in front of this launch; a kernel
+// instantiated with RES = true has nothing but that form in it (fewer registers).
+template <bool RES = false>
 __device__ __forceinline__ void load_windows(const BsigReadsDev &R, const BsigKParams &P, int mode,
                                              const BsigWorkItem &w, const BsigWorkItem *__restrict__ items,
                                              const uint2 *__restrict__ windows, uint2 (&win)[BSIG_MAX_CLASSES],
-                                             uint32_t tile)
+                                             uint32_t tile, PackedWin &pk, uint2 &clip)
 {
-    if (windows) {
-        const uint4 *wp = reinterpret_cast<const uint4 *>(windows + (size_t)BSIG_MAX_CLASSES * tile);
-        const uint4 a = wp[0], b = wp[1];
-        win[0] = make_uint2(a.x, a.y); win[1] = make_uint2(a.z, a.w);
-        win[2] = make_uint2(b.x, b.y); win[3] = make_uint2(b.z, b.w);
-        if (w.units_strand & BSIG_ITEM_HEAVY) {
+    if (RES || P.resolved) {
+        // the launch in front of this one looked the windows up (k_resolve_tiles): this load does not depend
+        // on the work item's
+        const BsigResolved r = reinterpret_cast<const BsigResolved *>(windows)[tile];
 #pragma unroll
-            for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = make_uint2(0u, 0u);
-        }
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = make_uint2(r.win[2 * c], r.win[2 * c + 1]);
+        pk.base = r.pbase;
+        pk.n_chunks = r.pchunks;
+        clip = make_uint2(0u, 0xFFFFFFFFu);
         return;
     }
     int64_t tlo, thi;
@@ -323,28 +429,71 @@ __device__ __forceinline__ void load_windows(const BsigReadsDev &R, const BsigKP
     bool live[BSIG_MAX_CLASSES];
     const int64_t ref_bp = (int64_t)(w.units_strand & BSIG_ITEM_UNITS_MASK) << BSIG_REF_UNIT_SHIFT;
     const uint64_t g0 = (uint64_t)w.ref_unit0 << BSIG_REF_UNIT_SHIFT;
+    // dead classes read a harmless valid word instead of branching around the load
+    const uint32_t *dummy = reinterpret_cast<const uint32_t *>(items);
 #pragma unroll
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+    for (int c = 0; c < BSIG_SPAN_CLASSES; ++c) {
         const BsigClassCols &C = R.cls[c];
         int64_t wlo = tlo - P.ext - C.maxspan + 1, whi = thi + P.ext;
         if (wlo < 0) wlo = 0;
         if (whi > ref_bp) whi = ref_bp;
-        live[c] = C.n != 0 && wlo < whi;
-        // dead classes read a harmless valid word instead of branching around the load
-        const uint32_t *dummy = reinterpret_cast<const uint32_t *>(items);
+        live[c] = C.n != 0 && wlo < whi && !windows;
         alo[c] = live[c] ? C.idx + ((g0 + (uint64_t)wlo) >> C.kshift) : dummy;
         ahi[c] = live[c] ? C.idx + (((g0 + (uint64_t)whi - 1) >> C.kshift) + 1) : dummy;
+    }
+    {
+        const BsigClassCols &C = R.cls[BSIG_CLASS_PACKED];
+        int64_t rlo, rhi;
+        const bool on = packed_window(C, w, tlo, thi, P.ext, rlo, rhi);
+        live[BSIG_CLASS_PACKED] = on;
+        const int64_t first_end = rlo + kPackChunk < rhi ? rlo + kPackChunk : rhi;
+        alo[BSIG_CLASS_PACKED] = on ? C.idx + ((g0 + (uint64_t)rlo) >> C.kshift) : dummy;
+        ahi[BSIG_CLASS_PACKED] = on ? C.idx + ((g0 + (uint64_t)first_end) >> C.kshift) : dummy;
+        pk.base = (int)rlo;
+        pk.n_chunks = on ? (int)((rhi - rlo + kPackChunk - 1) >> BSIG_PACK_POS_BITS) : 0;
     }
     uint32_t lo[BSIG_MAX_CLASSES], hi[BSIG_MAX_CLASSES];
 #pragma unroll
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { lo[c] = *alo[c]; hi[c] = *ahi[c]; }
 #pragma unroll
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = live[c] && lo[c] < hi[c] ? make_uint2(lo[c], hi[c]) : make_uint2(0u, 0u);
+    clip = make_uint2(0u, 0xFFFFFFFFu);
+    if (windows) {
+        const uint2 *wp = windows + (size_t)BSIG_MAX_CLASSES * tile;
+#pragma unroll
+        for (int c = 0; c < BSIG_SPAN_CLASSES; ++c) win[c] = wp[c];
+        clip = wp[BSIG_CLASS_PACKED];
+        uint2 &q = win[BSIG_CLASS_PACKED];
+        q.x = q.x > clip.x ? q.x : clip.x;
+        q.y = q.y < clip.y ? q.y : clip.y;
+        if (q.x >= q.y) q = make_uint2(0u, 0u);
+    }
     // a heavy tile only zero-fills its cells here; its reads come through slice items afterwards
     if (w.units_strand & BSIG_ITEM_HEAVY) {
 #pragma unroll
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = make_uint2(0u, 0u);
+        pk.n_chunks = 0;
     }
+}
+
+// The index lookups of a large launch as a launch of their own, one lane per tile: the pileup workgroups,
+// which hold LDS and registers for their whole life, then start with their windows one load away.
+__global__ void k_resolve_tiles(const BsigReadsDev R, const BsigKParams P, int mode,
+                                const BsigWorkItem *__restrict__ items, uint32_t n_items,
+                                BsigResolved *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    const BsigWorkItem w = items[t];
+    uint2 win[BSIG_MAX_CLASSES], clip;
+    PackedWin pk;
+    load_windows(R, P, mode, w, items, nullptr, win, t, pk, clip);
+    BsigResolved r;
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { r.win[2 * c] = win[c].x; r.win[2 * c + 1] = win[c].y; }
+    r.pbase = pk.base;
+    r.pchunks = pk.n_chunks;
+    out[t] = r;
 }
 
 // the accumulating form of store_vec: slices of a heavy tile add their (partial) image
@@ -366,7 +515,7 @@ __device__ __forceinline__ void add_vec(int32_t *__restrict__ gbase, int v, int4
 // half never sees a carry from the lower one.  Half the LDS per workgroup: 24 instead of 18
 // single-wave workgroups per CU (LDS is allocated in 1,280-byte granules on gfx950), which puts
 // config 2's 10,000 tiles into two rounds of resident workgroups instead of two and a sparse third.
-template <int NT, bool SS, int PRE, int WAVES>
+template <int NT, bool SS, int PRE, int WAVES, bool RES>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_profile(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
                                                 int32_t *__restrict__ out,
                                                 const uint2 *__restrict__ windows,
@@ -378,11 +527,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
     BSIG_STAMP(0);
     const uint32_t tile = tile_of_block(blockIdx.x, n_tiles);
     const BsigWorkItem w = items[tile];
-    uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile);
+    uint2 win[BSIG_MAX_CLASSES], clip;
+    PackedWin pk;
+    load_windows<RES>(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile, pk, clip);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     // clear the whole tile image: this needs nothing from the work item, so it overlaps its load
-    for (int v = tid; v < (P.tile_cells * S + 8 + 7) / 8; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    const int img_vec = (P.tile_cells * S + 8 + 7) / 8;
+    for (int v = tid; v < img_vec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    // ... and so does the packed class's filter table, which lives behind the image
+    uint8_t *ptab = reinterpret_cast<uint8_t *>(lds4 + img_vec);
+    build_ptab<NT>(ptab, R, P, tid);
     const int nv = w.nc * S;
     const int sh = (int)(w.out_off & 3);
     const int nvec = (sh + nv + 3) >> 2;
@@ -392,9 +546,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
 
-    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
-        if (!valid || read_rejected(P, fm, tl)) return;
-        const bool neg = (fm & 0x10u) != 0u;                          // isNegStrand (:11-13)
+    auto one = [&](int p, int e, bool neg /* isNegStrand, :11-13 */, bool rej, int tl, bool valid) {
+        if (!valid || rej || tlen_rejected(P, tl)) return;             // :328-333
         const int a = tl < 0 ? -tl : tl;
         const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;  // :339
         const int p5 = neg ? e - offset : p + offset;                  // :340-344
@@ -410,7 +563,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
             atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
         }
     };
-    if (!BSIG_ABLATE(1)) for_each_read<NT, PRE>(R, P, win, tid, one);
+    if (!BSIG_ABLATE(1)) {
+        for_each_read<NT, PRE>(R, P, win, pk.base, ptab, tid, one);
+        if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_PROFILE, w, pk.n_chunks, clip, ptab, tid, one);
+    }
     block_sync<NT>();
     BSIG_STAMP(2);
 
@@ -461,18 +617,20 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
     const int tid = threadIdx.x;
     const uint32_t tile = tile_of_block(blockIdx.x, n_tiles);
     const BsigWorkItem w = items[tile];
-    uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile);
+    uint2 win[BSIG_MAX_CLASSES], clip;
+    PackedWin pk;
+    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile, pk, clip);
     const int stride = (P.tile_cells * S) | 1;                 // odd: replicas shift by one bank
     const int n_rep = small_replicas(stride);
     for (int v = tid; v < n_rep * stride; v += NT) lds[v] = 0;
+    uint8_t *ptab = reinterpret_cast<uint8_t *>(lds + ((n_rep * stride + 3) & ~3));
+    build_ptab<NT>(ptab, R, P, tid);
     block_sync<NT>();
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     int32_t *mine = lds + (tid & (n_rep - 1)) * stride;
 
-    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
-        if (!valid || read_rejected(P, fm, tl)) return;
-        const bool neg = (fm & 0x10u) != 0u;
+    auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
+        if (!valid || rej || tlen_rejected(P, tl)) return;
         const int a = tl < 0 ? -tl : tl;
         const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
         const int p5 = neg ? e - offset : p + offset;
@@ -485,7 +643,8 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
         const int lc = cell - w.c0;
         if ((unsigned)lc < (unsigned)w.nc) atomicAdd(&mine[lc * S + (SS ? anti : 0)], 1);
     };
-    for_each_read<NT>(R, P, win, tid, one);
+    for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
+    if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_PROFILE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();
 
     const int nv = w.nc * S;
@@ -507,26 +666,30 @@ __global__ __launch_bounds__(NT) void k_count(const BsigWorkItem *__restrict__ i
                                               const BsigReadsDev R, const BsigKParams P)
 {
     __shared__ int32_t wsum[2 * (NT / kWave)];
+    __shared__ __attribute__((aligned(16))) uint8_t ptab[BSIG_PACK_CODES];
     const int tid = threadIdx.x;
     const uint32_t tile = tile_of_block(blockIdx.x, n_tiles);
     const BsigWorkItem w = items[tile];
-    uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win, tile);
+    uint2 win[BSIG_MAX_CLASSES], clip;
+    PackedWin pk;
+    load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win, tile, pk, clip);
+    build_ptab<NT>(ptab, R, P, tid);
+    block_sync<NT>();
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
     const int gn = w.nc;
     int c_sense = 0, c_anti = 0;
 
-    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
-        if (!valid || read_rejected(P, fm, tl)) return;
-        const bool neg = (fm & 0x10u) != 0u;
+    auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
+        if (!valid || rej || tlen_rejected(P, tl)) return;
         const int a = tl < 0 ? -tl : tl;
         const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
         const int p5 = neg ? e - offset : p + offset;
         if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
         if (neg != neg_range) ++c_anti; else ++c_sense;
     };
-    for_each_read<NT>(R, P, win, tid, one);
+    for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
+    if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_COUNT, w, pk.n_chunks, clip, ptab, tid, one);
 
     // wave reduction, then across the waves of the workgroup
 #pragma unroll
@@ -566,7 +729,8 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
                                                        const uint2 *__restrict__ windows,
                                                        const BsigReadsDev R, const BsigKParams P)
 {
-    __shared__ uint32_t stage[T][12];      // per tile: 4 windows, first base, bases, flags
+    __shared__ uint32_t stage[T][16];      // per tile: 5 windows, first base, bases, flags, packed base and chunks
+    __shared__ __attribute__((aligned(16))) uint8_t ptab[BSIG_PACK_CODES];
     const int lane = threadIdx.x;
     const uint32_t n_groups = (n_tiles + T - 1) / T;
     const uint32_t first = tile_of_block(blockIdx.x, n_groups) * T;
@@ -576,17 +740,20 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
     bool atomic = false;
     if (have) {
         const BsigWorkItem w = items[first + lane];
-        uint2 win[BSIG_MAX_CLASSES];
-        load_windows(R, P, BSIG_MODE_COUNT, w, items, nullptr, win, first + lane);
+        uint2 win[BSIG_MAX_CLASSES], clip;
+        PackedWin pk;
+        load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win, first + lane, pk, clip);
 #pragma unroll
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { stage[lane][2 * c] = win[c].x; stage[lane][2 * c + 1] = win[c].y; }
-        stage[lane][8] = (uint32_t)(w.loc + w.c0);
-        stage[lane][9] = (uint32_t)w.nc;
-        stage[lane][10] = w.units_strand;
+        stage[lane][10] = (uint32_t)(w.loc + w.c0);
+        stage[lane][11] = (uint32_t)w.nc;
+        stage[lane][12] = w.units_strand;
+        stage[lane][13] = (uint32_t)pk.base;
+        stage[lane][14] = (uint32_t)pk.n_chunks;
         out_off = w.out_off;
         atomic = (w.units_strand & BSIG_ITEM_ATOMIC) != 0u;
     }
-    (void)windows;
+    build_ptab<kWave>(ptab, R, P, lane);
     block_sync<kWave>();
     int my_sense = 0, my_anti = 0;
 #pragma unroll 1
@@ -596,20 +763,25 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c)
             wn[c] = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][2 * c]),
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][2 * c + 1]));
-        const int glo = __builtin_amdgcn_readfirstlane((int)stage[t][8]);
-        const int gn = __builtin_amdgcn_readfirstlane((int)stage[t][9]);
-        const bool neg_range = ((uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][10]) & BSIG_ITEM_NEG) != 0u;
+        const int glo = __builtin_amdgcn_readfirstlane((int)stage[t][10]);
+        const int gn = __builtin_amdgcn_readfirstlane((int)stage[t][11]);
+        const bool neg_range = ((uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][12]) & BSIG_ITEM_NEG) != 0u;
+        const int pbase = __builtin_amdgcn_readfirstlane((int)stage[t][13]);
+        const int pchunks = __builtin_amdgcn_readfirstlane((int)stage[t][14]);
         int c_sense = 0, c_anti = 0;
-        auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
-            if (!valid || read_rejected(P, fm, tl)) return;
-            const bool neg = (fm & 0x10u) != 0u;
+        auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
+            if (!valid || rej || tlen_rejected(P, tl)) return;
             const int a = tl < 0 ? -tl : tl;
             const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
             const int p5 = neg ? e - offset : p + offset;
             if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
             if (neg != neg_range) ++c_anti; else ++c_sense;
         };
-        for_each_read<kWave, PRE>(R, P, wn, lane, one);
+        for_each_read<kWave, PRE>(R, P, wn, pbase, ptab, lane, one);
+        if (pchunks > 1) {
+            const BsigWorkItem w2 = items[first + t];
+            packed_later_chunks<kWave>(R, P, BSIG_MODE_COUNT, w2, pchunks, make_uint2(0u, 0xFFFFFFFFu), ptab, lane, one);
+        }
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) {
             c_sense += __shfl_xor(c_sense, d);
@@ -654,10 +826,14 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
     const int lane = tid & (kWave - 1);
     const uint32_t tile = tile_of_block(blockIdx.x, n_tiles);
     const BsigWorkItem w = items[tile];
-    uint2 win[BSIG_MAX_CLASSES];
-    load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win, tile);
+    uint2 win[BSIG_MAX_CLASSES], clip;
+    PackedWin pk;
+    load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win, tile, pk, clip);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     for (int v = tid; v < img_vec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
+    // the packed class's filter table: behind the image and the scan totals (16-B aligned)
+    uint8_t *ptab = reinterpret_cast<uint8_t *>(lds4 + img_vec + (NT / kWave + 3) / 4);
+    build_ptab<NT>(ptab, R, P, tid);
     const int nv = w.nc;
     const int sh = (int)(w.out_off & 3);
     const int nvec = (sh + nv + 3) >> 2;
@@ -666,11 +842,10 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int rend1 = w.loc + w.len - 1;     // last base of the range
 
-    auto one = [&](int p, int e, uint32_t fm, int tl, bool valid) {
-        if (!valid || read_rejected(P, fm, tl)) return;
+    auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
+        if (!valid || rej || tlen_rejected(P, tl)) return;            // :394-399
         int start = p, end = e;                                       // :401-403
         if (P.tspan) {                                                // :404-413
-            const bool neg = (fm & 0x10u) != 0u;
             if (neg && tl < 0) start = end + tl + 1;
             else if (!neg && tl > 0) end = start + tl - 1;
         }
@@ -686,7 +861,8 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
             atomicAdd(&lds[kb >> 1], (kb & 1) ? -65536 : -1);
         }
     };
-    for_each_read<NT>(R, P, win, tid, one);
+    for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
+    if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_COVERAGE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();
 
     // cumsum (:464-470): each lane owns 4 consecutive cells (two packed dwords), wave scan of the
@@ -756,22 +932,84 @@ __global__ void k_cigar_end(int64_t n, const int32_t *__restrict__ pos,
 //   class 1 (span <= 4096):  flag (12 bits) | mapq << 12 | (span - 1) << 20
 // The SAM specification defines 12 flag bits; a read that sets a higher one (a uint16 can) and spans more
 // than 256 bp goes to class 2, whose words hold all 16.
-__device__ __forceinline__ int span_class(int span, uint32_t flag)
+// A short read (span <= 256) whose (flag, mapq) pair has a code in the file's pair table, with 12-bit flags
+// and pos inside its reference (the bucket index clamps positions to the reference; a packed word cannot
+// carry a position the index does not vouch for), goes to the packed class instead: one word per read.
+// codemap: 2^20 entries indexed by flag | mapq << 12, 0xFFFF = no code; NULL = no packed class.
+__device__ __forceinline__ int read_class(int span, uint32_t flag, uint32_t mapq, int p, int64_t ref_bp,
+                                          const uint16_t *__restrict__ codemap, uint32_t &code)
 {
-    return span <= 256 ? 0 : (span <= 4096 && flag < 4096u) ? 1 : span <= 65536 ? 2 : 3;
+    if (span <= 256) {
+        if (codemap && span >= 1 && flag < 4096u && p >= 0 && (int64_t)p < ref_bp) {
+            code = codemap[flag | (mapq << 12)];
+            if (code != 0xFFFFu) return BSIG_CLASS_PACKED;
+        }
+        return 0;
+    }
+    return (span <= 4096 && flag < 4096u) ? 1 : span <= 65536 ? 2 : 3;
 }
 
+// reference of read i: last r with ref_off[r] <= i
+__device__ __forceinline__ int ref_of_read(const int64_t *__restrict__ ref_off, int n_ref, int64_t i)
+{
+    int lo = 0, hi = n_ref;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ref_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 
 constexpr int kPrepThreads = 256;
 constexpr int kPrepChunk = 2048;     // reads per workgroup in k_span_hist / k_scatter
+
+// ---- the file's pair table: the (flag, mapq) pairs of short reads, counted on a sample --------------
+// Any table is correct (a read whose pair has no code stays in class 0); a sample of the file finds the
+// frequent pairs.  hist: 2^20 counters indexed by flag | mapq << 12.
+__global__ __launch_bounds__(kPrepThreads) void k_pair_sample(int64_t n, int64_t chunk_stride,
+                                                              const int32_t *__restrict__ pos, const int32_t *__restrict__ end,
+                                                              const uint16_t *__restrict__ flag, const uint8_t *__restrict__ mapq,
+                                                              uint32_t *__restrict__ hist)
+{
+    const int64_t base = (int64_t)blockIdx.x * chunk_stride * kPrepChunk;
+    for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
+        const int64_t i = base + r * kPrepThreads + threadIdx.x;
+        if (i >= n) break;
+        const int span = end[i] - pos[i] + 1;
+        const uint32_t f = flag[i];
+        if (span >= 1 && span <= 256 && f < 4096u && pos[i] >= 0) atomicAdd(&hist[f | ((uint32_t)mapq[i] << 12)], 1u);
+    }
+}
+// the non-empty counters as (key, count) pairs; *n_out may exceed cap (the caller then reads the counters themselves)
+__global__ void k_pair_compact(const uint32_t *__restrict__ hist, uint32_t n_keys, uint2 *__restrict__ out, uint32_t cap,
+                               uint32_t *__restrict__ n_out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_keys) return;
+    const uint32_t c = hist[k];
+    if (!c) return;
+    const uint32_t slot = atomicAdd(n_out, 1u);
+    if (slot < cap) out[slot] = make_uint2(k, c);
+}
+// codemap[key of code c] = c (codemap was filled with 0xFFFF); fmtab[c] = flag | mapq << 16
+__global__ void k_codemap_fill(const uint32_t *__restrict__ fmtab, int n_codes, uint16_t *__restrict__ codemap)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_codes) return;
+    const uint32_t fm = fmtab[c];
+    codemap[(fm & 0xFFFu) | ((fm >> 16) & 0xFFu) << 12] = (uint16_t)c;
+}
 
 // per-chunk class counts + per-class max span; also checks that the reads are sorted by position
 // inside every reference (maxspan[BSIG_MAX_CLASSES] is set to 1 otherwise)
 __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n_ref,
                                                             const int64_t *__restrict__ ref_off,
+                                                            const uint32_t *__restrict__ ref_units,
                                                             const int32_t *__restrict__ pos,
                                                             const int32_t *__restrict__ end,
                                                             const uint16_t *__restrict__ flag,
+                                                            const uint8_t *__restrict__ mapq,
+                                                            const uint16_t *__restrict__ codemap,
                                                             uint32_t *__restrict__ chunk_counts,
                                                             int32_t *__restrict__ maxspan)
 {
@@ -784,19 +1022,15 @@ __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n
     for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
         const int64_t i = base + r * kPrepThreads + tid;
         if (i < n) {
-            const int span = end[i] - pos[i] + 1;
-            const int c = span_class(span, flag[i]);
+            const int p = pos[i];
+            const int span = end[i] - p + 1;
+            const int rf = ref_of_read(ref_off, n_ref, i);
+            uint32_t code;
+            const int c = read_class(span, flag[i], mapq[i], p, (int64_t)ref_units[rf] << BSIG_REF_UNIT_SHIFT, codemap, code);
             atomicAdd(&cnt[c], 1u);
             atomicMax(&mx[c], span);
-            if (i > 0 && pos[i] < pos[i - 1]) {
-                // allowed only where a new reference starts: is i one of ref_off[1..n_ref-1]?
-                int lo = 0, hi = n_ref;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (ref_off[mid] <= i) lo = mid; else hi = mid;
-                }
-                if (ref_off[lo] != i) maxspan[BSIG_MAX_CLASSES] = 1;
-            }
+            // a position below its predecessor's is allowed only where a new reference starts
+            if (i > 0 && p < pos[i - 1] && ref_off[rf] != i) maxspan[BSIG_MAX_CLASSES] = 1;
         }
     }
     __syncthreads();
@@ -815,7 +1049,7 @@ struct ScatterOut {
     int32_t kshift[BSIG_MAX_CLASSES];
 };
 
-// stable partition of the reads into their span classes; chunk_base = exclusive scan of chunk_counts
+// stable partition of the reads into their classes; chunk_base = exclusive scan of chunk_counts
 __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_ref,
                                                           const int64_t *__restrict__ ref_off,
                                                           const uint32_t *__restrict__ ref_unit0,
@@ -825,6 +1059,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
                                                           const uint16_t *__restrict__ flag,
                                                           const uint8_t *__restrict__ mapq,
                                                           const int32_t *__restrict__ tlen,
+                                                          const uint16_t *__restrict__ codemap,
                                                           const uint64_t *__restrict__ chunk_base,
                                                           const ScatterOut O)
 {
@@ -838,8 +1073,13 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
     for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
         const int64_t i = base + r * kPrepThreads + tid;
         const bool valid = i < n;
-        int p = 0, e = 0, cls = -1;
-        if (valid) { p = pos[i]; e = end[i]; cls = span_class(e - p + 1, flag[i]); }
+        int p = 0, e = 0, cls = -1, rf = 0;
+        uint32_t code = 0;
+        if (valid) {
+            p = pos[i]; e = end[i];
+            rf = ref_of_read(ref_off, n_ref, i);
+            cls = read_class(e - p + 1, flag[i], mapq[i], p, (int64_t)ref_units[rf] << BSIG_REF_UNIT_SHIFT, codemap, code);
+        }
         uint32_t rank = 0;
 #pragma unroll
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
@@ -851,21 +1091,19 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
         if (valid) {
             uint64_t dst = run[cls] + rank;
             for (int k = 0; k < wv; ++k) dst += wcnt[k][cls];
-            // reference id of read i: last r with ref_off[r] <= i
-            int lo = 0, hi = n_ref;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (ref_off[mid] <= i) lo = mid; else hi = mid;
-            }
             int64_t pp = p < 0 ? 0 : p;
-            const int64_t ref_bp = (int64_t)ref_units[lo] << BSIG_REF_UNIT_SHIFT;
+            const int64_t ref_bp = (int64_t)ref_units[rf] << BSIG_REF_UNIT_SHIFT;
             if (pp >= ref_bp) pp = ref_bp - 1;
-            const uint64_t g = ((uint64_t)ref_unit0[lo] << BSIG_REF_UNIT_SHIFT) + (uint64_t)pp;
-            O.pos[cls][dst] = p;
+            const uint64_t g = ((uint64_t)ref_unit0[rf] << BSIG_REF_UNIT_SHIFT) + (uint64_t)pp;
             uint32_t fmw = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 16);
-            if (cls == 0) fmw |= (uint32_t)(e - p) << 24;      // span - 1 <= 255
-            else if (cls == 1) fmw = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 12) | ((uint32_t)(e - p) << 20);   // flag < 4096, span - 1 <= 4095
-            else O.end[cls][dst] = e;
+            if (cls == BSIG_CLASS_PACKED) {
+                fmw = ((uint32_t)p & kPackPosMask) | ((uint32_t)(e - p) << BSIG_PACK_POS_BITS) | (code << 23);   // span - 1 <= 255
+            } else {
+                O.pos[cls][dst] = p;
+                if (cls == 0) fmw |= (uint32_t)(e - p) << 24;      // span - 1 <= 255
+                else if (cls == 1) fmw = (uint32_t)flag[i] | ((uint32_t)mapq[i] << 12) | ((uint32_t)(e - p) << 20);   // flag < 4096, span - 1 <= 4095
+                else O.end[cls][dst] = e;
+            }
             O.fm[cls][dst] = fmw;
             O.tlen[cls][dst] = tlen[i];
             O.gb[cls][dst] = (uint32_t)(g >> O.kshift[cls]);
@@ -937,6 +1175,15 @@ __device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t
     }
     return lo;
 }
+// the same over the packed words of one chunk (positions are base + the low bits' distance from base)
+__device__ __forceinline__ uint32_t lower_bound_packed(const uint32_t *words, uint32_t lo, uint32_t hi, int64_t base, int64_t key)
+{
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (base + (int64_t)((words[mid] - (uint32_t)base) & kPackPosMask) < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 
 __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
                          const BsigWorkItem *__restrict__ items, int64_t n_items,
@@ -948,7 +1195,7 @@ __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
     int64_t tlo, thi;
     item_interval(w, P, mode, tlo, thi);
     unsigned long long streamed = 0;
-    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+    for (int c = 0; c < BSIG_SPAN_CLASSES; ++c) {
         const BsigClassCols &C = R.cls[c];
         if (C.n == 0) continue;
         uint32_t j_lo, j_hi;
@@ -960,7 +1207,28 @@ __global__ void k_visits(const BsigReadsDev R, const BsigKParams P, int mode,
         const uint32_t b = lower_bound_pos(C.pos, a, j_hi, whi);
         if (b > a) atomicAdd(&acc[c], (unsigned long long)(b - a));
     }
-    atomicAdd(&acc[4], streamed);
+    {
+        const BsigClassCols &C = R.cls[BSIG_CLASS_PACKED];
+        int64_t rlo, rhi;
+        if (packed_window(C, w, tlo, thi, P.ext, rlo, rhi)) {
+            int64_t wlo = tlo - P.ext - C.maxspan + 1;
+            const int64_t whi = thi + P.ext;
+            if (wlo < 0) wlo = 0;
+            const uint64_t g0 = (uint64_t)w.ref_unit0 << BSIG_REF_UNIT_SHIFT;
+            unsigned long long v = 0;
+            for (int64_t a = rlo; a < rhi; a += kPackChunk) {
+                const int64_t b = a + kPackChunk < rhi ? a + kPackChunk : rhi;
+                const uint32_t j_lo = C.idx[(g0 + (uint64_t)a) >> C.kshift], j_hi = C.idx[(g0 + (uint64_t)b) >> C.kshift];
+                if (j_lo >= j_hi) continue;
+                streamed += ((j_hi + 3u) & ~3u) - (j_lo & ~3u);
+                const uint32_t x = lower_bound_packed(C.fm, j_lo, j_hi, a, wlo);
+                const uint32_t y = lower_bound_packed(C.fm, x, j_hi, a, whi);
+                v += y - x;
+            }
+            if (v) atomicAdd(&acc[BSIG_CLASS_PACKED], v);
+        }
+    }
+    atomicAdd(&acc[BSIG_MAX_CLASSES], streamed);
 }
 
 }  // namespace
@@ -977,7 +1245,7 @@ static int g_knobs[4] = {-1, -1, -1, -1};
 static int knob(int k)
 {
     static const char *const names[4] = {"BAMSIGNALS_PROFILE_PRE", "BAMSIGNALS_COUNT_TILES", "BAMSIGNALS_COUNT_PRE", "BAMSIGNALS_KNOB3"};
-    static const int dflt[4] = {3, 4, 2, 0};
+    static const int dflt[4] = {2, 4, 2, 0};
     if (g_knobs[k] < 0) {
         const char *e = getenv(names[k]);
         g_knobs[k] = e ? atoi(e) : dflt[k];
@@ -994,31 +1262,41 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
     // count family: consecutive tiles per wave and class-0 passes in flight (knobs 1 and 2; 4 x 2 measured best
     // on config 3's tiling, scripts/count_sweep.py)
     const int count_tiles = knob(1), count_pre = knob(2);
-    if (windows && resolve_first)
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_items * BSIG_MAX_CLASSES + 255) / 256)), dim3(256), 0, st,
-                           R, P, mode, items, n_items, windows);
+    if (windows && resolve_first) {
+        // P.resolved is set: the windows of every tile first (one lane per tile), with the lookup form of the parameters
+        BsigKParams Q = P;
+        Q.resolved = 0;
+        hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st,
+                           R, Q, mode, items, (uint32_t)n_items, reinterpret_cast<BsigResolved *>(windows));
+    }
     const dim3 grid((unsigned)n_items), block(NT);
     if (mode == BSIG_MODE_PROFILE && tile_cells * (ss ? 2 : 1) <= kSmallCells && P.binsize > 1) {
         const int stride = (tile_cells * (ss ? 2 : 1)) | 1;
-        const size_t lds = (size_t)small_replicas(stride) * stride * sizeof(int32_t);
+        const size_t lds = (size_t)((small_replicas(stride) * stride + 3) & ~3) * sizeof(int32_t) + BSIG_PACK_CODES;   // + the packed class's table
         if (ss) hipLaunchKernelGGL((k_profile_small<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
         else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (mode == BSIG_MODE_PROFILE) {
-        const size_t lds = (size_t)((tile_cells * (ss ? 2 : 1) + 8 + 7) / 8) * 16;     // 16-bit counters
+        const size_t lds = (size_t)((tile_cells * (ss ? 2 : 1) + 8 + 7) / 8) * 16 + BSIG_PACK_CODES;     // 16-bit counters + the packed class's table
         // class-0 passes requested before anything is consumed (knob 0: 2, 3 or 4; fewer = fewer VGPRs = more
         // resident waves, more = one round trip for denser windows)
         const int pre = knob(0);
-#define BSIG_KP(SS_, PRE_, W_) hipLaunchKernelGGL((k_profile<NT, SS_, PRE_, W_>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P)
-        // knob 3: ask the compiler for 8 waves per SIMD (96 SGPRs, the rest spilled into VGPR lanes) -- only the
-        // two-pass variant has the VGPRs to spare
-        const bool w8 = knob(3) == 8 && NT == kWave;
+#define BSIG_KP(SS_, PRE_, W_)                                                                                                          \
+    do {                                                                                                                                \
+        if (P.resolved) hipLaunchKernelGGL((k_profile<NT, SS_, PRE_, W_, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P); \
+        else hipLaunchKernelGGL((k_profile<NT, SS_, PRE_, W_, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P); \
+    } while (0)
+        // the build for 8 waves per SIMD (96 SGPRs, the rest kept in VGPR lanes; 57 VGPRs in the resolved form, which
+        // alone has them to spare): narrow tiles -- many workgroups per byte moved -- gain from the eighth wave,
+        // 2-kb tiles lose (same bases in 500 / 1,000 / 1,500 / 2,000-cell tiles, two launches, 7 -> 8 waves:
+        // 354 -> 316, 227 -> 215, 212 -> 212, 187 -> 192 us).  knob 3: 8 = always, 1 = never, 0 = by the tile image
+        const bool w8 = NT == kWave && P.resolved && (knob(3) == 8 || (knob(3) == 0 && lds <= 3072));
         if (ss) { if (pre <= 2) { if (w8) BSIG_KP(true, 2, 8); else BSIG_KP(true, 2, 1); } else if (pre == 3) BSIG_KP(true, 3, 1); else BSIG_KP(true, 4, 1); }
         else    { if (pre <= 2) { if (w8) BSIG_KP(false, 2, 8); else BSIG_KP(false, 2, 1); } else if (pre == 3) BSIG_KP(false, 3, 1); else BSIG_KP(false, 4, 1); }
 #undef BSIG_KP
     } else if (mode == BSIG_MODE_COVERAGE) {
-        const size_t lds = (size_t)((tile_cells + 8 + 7) / 8) * 16 + (size_t)(NT / 64) * sizeof(int32_t);   // signed 16-bit cells
+        const size_t lds = (size_t)((tile_cells + 8 + 7) / 8) * 16 + (size_t)((NT / 64 + 3) / 4) * 16 + BSIG_PACK_CODES;   // signed 16-bit cells, scan totals, the packed class's table
         hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
-    } else if (NT == kWave && !windows && count_tiles > 1) {
+    } else if (NT == kWave && (!windows || P.resolved) && count_tiles > 1) {
         // several consecutive tiles per wave (the slices of heavy tiles, which come with fixed windows, and
         // the wider workgroups keep the one-tile kernel)
         const int T = count_tiles >= 8 ? 8 : count_tiles >= 4 ? 4 : 2;
@@ -1075,18 +1353,39 @@ hipError_t launch_cigar_end(int64_t n, const int32_t *pos, const uint16_t *flag,
 
 int64_t prep_chunks(int64_t n) { return (n + kPrepChunk - 1) / kPrepChunk; }
 
-hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, const int32_t *pos,
-                            const int32_t *end, const uint16_t *flag, uint32_t *chunk_counts, int32_t *maxspan, hipStream_t st)
+hipError_t launch_pair_sample(int64_t n, const int32_t *pos, const int32_t *end, const uint16_t *flag, const uint8_t *mapq,
+                              uint32_t *hist, uint2 *pairs, uint32_t cap, uint32_t *n_pairs, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    // up to 1,024 chunks of 2,048 reads, evenly spread over the file (all of it up to 2 M reads)
+    const int64_t chunks = prep_chunks(n);
+    const int64_t stride = std::max<int64_t>(1, chunks / 1024);
+    const int64_t blocks = (chunks + stride - 1) / stride;
+    hipLaunchKernelGGL(k_pair_sample, dim3((unsigned)blocks), dim3(kPrepThreads), 0, st, n, stride, pos, end, flag, mapq, hist);
+    hipLaunchKernelGGL(k_pair_compact, dim3((1u << 20) / 256), dim3(256), 0, st, hist, 1u << 20, pairs, cap, n_pairs);
+    return hipGetLastError();
+}
+
+hipError_t launch_codemap_fill(const uint32_t *fmtab, int n_codes, uint16_t *codemap, hipStream_t st)
+{
+    if (n_codes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_codemap_fill, dim3((unsigned)((n_codes + 255) / 256)), dim3(256), 0, st, fmtab, n_codes, codemap);
+    return hipGetLastError();
+}
+
+hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, const uint32_t *ref_units, const int32_t *pos,
+                            const int32_t *end, const uint16_t *flag, const uint8_t *mapq, const uint16_t *codemap,
+                            uint32_t *chunk_counts, int32_t *maxspan, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_span_hist, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
-                       n, n_ref, ref_off, pos, end, flag, chunk_counts, maxspan);
+                       n, n_ref, ref_off, ref_units, pos, end, flag, mapq, codemap, chunk_counts, maxspan);
     return hipGetLastError();
 }
 
 hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, const uint32_t *ref_unit0,
                           const uint32_t *ref_units, const int32_t *pos, const int32_t *end,
-                          const uint16_t *flag, const uint8_t *mapq, const int32_t *tlen,
+                          const uint16_t *flag, const uint8_t *mapq, const int32_t *tlen, const uint16_t *codemap,
                           const uint64_t *chunk_base, const ScatterPtrs &S, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
@@ -1096,7 +1395,7 @@ hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, cons
         O.gb[c] = S.gb[c]; O.kshift[c] = S.kshift[c];
     }
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
-                       n, n_ref, ref_off, ref_unit0, ref_units, pos, end, flag, mapq, tlen, chunk_base, O);
+                       n, n_ref, ref_off, ref_unit0, ref_units, pos, end, flag, mapq, tlen, codemap, chunk_base, O);
     return hipGetLastError();
 }
 
@@ -1141,8 +1440,10 @@ hipError_t bsig::warm_pileup_module(hipStream_t st)
     return hipGetLastError();
 }
 
+extern "C" int bsig_debug_set_resolve_min(long long n_tiles);     // runtime.hip
 extern "C" int bsig_debug_set_knob(int which, int value)
 {
+    if (which == 4) return bsig_debug_set_resolve_min(value);
     if (which < 0 || which >= 4 || value < 0) return -1;
     bsig::g_knobs[which] = value;
     return 0;

@@ -266,7 +266,18 @@ struct bsig_plan {
     bool needs_zero = false;
     bool have_stats = false;
     bsig_plan_stats stats{};
+    BsigResolved *resolved = nullptr;   // large launches: the windows of every tile, written by k_resolve_tiles in every run
 };
+static int64_t g_resolve_min_override = -1;     // bsig_debug_set_knob(4, n): two launches from n tiles on (sweeps)
+// does a run of this plan look its windows up in a launch of its own?  (measured at the north star's read density,
+// scripts/ns_variants.py: 15,000 tiles 28.3 us fused / 31.1 us in two launches, 25,000 43.3 / 46.2, 35,000 71.8 / 66.3,
+// 50,000 112.0 / 107.3, 100,000 189.7 / 177.1; config 5's share 180.6 / 157.5, config 4's call 407 / 370:
+// env BAMSIGNALS_RESOLVE_MIN_TILES, default 32,768)
+static bool plan_two_launches(const bsig_plan *p)
+{
+    static const int64_t resolve_min = getenv("BAMSIGNALS_RESOLVE_MIN_TILES") ? atoll(getenv("BAMSIGNALS_RESOLVE_MIN_TILES")) : (int64_t)32768;
+    return p->n_items > 0 && p->n_items >= (g_resolve_min_override >= 0 ? g_resolve_min_override : resolve_min);
+}
 
 extern "C" {
 
@@ -420,22 +431,85 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
 
     R->info = bsig_reads_info{};
     R->info.n_reads = n;
+    R->dev.fmtab = nullptr;
+    R->dev.n_codes = 0;
     if (n == 0 || n_ref == 0) {
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) R->dev.cls[c] = BsigClassCols{};
         return BSIG_OK;
     }
     DevPool tmp;
-    // span classes: per-chunk counts -> host exclusive scan
+    const bool diag = getenv("BSIG_DIAG_DECODE") != nullptr;
+    const auto t_diag0 = std::chrono::steady_clock::now();
+    auto diag_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_diag0).count(); };
+    int64_t *d_ref_off;
+    uint32_t *d_unit0, *d_units;
+    HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
+    HIP_TRY(tmp.alloc(&d_unit0, n_ref));
+    HIP_TRY(tmp.alloc(&d_units, n_ref));
+    HIP_TRY(hipMemcpyAsync(d_ref_off, ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_unit0, R->ref_unit0.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_units, R->ref_units.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+
+    // ---- the file's pair table (bsig_types.h): the BSIG_PACK_CODES most frequent (flag, mapq) pairs among a
+    // sample of the short reads, most frequent first, ties by key -- the same table on every GPU that lays
+    // out the same columns.  env BAMSIGNALS_PACK=0: no packed class (testing; every short read in class 0).
+    uint16_t *d_codemap = nullptr;
+    if (!(getenv("BAMSIGNALS_PACK") && !strcmp(getenv("BAMSIGNALS_PACK"), "0"))) {
+        constexpr uint32_t kKeys = 1u << 20, kPairCap = 16384;
+        // one block for the counters, the pair list, its length and the code map: 4 MB + 128 KB + 2 MB, rounded
+        // up to what the cache of free blocks keeps (a decode's layout finds it there again)
+        uint8_t *blk;
+        HIP_TRY(tmp.alloc(&blk, std::max<size_t>(bsig::kBlockCacheMin, (size_t)kKeys * 4 + kPairCap * 8 + 256 + (size_t)kKeys * 2)));
+        uint32_t *d_hist = (uint32_t *)blk;
+        uint2 *d_pairs = (uint2 *)(blk + (size_t)kKeys * 4);
+        uint32_t *d_npairs = (uint32_t *)(blk + (size_t)kKeys * 4 + kPairCap * 8);
+        d_codemap = (uint16_t *)(blk + (size_t)kKeys * 4 + kPairCap * 8 + 256);
+        HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)kKeys * 4 + kPairCap * 8 + 256, st));
+        HIP_TRY(hipMemsetAsync(d_codemap, 0xFF, (size_t)kKeys * 2, st));
+        HIP_TRY(bsig::launch_pair_sample(n, d_pos, d_end, d_flag, d_mapq, d_hist, d_pairs, kPairCap, d_npairs, st));
+        uint32_t n_pairs = 0;
+        HIP_TRY(hipMemcpyAsync(&n_pairs, d_npairs, sizeof n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<uint2> pairs;
+        if (n_pairs <= kPairCap) {
+            pairs.resize(n_pairs);
+            if (n_pairs) HIP_TRY(hipMemcpyAsync(pairs.data(), d_pairs, (size_t)n_pairs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        } else {
+            // more distinct pairs than the list holds (which of them it caught depends on timing): read the counters
+            std::vector<uint32_t> hist(kKeys);
+            HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, (size_t)kKeys * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (uint32_t k = 0; k < kKeys; ++k)
+                if (hist[k]) pairs.push_back(make_uint2(k, hist[k]));
+        }
+        std::sort(pairs.begin(), pairs.end(), [](const uint2 &x, const uint2 &y) { return x.y != y.y ? x.y > y.y : x.x < y.x; });
+        const int n_codes = (int)std::min<size_t>(pairs.size(), BSIG_PACK_CODES);
+        if (n_codes > 0) {
+            std::vector<uint32_t> fmtab(BSIG_PACK_CODES, 0u);
+            for (int c = 0; c < n_codes; ++c) fmtab[(size_t)c] = (pairs[(size_t)c].x & 0xFFFu) | (pairs[(size_t)c].x >> 12) << 16;
+            uint32_t *d_fmtab;
+            HIP_TRY(R->pool.alloc(&d_fmtab, BSIG_PACK_CODES));
+            HIP_TRY(hipMemcpyAsync(d_fmtab, fmtab.data(), BSIG_PACK_CODES * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(bsig::launch_codemap_fill(d_fmtab, n_codes, d_codemap, st));
+            HIP_TRY(hipStreamSynchronize(st));          // (fmtab is a local)
+            R->dev.fmtab = d_fmtab;
+            R->dev.n_codes = n_codes;
+            R->fmtab = fmtab;
+        } else {
+            d_codemap = nullptr;
+        }
+        if (diag) fprintf(stderr, "  [layout] pair table: %u pairs in the sample, %d codes, %.1f ms\n", n_pairs, n_codes, diag_ms());
+    }
+
+    // classes: per-chunk counts -> host exclusive scan
     const int64_t n_chunks = bsig::prep_chunks(n);
     uint32_t *d_counts;
     int32_t *d_maxspan;
     HIP_TRY(tmp.alloc(&d_counts, n_chunks * BSIG_MAX_CLASSES));
     HIP_TRY(tmp.alloc(&d_maxspan, BSIG_MAX_CLASSES + 1));
     HIP_TRY(hipMemsetAsync(d_maxspan, 0, (BSIG_MAX_CLASSES + 1) * sizeof(int32_t), st));
-    int64_t *d_ref_off;
-    HIP_TRY(tmp.alloc(&d_ref_off, n_ref + 1));
-    HIP_TRY(hipMemcpyAsync(d_ref_off, ref_off, (n_ref + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_pos, d_end, d_flag, d_counts, d_maxspan, st));
+    HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_units, d_pos, d_end, d_flag, d_mapq, d_codemap, d_counts, d_maxspan, st));
     std::vector<uint32_t> counts(n_chunks * BSIG_MAX_CLASSES);
     int32_t maxspan[BSIG_MAX_CLASSES + 1];
     HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -444,20 +518,21 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
     if (maxspan[BSIG_MAX_CLASSES])
         return fail(BSIG_ERR_ARG, "reads must be sorted by position inside every reference (coordinate-sorted BAM order)");
     std::vector<uint64_t> base(n_chunks * BSIG_MAX_CLASSES);
-    uint64_t class_n[BSIG_MAX_CLASSES] = {0, 0, 0, 0};
+    uint64_t class_n[BSIG_MAX_CLASSES] = {};
     for (int64_t k = 0; k < n_chunks; ++k)
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
             base[k * BSIG_MAX_CLASSES + c] = class_n[c];
             class_n[c] += counts[k * BSIG_MAX_CLASSES + c];
         }
+    if (diag) fprintf(stderr, "  [layout] class counts %.1f ms\n", diag_ms());
 
-    const bool diag = getenv("BSIG_DIAG_DECODE") != nullptr;
-    const auto t_diag0 = std::chrono::steady_clock::now();
-    // bucket width per class: about 16 reads per bucket, 16 bp .. 64 kbp
+    // bucket width per class: about 16 reads per bucket, 16 bp .. 64 kbp (the packed class: at most one
+    // chunk of its position bits)
     bsig::ScatterPtrs S{};
-    uint64_t n_buckets[BSIG_MAX_CLASSES] = {0, 0, 0, 0};
+    uint64_t n_buckets[BSIG_MAX_CLASSES] = {};
     int min_shift = 4;
     while ((total_bp >> min_shift) >= (1ull << 32)) ++min_shift;
+    if (min_shift > BSIG_PACK_POS_BITS) return fail(BSIG_ERR_ARG, "genome too large for the bucket index");
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         BsigClassCols &C = R->dev.cls[c];
         C = BsigClassCols{};
@@ -466,16 +541,16 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         double per_bucket = 16.0;
         if (const char *v = getenv("BAMSIGNALS_BUCKET_READS")) per_bucket = std::max(1.0, atof(v));
         const double bp_per_bucket = per_bucket * (double)total_bp / (double)class_n[c];
+        const int max_shift = c == BSIG_CLASS_PACKED ? BSIG_PACK_POS_BITS : BSIG_REF_UNIT_SHIFT;
         int k = 4;
-        while (k < BSIG_REF_UNIT_SHIFT && (double)(1ull << (k + 1)) <= bp_per_bucket) ++k;
+        while (k < max_shift && (double)(1ull << (k + 1)) <= bp_per_bucket) ++k;
         k = std::max(k, min_shift);
-        if (k > BSIG_REF_UNIT_SHIFT) return fail(BSIG_ERR_ARG, "genome too large for the bucket index");
+        if (k > max_shift) return fail(BSIG_ERR_ARG, "genome too large for the bucket index");
         const size_t cap = ((size_t)class_n[c] + 3) / 4 * 4 + 4;
-        int32_t *p, *e, *t;
+        int32_t *p = nullptr, *e = nullptr, *t;
         uint32_t *f, *gb, *idx;
-        HIP_TRY(R->pool.alloc(&p, cap));
-        e = nullptr;
-        if (c >= 2) HIP_TRY(R->pool.alloc(&e, cap));      // classes 0 and 1 pack their span into fm
+        if (c != BSIG_CLASS_PACKED) HIP_TRY(R->pool.alloc(&p, cap));      // a packed word carries its position
+        if (c == 2 || c == 3) HIP_TRY(R->pool.alloc(&e, cap));           // classes 0, 1 and packed keep their span in fm
         HIP_TRY(R->pool.alloc(&f, cap));
         HIP_TRY(R->pool.alloc(&t, cap));
         HIP_TRY(tmp.alloc(&gb, cap));
@@ -484,7 +559,7 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         R->col_cap[c] = cap;
         R->idx_entries[c] = n_buckets[c] + 2;
         // the tail padding is read by the 16-B loads: keep it defined
-        HIP_TRY(hipMemsetAsync(p + cap - 8, 0, 8 * sizeof(int32_t), st));
+        if (p) HIP_TRY(hipMemsetAsync(p + cap - 8, 0, 8 * sizeof(int32_t), st));
         if (e) HIP_TRY(hipMemsetAsync(e + cap - 8, 0, 8 * sizeof(int32_t), st));
         HIP_TRY(hipMemsetAsync(f + cap - 8, 0, 8 * sizeof(int32_t), st));
         HIP_TRY(hipMemsetAsync(t + cap - 8, 0, 8 * sizeof(int32_t), st));
@@ -496,25 +571,20 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         R->info.class_bucket_shift[c] = k;
         R->info.n_classes += 1;
     }
+    R->info.n_codes = R->dev.n_codes;
 
-    if (diag)
-        fprintf(stderr, "  [layout] column + index allocations %.1f ms\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_diag0).count());
-    uint32_t *d_unit0, *d_units;
+    if (diag) fprintf(stderr, "  [layout] column + index allocations %.1f ms\n", diag_ms());
     uint64_t *d_base;
-    HIP_TRY(tmp.alloc(&d_unit0, n_ref));
-    HIP_TRY(tmp.alloc(&d_units, n_ref));
     HIP_TRY(tmp.alloc(&d_base, base.size()));
-    HIP_TRY(hipMemcpyAsync(d_unit0, R->ref_unit0.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_units, R->ref_units.data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_base, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(bsig::launch_scatter(n, n_ref, d_ref_off, d_unit0, d_units, d_pos, d_end, d_flag, d_mapq, d_tlen,
+    HIP_TRY(bsig::launch_scatter(n, n_ref, d_ref_off, d_unit0, d_units, d_pos, d_end, d_flag, d_mapq, d_tlen, d_codemap,
                                  d_base, S, st));
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c)
         if (class_n[c])
             HIP_TRY(bsig::launch_build_idx((int64_t)class_n[c], S.gb[c], n_buckets[c],
                                            const_cast<uint32_t *>(R->dev.cls[c].idx), st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (diag) fprintf(stderr, "  [layout] scatter + indexes %.1f ms\n", diag_ms());
     R->info.hbm_bytes = R->pool.bytes;
     return BSIG_OK;
 }
@@ -619,6 +689,9 @@ int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **out)
     R->ref_unit0 = src->ref_unit0;
     R->ref_units = src->ref_units;
     R->ref_len = src->ref_len;
+    R->fmtab = src->fmtab;
+    R->dev.fmtab = nullptr;
+    R->dev.n_codes = src->dev.n_codes;
     hipStream_t st = dst_ctx->stream;
     hipError_t e = hipSuccess;
     auto copy = [&](const void *from, size_t bytes, void **to) {
@@ -642,6 +715,11 @@ int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **out)
         copy(S.fm, cb, &p); D.fm = (const uint32_t *)p;
         copy(S.tlen, cb, &p); D.tlen = (const int32_t *)p;
         copy(S.idx, (size_t)src->idx_entries[c] * sizeof(uint32_t), &p); D.idx = (const uint32_t *)p;
+    }
+    {
+        void *p;
+        copy(src->dev.fmtab, BSIG_PACK_CODES * sizeof(uint32_t), &p);
+        R->dev.fmtab = (const uint32_t *)p;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
@@ -786,9 +864,14 @@ struct SidecarHeader {
     uint32_t stamp_len, n_classes;
     uint64_t file_bytes;
     SidecarClass cls[BSIG_MAX_CLASSES];
-    uint64_t checksum;              // of every column and index as it lay in HBM when the file was written
+    uint64_t checksum;              // of every column, index and the pair table as they lay in HBM when the file was written
+    uint32_t n_codes, reserved;     // pairs in the packed class's table (the table follows the reference arrays)
 };
-constexpr uint32_t kSidecarVersion = 3;
+constexpr uint32_t kSidecarVersion = 4;
+// which columns a class has: pos (all but the packed class), end (classes 2 and 3), fm, tlen
+inline bool class_has_pos(int c) { return c != BSIG_CLASS_PACKED; }
+inline bool class_has_end(int c) { return c == 2 || c == 3; }
+inline int class_columns(int c) { return 2 + (class_has_pos(c) ? 1 : 0) + (class_has_end(c) ? 1 : 0); }
 inline uint64_t pad64(uint64_t v) { return (v + 63) & ~(uint64_t)63; }
 }  // namespace
 
@@ -814,6 +897,7 @@ int layout_checksum(const bsig_reads *R, uint64_t *out)
         if (e == hipSuccess) e = bsig::launch_checksum(C.idx, R->idx_entries[c] - 1, salt, d_acc, st);
         salt += 0x100000001ull;
     }
+    if (R->dev.fmtab && e == hipSuccess) e = bsig::launch_checksum(R->dev.fmtab, BSIG_PACK_CODES, salt, d_acc, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_acc);
@@ -835,12 +919,13 @@ int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp
     H.n_reads = reads->info.n_reads;
     H.stamp_len = (uint32_t)strlen(stamp);
     H.n_classes = (uint32_t)reads->info.n_classes;
-    uint64_t bytes = pad64(sizeof H) + pad64(H.stamp_len) + 3 * pad64((uint64_t)H.n_ref * 4);
+    H.n_codes = (uint32_t)reads->dev.n_codes;
+    uint64_t bytes = pad64(sizeof H) + pad64(H.stamp_len) + 3 * pad64((uint64_t)H.n_ref * 4) + (H.n_codes ? pad64(BSIG_PACK_CODES * 4) : 0);
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         const BsigClassCols &C = reads->dev.cls[c];
         H.cls[c] = SidecarClass{C.n, C.maxspan, C.kshift, C.n ? reads->col_cap[c] : 0, C.n ? reads->idx_entries[c] : 0};
         if (!C.n) continue;
-        bytes += (c >= 2 ? 4 : 3) * pad64(H.cls[c].col_cap * 4) + pad64(H.cls[c].idx_entries * 4);
+        bytes += class_columns(c) * pad64(H.cls[c].col_cap * 4) + pad64(H.cls[c].idx_entries * 4);
     }
     H.file_bytes = bytes;
     {
@@ -862,6 +947,7 @@ int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp
     put(reads->ref_len.data(), (uint64_t)H.n_ref * 4);
     put(reads->ref_unit0.data(), (uint64_t)H.n_ref * 4);
     put(reads->ref_units.data(), (uint64_t)H.n_ref * 4);
+    if (H.n_codes) put(reads->fmtab.data(), BSIG_PACK_CODES * 4);
     std::vector<uint8_t> host;
     int rc = BSIG_OK;
     auto put_dev = [&](const void *d, uint64_t n) {
@@ -873,8 +959,8 @@ int bsig_reads_save(const bsig_reads *reads, const char *path, const char *stamp
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
         const BsigClassCols &C = reads->dev.cls[c];
         if (!C.n) continue;
-        put_dev(C.pos, H.cls[c].col_cap * 4);
-        if (c >= 2) put_dev(C.end, H.cls[c].col_cap * 4);
+        if (class_has_pos(c)) put_dev(C.pos, H.cls[c].col_cap * 4);
+        if (class_has_end(c)) put_dev(C.end, H.cls[c].col_cap * 4);
         put_dev(C.fm, H.cls[c].col_cap * 4);
         put_dev(C.tlen, H.cls[c].col_cap * 4);
         put_dev(C.idx, H.cls[c].idx_entries * 4);
@@ -962,6 +1048,17 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
     R->ref_units.assign((const uint32_t *)p_un, (const uint32_t *)p_un + H.n_ref);
     R->info = bsig_reads_info{};
     R->info.n_reads = H.n_reads;
+    if (H.n_codes > BSIG_PACK_CODES || (H.n_codes == 0) != (H.cls[BSIG_CLASS_PACKED].n == 0))
+        return fail(BSIG_ERR_FORMAT, "%s is damaged (pair table)", path);
+    if (H.n_codes) {
+        const uint8_t *p_tab = take(BSIG_PACK_CODES * 4);
+        if (!p_tab) return fail(BSIG_ERR_FORMAT, "%s is truncated", path);
+        R->fmtab.assign((const uint32_t *)p_tab, (const uint32_t *)p_tab + BSIG_PACK_CODES);
+        // a code's pair: 12 flag bits, an 8-bit mapq, nothing else; unused entries zero
+        for (uint32_t c = 0; c < BSIG_PACK_CODES; ++c)
+            if ((R->fmtab[c] & 0xFF00F000u) || (c >= H.n_codes && R->fmtab[c]))
+                return fail(BSIG_ERR_FORMAT, "%s is damaged (pair table)", path);
+    }
     // The file's numbers steer device-side indexing (bucket numbers, read windows), so nothing is taken on
     // trust: the unit tables must be the ones layout_from_device derives from the reference lengths, every
     // class's shapes must follow from its read count and bucket shift, the counts must add up -- and below
@@ -993,7 +1090,7 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
         const SidecarClass &K = H.cls[c];
         if (K.n <= 0) continue;
         if ((uint64_t)K.n >= (1ull << 32) - 8 || K.col_cap != ((uint64_t)K.n + 3) / 4 * 4 + 4 || K.kshift < 4 ||
-            K.kshift > BSIG_REF_UNIT_SHIFT || (total_bp >> K.kshift) >= (1ull << 32) || K.idx_entries != (total_bp >> K.kshift) + 2 ||
+            K.kshift > (c == BSIG_CLASS_PACKED ? BSIG_PACK_POS_BITS : BSIG_REF_UNIT_SHIFT) || (c == BSIG_CLASS_PACKED && K.maxspan > 256) || (total_bp >> K.kshift) >= (1ull << 32) || K.idx_entries != (total_bp >> K.kshift) + 2 ||
             K.maxspan < 1)
             return fail(BSIG_ERR_FORMAT, "%s is damaged (shape of span class %d)", path, c);
         auto load = [&](uint64_t count, const void **dst) -> int {
@@ -1004,8 +1101,9 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
             *dst = d;
             return upload_staged(ctx->device, ctx->stream, src, (uint8_t *)d, (size_t)count * 4);
         };
-        int rc = load(K.col_cap, (const void **)&C.pos);
-        if (!rc && c >= 2) rc = load(K.col_cap, (const void **)&C.end);
+        int rc = BSIG_OK;
+        if (class_has_pos(c)) rc = load(K.col_cap, (const void **)&C.pos);
+        if (!rc && class_has_end(c)) rc = load(K.col_cap, (const void **)&C.end);
         if (!rc) rc = load(K.col_cap, (const void **)&C.fm);
         if (!rc) rc = load(K.col_cap, (const void **)&C.tlen);
         if (!rc) rc = load(K.idx_entries, (const void **)&C.idx);
@@ -1017,6 +1115,16 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
         R->info.class_maxspan[c] = K.maxspan;
         R->info.class_bucket_shift[c] = K.kshift;
         R->info.n_classes += 1;
+    }
+    R->dev.fmtab = nullptr;
+    R->dev.n_codes = (int32_t)H.n_codes;
+    R->info.n_codes = (int32_t)H.n_codes;
+    if (H.n_codes) {
+        uint32_t *d = nullptr;
+        HIP_TRY(R->pool.alloc(&d, BSIG_PACK_CODES));
+        HIP_TRY(hipMemcpyAsync(d, R->fmtab.data(), BSIG_PACK_CODES * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        R->dev.fmtab = d;
     }
     R->info.hbm_bytes = R->pool.bytes;
     // what arrived in HBM: indexes the kernels can follow blindly, and the bytes the writer had
@@ -1131,7 +1239,9 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     std::vector<BsigWorkItem> items;
     items.reserve(n);
     const int64_t mult = K.ss ? 2 : 1;
-    const int count_split = 1 << 15;      // count mode: bases per workgroup
+    // count mode: bases per workgroup (with the window's reach on both sides still one chunk of the packed
+    // class's position bits: one index lookup per tile)
+    const int count_split = 1 << (BSIG_PACK_POS_BITS - 1);
     // bins wider than a workgroup should stream on its own: every bin becomes bamCount-style
     // sub-intervals that add into the (zeroed) result with integer atomics
     const bool wide_bins = mode == BSIG_MODE_PROFILE && prm->tile_cells <= 0 && K.binsize > count_split / 2;
@@ -1273,8 +1383,22 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     // (heavy tiles need no fill: their main item stores 0 and only the slices add)
     if (p->kernel_mode == BSIG_MODE_COUNT && p->needs_zero)
         HIP_TRY(hipMemsetAsync(out_dev, 0, cells * sizeof(int32_t), st));
-    HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
-                                p->tile_cells, nullptr, false, out_dev, st));
+    // Large launches look their tiles' windows up in a launch of their own (k_resolve_tiles, one lane per tile), so
+    // that a pileup workgroup -- which holds its LDS and registers from its first instruction on -- gets its work
+    // item and its windows in ONE memory round trip instead of two dependent ones; small launches, where a second
+    // launch costs more than it hides, look them up inside the pileup kernel.  Both forms are the step: the index
+    // lookup (bam_itr_queryi's counterpart, ref: :267) runs on every bsig_plan_run.
+    const bool two_launches = plan_two_launches(p);
+    if (two_launches) {
+        if (!p->resolved) HIP_TRY(p->pool.alloc(&p->resolved, (size_t)p->n_items));
+        BsigKParams res = p->kp;
+        res.resolved = 1;
+        HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, res, p->items, p->n_items,
+                                    p->tile_cells, p->resolved, true, out_dev, st));
+    } else {
+        HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
+                                    p->tile_cells, nullptr, false, out_dev, st));
+    }
     if (p->n_heavy_slices) {
         // the first launch zero-filled the heavy tiles; their slices now add their partial images
         BsigKParams acc = p->kp;
@@ -1323,7 +1447,7 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
     if (!p || !s) return fail(BSIG_ERR_ARG, "NULL argument");
     if (!p->have_stats) {
         hipStream_t st = p->ctx->stream;
-        unsigned long long *d_acc = nullptr, acc[BSIG_MAX_CLASSES + 1] = {0, 0, 0, 0, 0};
+        unsigned long long *d_acc = nullptr, acc[BSIG_MAX_CLASSES + 1] = {};
         HIP_TRY(hipSetDevice(p->ctx->device));
         HIP_TRY(hipMalloc((void **)&d_acc, sizeof acc));
         hipError_t e = hipMemsetAsync(d_acc, 0, sizeof acc, st);
@@ -1336,16 +1460,20 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         t.n_ranges = p->n_ranges;
         t.n_items = p->n_items;
         t.cells = p->off.back();
+        t.visits_packed = (int64_t)acc[BSIG_CLASS_PACKED];   // one word per read
         t.visits_short = (int64_t)(acc[0] + acc[1]);         // classes 0 and 1: no end column
-        t.visits = (int64_t)(acc[0] + acc[1] + acc[2] + acc[3]);
-        t.streamed = (int64_t)acc[4];
-        t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // span <= 4096: pos + packed flag/mapq/span [+ tlen]
+        t.visits = (int64_t)(acc[0] + acc[1] + acc[2] + acc[3] + acc[BSIG_CLASS_PACKED]);
+        t.streamed = (int64_t)acc[BSIG_MAX_CLASSES];
+        t.bytes_per_visit_packed = p->kp.use_tlen ? 8 : 4;     // the packed word [+ tlen]
+        t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // span <= 4096: pos + flag/mapq/span in one word [+ tlen]
         t.bytes_per_visit_long = p->kp.use_tlen ? 16 : 12;     // pos + end + flag/mapq [+ tlen]
         // reads + work items + index entries + result cells
         const int64_t per_item = (int64_t)sizeof(BsigWorkItem);
-        t.algorithmic_bytes = t.bytes_per_visit_short * t.visits_short +
-                              t.bytes_per_visit_long * (t.visits - t.visits_short) + per_item * t.n_items +
+        t.algorithmic_bytes = t.bytes_per_visit_packed * t.visits_packed + t.bytes_per_visit_short * t.visits_short +
+                              t.bytes_per_visit_long * (t.visits - t.visits_short - t.visits_packed) + per_item * t.n_items +
                               8 * t.n_items * p->reads->info.n_classes + 4 * t.cells;
+        // two launches: the work item is read twice and the tile's windows are written and read once
+        if (plan_two_launches(p)) t.algorithmic_bytes += (per_item + 2 * (int64_t)sizeof(BsigResolved)) * t.n_items;
         p->have_stats = true;
     }
     *s = p->stats;
@@ -1353,6 +1481,12 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
 }
 
 void bsig_plan_free(bsig_plan *p) { delete p; }
+
+int bsig_debug_set_resolve_min(long long n_tiles)
+{
+    g_resolve_min_override = n_tiles;
+    return 0;
+}
 
 int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const int32_t *rid,
                         const int32_t *loc, const int32_t *len, const int32_t *strand,

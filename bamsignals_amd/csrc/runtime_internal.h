@@ -83,8 +83,9 @@ struct bsig_reads {
     DevPool pool;
     bsig_reads_info info{};
     int32_t n_ref = 0;
-    uint64_t col_cap[BSIG_MAX_CLASSES] = {0, 0, 0, 0};      // elements allocated per class column
-    uint64_t idx_entries[BSIG_MAX_CLASSES] = {0, 0, 0, 0};  // entries allocated per class index
+    uint64_t col_cap[BSIG_MAX_CLASSES] = {};      // elements allocated per class column
+    uint64_t idx_entries[BSIG_MAX_CLASSES] = {};  // entries allocated per class index
+    std::vector<uint32_t> fmtab;                  // host copy of dev.fmtab (BSIG_PACK_CODES entries, or empty)
     std::vector<uint32_t> ref_unit0, ref_units;
     std::vector<int32_t> ref_len;
 };

@@ -214,7 +214,9 @@ class Reads:
     def info(self):
         inf = _lib.ReadsInfo()
         _lib.check(self._lib.bsig_reads_get_info(self._h, C.byref(inf)))
-        return dict(n_reads=inf.n_reads, hbm_bytes=inf.hbm_bytes, n_classes=inf.n_classes,
+        # class_*: [span <= 256 with a rare flag/mapq pair, <= 4096, <= 65536, longer, packed (span <= 256, one
+        # word per read)]; n_codes = pairs in the packed class's table
+        return dict(n_reads=inf.n_reads, hbm_bytes=inf.hbm_bytes, n_classes=inf.n_classes, n_codes=inf.n_codes,
                     class_n=list(inf.class_n), class_maxspan=list(inf.class_maxspan),
                     class_bucket_shift=list(inf.class_bucket_shift))
 

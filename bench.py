@@ -522,6 +522,7 @@ class Workload:
                 # (not used for `achieved`: the packed HBM layout moves fewer bytes per visit)
                 "algorithmic_bytes_survey_formula": 15 * st["visits"] + 16 * st["n_ranges"] + 4 * st["cells"],
                 "visits": st["visits"], "streamed_reads": st["streamed"], "visits_short": st["visits_short"],
+                "visits_packed": st["visits_packed"], "bytes_per_visit_packed": st["bytes_per_visit_packed"],
                 "bytes_per_visit_short": st["bytes_per_visit_short"],
                 "bytes_per_visit_long": st["bytes_per_visit_long"],
                 "items": st["n_items"], "cells": st["cells"]}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BSIG_ABI_VERSION 3
+#define BSIG_ABI_VERSION 4
 
 enum {
     BSIG_OK = 0,
@@ -108,13 +108,19 @@ typedef struct {
 
 typedef struct bsig_reads bsig_reads;
 
+/* Classes of the resident layout: 0..3 by reference span (<= 256 | <= 4096 | <= 65536 | longer); 4 = the
+ * packed class: short reads (span <= 256) whose (flag, mapq) pair is one of the file's 512 most frequent
+ * pairs -- ONE 32-bit word per read (15 position bits, span - 1, a 9-bit code into the pair table), so a
+ * visit of such a read moves 4 bytes (8 with the template length); the other short reads stay in class 0 */
+#define BSIG_N_CLASSES 5
 typedef struct {
     int64_t n_reads;
     int64_t hbm_bytes;              /* resident bytes: class columns + bucket indexes            */
-    int32_t n_classes;              /* span classes in use                                       */
-    int64_t class_n[4];
-    int32_t class_maxspan[4];
-    int32_t class_bucket_shift[4];
+    int32_t n_classes;              /* classes in use                                            */
+    int32_t n_codes;                /* (flag, mapq) pairs in the packed class's table            */
+    int64_t class_n[BSIG_N_CLASSES];
+    int32_t class_maxspan[BSIG_N_CLASSES];
+    int32_t class_bucket_shift[BSIG_N_CLASSES];
 } bsig_reads_info;
 
 int bsig_reads_upload(bsig_ctx *ctx, const bsig_columns *cols, bsig_reads **reads);
@@ -163,11 +169,15 @@ typedef struct {
     int64_t n_items;           /* workgroup tiles                                               */
     int64_t cells;             /* int32 output cells                                            */
     int64_t visits;            /* reads in the exact candidate windows of all tiles (V)         */
-    int64_t visits_short;      /* ... of them in span classes 0-1 (span <= 4096: 4 B shorter)   */
+    int64_t visits_short;      /* ... of them in span classes 0-1 (span <= 4096: no end column) */
     int64_t streamed;          /* reads actually loaded (windows rounded to index buckets)      */
-    int64_t algorithmic_bytes; /* sum(bytes_per_visit*V) + 32*items + 8*items*classes + 4*cells */
+    int64_t algorithmic_bytes; /* sum(bytes_per_visit*V) + 32*items + 8*items*classes + 4*cells
+                                * (+ (32 + 2*48)*items when the windows are looked up by a launch of their own) */
     int32_t bytes_per_visit_short;   /* 8  (pos + flag|mapq|span - 1), 12 with the tlen column  */
     int32_t bytes_per_visit_long;    /* 12 (pos + end + flag|mapq), 16 with the tlen column     */
+    int64_t visits_packed;     /* ... of V in the packed class (not part of visits_short)       */
+    int32_t bytes_per_visit_packed;  /* 4  (one word), 8 with the tlen column                   */
+    int32_t reserved;
 } bsig_plan_stats;
 
 int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--ranges", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--only", default="", help="comma-separated variant names")
     a = ap.parse_args()
     import torch
 
@@ -25,13 +27,18 @@ def main():
     from bamsignals_amd import _lib
     args = argparse.Namespace(seed=0xBA51, tile_cells=0, threads=0)
     stream = torch.cuda.Stream()
-    w = bench.Workload(args, a.config, 0, 1, 0, stream, a.reads, a.ranges, 0, 0)
+    w = bench.Workload(args, a.config, 0, 1, 0, stream, a.reads, a.ranges, a.width, 0)
     lib = _lib.load()
-    variants = [("pre4", 4, 0), ("pre3", 3, 0), ("pre2", 2, 0), ("pre2+8waves", 2, 8)]
+    # (name, class passes in flight, 8-wave build, tiles from which the windows are looked up by a launch of their own)
+    never = 1 << 30
+    variants = [("pre3", 3, 1, never), ("pre2", 2, 1, never), ("pre3+resolve-launch", 3, 1, 0), ("pre2+resolve-launch", 2, 1, 0),
+                ("pre4+resolve-launch", 4, 1, 0), ("pre2+8waves+resolve-launch", 2, 8, 0), ("default", 2, 0, -1)]
+    if a.only:
+        variants = [v for v in variants if v[0] in a.only.split(",")]
     ref = None
     for rnd in range(2):
-        for name, pre, w8 in variants:
-            assert lib.bsig_debug_set_knob(0, pre) == 0 and lib.bsig_debug_set_knob(3, w8) == 0
+        for name, pre, w8, rmin in variants:
+            assert lib.bsig_debug_set_knob(0, pre) == 0 and lib.bsig_debug_set_knob(3, w8) == 0 and lib.bsig_debug_set_knob(4, rmin) == 0
             _, ms = w.timed(a.steps, 10, stream, lambda: None)
             got = [o.clone() for o in w.outs]
             if ref is None:

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--ranges", type=int, default=10_000)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--tile-cells", type=int, default=0)
+    ap.add_argument("--refs", type=int, default=1, help="references of 250 Mbp (10 with --reads 500000000 = the north star's shape)")
+    ap.add_argument("--width", type=int, default=2000)
     a = ap.parse_args()
     import torch
 
@@ -27,22 +29,22 @@ def main():
     from bamsignals_amd.device import Context, Plan, Reads, make_params
     from bamsignals_amd.synth import synth_ranges, synth_reads
 
-    ref_len = [250_000_000]
+    ref_len = [250_000_000] * a.refs
     cols = synth_reads(a.reads, ref_len, with_cigar=False)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx = Context(0, stream=stream.cuda_stream)
         reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
         plans, outs = [], []
-        for b in range(8):
-            rg = synth_ranges(a.ranges, 2000, ref_len, seed=100 + b)
+        for b in range(8 if a.reads <= 100_000_000 else 2):
+            rg = synth_ranges(a.ranges, a.width, ref_len, seed=100 + b)
             p = Plan(ctx, reads, rg["rid"], rg["loc"], rg["len"], rg["strand"],
                      make_params(_lib.MODE_PROFILE, binsize=1, threads=a.threads, tile_cells=a.tile_cells))
             plans.append(p)
             outs.append(torch.empty(p.cells, dtype=torch.int32, device="cuda"))
         n_items = plans[0].stats()["n_items"]
         for s in range(24):
-            plans[s % 8].run_device(outs[s % 8].data_ptr())
+            plans[s % len(plans)].run_device(outs[s % len(plans)].data_ptr())
         torch.cuda.synchronize()
         stamps = torch.zeros(n_items * 8, dtype=torch.int64, device="cuda")
         lib = _lib.load()

@@ -82,3 +82,26 @@ def core_args(kind, p):
     if kind == "ff16":
         a["filteredF"] = 16
     return a
+
+
+def expected_packed(pos, end, flag, mapq, ref_off, ref_len, n_codes=512):
+    """Which reads the resident layout puts into its packed class (csrc/bsig_types.h), restated: short reads
+    (span <= 256) with 12-bit flags and a position inside their reference (rounded up to 64-kbp units) whose
+    (flag, mapq) pair is one of the `n_codes` most frequent pairs -- most frequent first, ties by key
+    flag | mapq << 12 -- among the short reads of a sample of the file (up to 1,024 evenly spaced chunks of
+    2,048 reads: all of a file of up to 2 M reads).  Returns (boolean mask, number of codes)."""
+    pos = np.asarray(pos, np.int64); end = np.asarray(end, np.int64)
+    flag = np.asarray(flag, np.int64); mapq = np.asarray(mapq, np.int64)
+    n = len(pos)
+    span = end - pos + 1
+    cand = (span >= 1) & (span <= 256) & (flag < 4096) & (pos >= 0)
+    chunks = (n + 2047) // 2048
+    stride = max(1, chunks // 1024)
+    sampled = (np.arange(n) // 2048) % stride == 0
+    key = flag | (mapq << 12)
+    keys, counts = np.unique(key[cand & sampled], return_counts=True)
+    order = np.lexsort((keys, -counts))
+    table = keys[order][:n_codes]
+    rid = np.searchsorted(np.asarray(ref_off)[1:], np.arange(n), side="right")
+    ref_bp = ((np.asarray(ref_len, np.int64) >> 16) + 1) << 16
+    return cand & (pos < ref_bp[rid]) & np.isin(key, table), len(table)

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported():
     lib = _lib.load()
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.bsig_abi_version() == 3
+    assert lib.bsig_abi_version() == 4
 
 
 def test_layout_matches_oracle():

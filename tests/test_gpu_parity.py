@@ -3,7 +3,7 @@ Bit-exact: all arithmetic is 32-bit integer."""
 import numpy as np
 import pytest
 
-from conftest import core_args, parse_key
+from conftest import core_args, expected_packed, parse_key
 
 pytestmark = pytest.mark.gpu
 
@@ -111,23 +111,25 @@ def synth(ctx):
         gpu = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], flag, cols["mapq"], cols["tlen"],
                     cigar_off=cols["cigar_off"], cigar=cig)
         orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], end, flag, cols["mapq"], cols["tlen"])
-        out[name] = (gpu, orc, cols, end)
+        out[name] = (gpu, orc, cols, end, flag)
     yield out
     for gpu, *_ in out.values():
         gpu.close()
 
 
 def test_span_classes(synth):
-    gpu, _, cols, end = synth["se"]
+    gpu, _, cols, end, flag = synth["se"]
     info = gpu.info()
     span = end - cols["pos"] + 1
-    want = [int(np.sum(span <= 256)), int(np.sum((span > 256) & (span <= 4096))),
-            int(np.sum((span > 4096) & (span <= 65536))), int(np.sum(span > 65536))]
-    assert info["class_n"] == want
-    assert all(w > 0 for w in want)
+    packed, n_codes = expected_packed(cols["pos"], end, flag, cols["mapq"], cols["ref_off"], cols["ref_len"])
+    want = [int(np.sum((span <= 256) & ~packed)), int(np.sum((span > 256) & (span <= 4096))),
+            int(np.sum((span > 4096) & (span <= 65536))), int(np.sum(span > 65536)), int(np.sum(packed))]
+    assert info["class_n"] == want and info["n_codes"] == n_codes
+    assert all(w > 0 for w in want[1:])
     for c, (lo, hi) in enumerate(((0, 256), (256, 4096), (4096, 65536), (65536, 1 << 31))):
-        m = (span > lo) & (span <= hi)
-        assert info["class_maxspan"][c] == int(span[m].max())
+        m = (span > lo) & (span <= hi) & ~packed
+        assert info["class_maxspan"][c] == (int(span[m].max()) if m.any() else 0)
+    assert info["class_maxspan"][4] == int(span[packed].max()) and info["class_bucket_shift"][4] <= 15
 
 
 def _rand_ranges(rng, ref_len, n, maxw):
@@ -174,7 +176,7 @@ def test_flag_bits_above_the_sam_specification(ctx, synth):
     from bamsignals_amd.device import Reads
     from bamsignals_amd.synth import synth_ranges
     from oracle import oracle_c
-    _, _, cols, end = synth["pe"]
+    _, _, cols, end, _ = synth["pe"]
     flag = cols["flag"].copy()
     span = end - cols["pos"] + 1
     rng = np.random.default_rng(77)
@@ -200,11 +202,81 @@ def test_flag_bits_above_the_sam_specification(ctx, synth):
     reads.close()
 
 
+def test_packed_class_and_what_stays_outside_it(ctx, synth, monkeypatch):
+    """The packed class holds short reads whose (flag, mapq) pair has one of the file's 512 codes, one 32-bit
+    word per read: 15 position bits, span - 1, the code.  Everything else a short read can be stays in class 0
+    and must give the same counts: more than 512 pairs in the file (the rare ones), flag bits above the SAM
+    specification, a position beyond the reference.  A window wider than the 32,768 bases the position bits span
+    (a shift or a template length filter of tens of kilobases) is walked in chunks.  BAMSIGNALS_PACK=0 lays
+    the same reads out without a packed class (every short read in class 0): same results again."""
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_ranges
+    from oracle import oracle_c
+    _, _, cols, end, flag0 = synth["pe"]
+    rng = np.random.default_rng(404)
+    n = len(cols["pos"])
+    flag = flag0.copy()
+    mapq = rng.integers(0, 256, n).astype(np.uint8)                   # 256 mapq values x 8+ flags: far more than 512 pairs
+    mapq[rng.random(n) < 0.5] = 60                                    # ... half of the reads on a few frequent ones
+    odd = rng.random(n) < 0.02
+    flag[odd] |= rng.choice(np.asarray([0x1000, 0x8000], np.uint16), int(odd.sum()))
+    pos = cols["pos"].copy()
+    end = end.copy()
+    # the last reads of the last reference hang over its end by more than a 64-kbp unit (invalid but
+    # representable): their position is not one the bucket index can vouch for
+    last = np.arange(n - 6, n)
+    over = (int(cols["ref_len"][-1]) >> 16 << 16) + 65_536 + np.arange(6, dtype=np.int32) * 7
+    pos[last] = over
+    end[last] = over + 49
+    for pack in ("1", "0"):
+        monkeypatch.setenv("BAMSIGNALS_PACK", pack)
+        reads = Reads(ctx, cols["ref_len"], cols["ref_off"], pos, flag, mapq, cols["tlen"], end=end)
+        info = reads.info()
+        span = end.astype(np.int64) - pos + 1
+        if pack == "1":
+            packed, n_codes = expected_packed(pos, end, flag, mapq, cols["ref_off"], cols["ref_len"])
+            assert n_codes == 512 == info["n_codes"]
+            assert not packed[last].any() and not packed[flag >= 4096].any()
+            assert info["class_n"][4] == int(packed.sum()) > 0
+            assert info["class_n"][0] == int(np.sum((span <= 256) & ~packed)) > 0
+        else:
+            assert info["class_n"][4] == 0 and info["n_codes"] == 0 and info["class_n"][0] == int(np.sum(span <= 256))
+        orc = oracle_c.OracleReads(cols["ref_off"], pos, end, flag, mapq, cols["tlen"])
+        rg = synth_ranges(300, 3000, cols["ref_len"], seed=405, jitter=2500)
+        big = _rand_ranges(rng, cols["ref_len"], 10, 150_000)
+        for ranges in (rg, big):
+            for a in (dict(binsize=1, ss=True, mapqual=61), dict(binsize=1, filteredF=0x8010), dict(binsize=-1, ss=True, requiredF=66),
+                      dict(binsize=25, requiredF=66, tlen_filter=(0, 900), pe_mid=True, shift=7, mapqual=3),
+                      # windows of 2 x 40 kb + the range: two or three chunks of position bits per tile
+                      dict(binsize=1, shift=40_000, ss=True), dict(binsize=-1, shift=-70_000),
+                      dict(binsize=300, requiredF=66, tlen_filter=(0, 50_000), pe_mid=True, ss=True)):
+                want, _ = oracle_c.pileup_core(orc, ranges, **a)
+                for threads in (64, 256):
+                    got, _ = _gpu(ctx, reads, ranges, "pileup", threads=threads, **dict(a))
+                    assert np.array_equal(got, want), (pack, a, threads)
+            for a in (dict(mapqual=200), dict(filteredF=0x1400, requiredF=66, tlen_filter=(0, 1000), tspan=True),
+                      dict(requiredF=66, tlen_filter=(0, 45_000), tspan=True)):
+                want, _ = oracle_c.coverage_core(orc, ranges, **a)
+                got, _ = _gpu(ctx, reads, ranges, "coverage", **dict(a))
+                assert np.array_equal(got, want), (pack, a)
+        # ... and through the slices of heavy tiles (fixed read ranges clip the packed class's chunks)
+        monkeypatch.setenv("BAMSIGNALS_HEAVY_READS", "64")
+        for a in (dict(binsize=1, shift=40_000, ss=True), dict(binsize=-1, mapqual=20), dict(binsize=7)):
+            want, _ = oracle_c.pileup_core(orc, rg, **a)
+            got, _ = _gpu(ctx, reads, rg, "pileup", **dict(a))
+            assert np.array_equal(got, want), (pack, "heavy", a)
+        want, _ = oracle_c.coverage_core(orc, rg, requiredF=66, tlen_filter=(0, 45_000), tspan=True)
+        got, _ = _gpu(ctx, reads, rg, "coverage", requiredF=66, tlen_filter=(0, 45_000), tspan=True)
+        assert np.array_equal(got, want), (pack, "heavy coverage")
+        monkeypatch.delenv("BAMSIGNALS_HEAVY_READS")
+        reads.close()
+    monkeypatch.delenv("BAMSIGNALS_PACK")
+
 
 @pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
 def test_pileup_vs_oracle(ctx, synth, which, cases):
     from oracle import oracle_c
-    gpu, orc, cols, _ = synth[which]
+    gpu, orc, cols, _, _ = synth[which]
     rng = np.random.default_rng(21)
     small = _rand_ranges(rng, cols["ref_len"], 300, 3000)
     big = _rand_ranges(rng, cols["ref_len"], 12, 120_000)          # many tiles / split counts
@@ -220,7 +292,7 @@ def test_pileup_vs_oracle(ctx, synth, which, cases):
 @pytest.mark.parametrize("which", ["se", "pe"])
 def test_coverage_vs_oracle(ctx, synth, which):
     from oracle import oracle_c
-    gpu, orc, cols, _ = synth[which]
+    gpu, orc, cols, _, _ = synth[which]
     rng = np.random.default_rng(22)
     small = _rand_ranges(rng, cols["ref_len"], 300, 3000)
     big = _rand_ranges(rng, cols["ref_len"], 12, 120_000)
@@ -241,7 +313,7 @@ def test_whole_reference_tiling_properties(ctx, synth):
     """Size-independent checks on a 1-bp tiling of every reference (BASELINE config 3 shape)."""
     from bamsignals_amd.synth import tile_ranges
     from oracle import oracle_c
-    gpu, orc, cols, end = synth["se"]
+    gpu, orc, cols, end, _ = synth["se"]
     tiles = tile_ranges(cols["ref_len"], 2000, strand=0)
     prof, _ = _gpu(ctx, gpu, tiles, "pileup", binsize=1)
     # every read whose 5' end is inside its reference is counted exactly once
@@ -275,7 +347,7 @@ def test_whole_reference_tiling_properties(ctx, synth):
 
 def test_empty_inputs(ctx, synth):
     from bamsignals_amd.device import Reads
-    gpu, _, cols, _ = synth["se"]
+    gpu, _, cols, _, _ = synth["se"]
     empty = dict(rid=np.zeros(0, np.int32), loc=np.zeros(0, np.int32), len=np.zeros(0, np.int32),
                  strand=np.zeros(0, np.int32))
     for kind, a in (("pileup", dict(binsize=1)), ("pileup", dict(binsize=-1)), ("coverage", dict())):
@@ -292,7 +364,7 @@ def test_empty_inputs(ctx, synth):
 
 def test_error_paths(ctx, synth):
     from bamsignals_amd import _lib
-    gpu, _, cols, _ = synth["se"]
+    gpu, _, cols, _, _ = synth["se"]
     rg = dict(rid=np.asarray([0], np.int32), loc=np.asarray([10], np.int32), len=np.asarray([100], np.int32),
               strand=np.asarray([1], np.int32))
     with pytest.raises(_lib.BsigError) as e:
@@ -368,7 +440,7 @@ def test_very_wide_bins(ctx, synth):
     from oracle import oracle_c
     rng = np.random.default_rng(77)
     for which, extra in (("se", dict()), ("pe", dict(requiredF=66, tlen_filter=(0, 800), pe_mid=True))):
-        gpu, orc, cols, _ = synth[which]
+        gpu, orc, cols, _, _ = synth[which]
         m = 30
         rid = rng.integers(0, len(cols["ref_len"]), m).astype(np.int32)
         rg = dict(rid=rid, loc=(rng.random(m) * cols["ref_len"][rid] * 0.5).astype(np.int32) - 100,
@@ -386,7 +458,7 @@ def test_heavy_tile_slices(ctx, synth, monkeypatch):
     must not change.  Then a real hotspot at the default threshold."""
     from bamsignals_amd.device import Reads
     from oracle import oracle_c
-    gpu, orc, cols, _ = synth["pe"]
+    gpu, orc, cols, _, _ = synth["pe"]
     rng = np.random.default_rng(5)
     rg = _rand_ranges(rng, cols["ref_len"], 120, 6000)
     for thr in ("8", "300"):

@@ -520,8 +520,12 @@ def test_damaged_reads_files_are_refused(synth_bam, tmp_path):
     r.save(str(f), "s")
     raw = f.read_bytes()
     Reads.load(ctx, str(f), "s").close()
-    # header: magic 8, version 4, n_ref 4, n_reads 8, stamp_len 4, n_classes 4, file_bytes 8, then 4 x (n 8, maxspan 4, kshift 4, col_cap 8, idx_entries 8)
-    cls0 = 8 + 4 + 4 + 8 + 4 + 4 + 8
+    # header: magic 8, version 4, n_ref 4, n_reads 8, stamp_len 4, n_classes 4, file_bytes 8, then 5 x (n 8, maxspan 4, kshift 4,
+    # col_cap 8, idx_entries 8), checksum 8, n_codes 4, reserved 4; the entry of the packed class (the last) is patched: it holds
+    # nearly all reads of this file
+    cls0 = 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 * 32
+    n_codes_at = 8 + 4 + 4 + 8 + 4 + 4 + 8 + 5 * 32 + 8
+    assert struct.unpack_from("<q", raw, cls0)[0] > 0 and 0 < struct.unpack_from("<I", raw, n_codes_at)[0] <= 512
     def patched(off, fmt, value):
         x = bytearray(raw)
         x[off:off + struct.calcsize(fmt)] = struct.pack(fmt, value)
@@ -537,6 +541,9 @@ def test_damaged_reads_files_are_refused(synth_bam, tmp_path):
         "read count": patched(16, "<q", struct.unpack_from("<q", raw, 16)[0] + 5),
         "idx entries": patched(cls0 + 24, "<Q", struct.unpack_from("<Q", raw, cls0 + 24)[0] - 1),
         "maxspan": patched(cls0 + 8, "<i", 0),
+        "maxspan beyond a packed word's span bits": patched(cls0 + 8, "<i", 300),
+        "number of codes": patched(n_codes_at, "<I", 600),
+        "no codes but packed reads": patched(n_codes_at, "<I", 0),
     }
     for what, blob in cases.items():
         g = tmp_path / "bad.bsig"
