@@ -149,6 +149,8 @@ def load():
     lib.bsig_segmap_free.restype = None
     lib.bsig_last_call_timing.argtypes = [C.POINTER(C.c_double)]
     lib.bsig_last_call_timing.restype = None
+    lib.bsig_last_call_timing_ex.argtypes = [C.POINTER(C.c_double), C.c_int32]
+    lib.bsig_last_call_timing_ex.restype = None
     lib.bsig_check_list.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.bsig_check_list.restype = C.c_int32
     lib.bsig_fast_width.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]

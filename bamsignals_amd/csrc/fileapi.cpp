@@ -49,6 +49,13 @@ namespace {
 // upload + HBM layout, plan + kernels + result download, total; [5] = 1 if the BAM was already
 // resident in HBM
 thread_local double g_call_timing[6] = {0, 0, 0, 0, 0, 0};
+// ... and where the time of its stages went (bsig_last_call_timing_ex, slots 6..15)
+thread_local double g_call_timing_ex[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+struct AllocSnap {
+    int64_t ns, calls;
+    static AllocSnap now() { return AllocSnap{bsig::g_alloc_meter.ns.load(), bsig::g_alloc_meter.calls.load()}; }
+    double seconds_since(const AllocSnap &a) const { return (double)(ns - a.ns) * 1e-9; }
+};
 // how the calling thread's last file-level call was carried out (bsig_last_call_route)
 thread_local char g_call_route[320] = "";
 inline double now_s()
@@ -503,10 +510,12 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (n < 0 || (n > 0 && (!seq_code || !start || !width || !strand || !levels)))
         return fail(BSIG_ERR_ARG, "range arrays missing");
     if (!off) return fail(BSIG_ERR_ARG, "offsets missing");
-    double *T = g_call_timing;
+    double *T = g_call_timing, *X = g_call_timing_ex;
     for (int k = 0; k < 6; ++k) T[k] = 0;
+    for (int k = 0; k < 10; ++k) X[k] = 0;
     g_call_route[0] = 0;
     const double t_begin = now_s();
+    const AllocSnap a_begin = AllocSnap::now();
     // ref: Bamfile ctor :200-214 opens file + index on every call; here an unchanged file (same
     // size and mtime of the BAM and of its index) reuses the parsed header and BAI
     // (keyed by the resolved path: "a.bam" and "./a.bam" are one file, one resident copy)
@@ -652,6 +661,7 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             T[5] = 1;
         } else {
         const double t_dec = now_s();
+        const AllocSnap a_dec = AllocSnap::now();
         res = std::make_shared<Resident>();
         res->key = rkey;
         res->slots = slots;
@@ -726,9 +736,13 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         }
         T[2] = t6[5];
         T[1] = now_s() - t_dec - T[2];
+        // driver allocation calls of the decode stage, layout included (they run on this thread and on the helper
+        // that reserves the resident columns; the meter is per process: concurrent calls of other threads add to it)
+        X[0] = AllocSnap::now().seconds_since(a_dec);
+        bsig::decode_reservation_info(&X[8], &X[9]);
         if (!key.empty()) {
-            bsig_reads_info inf;
-            if (bsig_reads_get_info(res->reads[0], &inf) == BSIG_OK) res->bytes = inf.hbm_bytes;
+            // (what the reads hold on the device, slabs and an over-sized reservation included)
+            res->bytes = res->reads[0]->pool.footprint();
             std::lock_guard<std::mutex> lock(g_cache.mu);
             bool still = false;                            // (bsig_cache_clear may have run meanwhile)
             for (auto &sp : g_cache.slot_sets) still = still || sp == slots;
@@ -757,10 +771,27 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     if (!side_to_write.empty()) (void)bsig_reads_save(res->reads[0], side_to_write.c_str(), side_stamp.c_str());
 
     const double t_run = now_s();
+    const AllocSnap a_run = AllocSnap::now();
     std::string gather;
-    if (!many) rc = bsig_pileup_columns(slots->ctx[0], res->reads[0], n, rid.data(), loc.data(), width, strand, &prm, out, off);
-    else rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, gather);
+    if (!many) {
+        // plan (ranges -> tiles in HBM), kernels, download -- timed apart
+        bsig_plan *plan = nullptr;
+        rc = bsig_plan_create(slots->ctx[0], res->reads[0], n, rid.data(), loc.data(), width, strand, &prm, &plan);
+        X[3] = now_s() - t_run;
+        if (rc == BSIG_OK && memcmp(off, bsig_plan_offsets(plan), (size_t)(n + 1) * sizeof(int64_t)) != 0)
+            rc = fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters");
+        if (rc == BSIG_OK) rc = bsig::plan_run_host_timed(plan, out, &X[4], &X[5]);
+        if (plan) bsig_plan_free(plan);
+    } else {
+        rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, gather);
+    }
     T[3] = now_s() - t_run;
+    X[1] = AllocSnap::now().seconds_since(a_run);
+    {
+        const AllocSnap a_end = AllocSnap::now();
+        X[2] = a_end.seconds_since(a_begin);
+        X[6] = (double)(a_end.calls - a_begin.calls);
+    }
     if (rc == BSIG_OK) rc = bam_index_wait(bam);      // a damaged index fails the call, as it does in the reference's open
     T[4] = now_s() - t_begin;
     snprintf(g_call_route, sizeof g_call_route, "%zu GPU slot(s); reads: %s; result: %s", nd, how_decoded.c_str(),
@@ -922,6 +953,11 @@ int32_t bsig_effective_cpus(void) { return (int32_t)bsig::effective_cpus(); }
 void bsig_last_call_timing(double *t6)
 {
     for (int k = 0; k < 6; ++k) t6[k] = g_call_timing[k];
+}
+
+void bsig_last_call_timing_ex(double *t, int32_t n)
+{
+    for (int k = 0; k < n && k < 16; ++k) t[k] = k < 6 ? g_call_timing[k] : g_call_timing_ex[k - 6];
 }
 
 void bsig_bam_decode_timing(double *t6)

@@ -54,6 +54,7 @@ using bsig::fail;
 // the per-process cache of large free device blocks (runtime_internal.h)
 // ---------------------------------------------------------------------------------------------
 namespace bsig {
+AllocMeter g_alloc_meter;
 namespace {
 struct BlockCache {
     struct Blk { int dev; void *p; size_t bytes; };
@@ -131,7 +132,7 @@ void arena_reserve(int device)
     Arena a;
     a.dev = device;
     a.size = (size_t)gb << 30;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&a.base, a.size) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipSetDevice(device) != hipSuccess || metered_malloc((void **)&a.base, a.size) != hipSuccess) { (void)hipGetLastError(); return; }
     a.free_.push_back({0, a.size});
     g_arenas.push_back(a);
 }
@@ -144,7 +145,7 @@ static void arena_release_idle()
         Arena &a = g_arenas[k];
         if (a.free_.size() == 1 && a.free_[0].first == 0 && a.free_[0].second == a.size) {
             (void)hipSetDevice(a.dev);
-            (void)hipFree(a.base);
+            (void)metered_free(a.base);
             g_arenas.erase(g_arenas.begin() + (long)k);
         } else {
             ++k;
@@ -174,13 +175,13 @@ hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, siz
         }
     }
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(p, bytes);
+    if (e == hipSuccess) e = metered_malloc(p, bytes);
     if (e == hipErrorOutOfMemory) {
         // the cache itself may be what fills the device: hand it back and try once more
         (void)hipGetLastError();
         block_cache_release();
         (void)hipSetDevice(device);
-        e = hipMalloc(p, bytes);
+        e = metered_malloc(p, bytes);
     }
     if (e != hipSuccess) { *p = nullptr; return e; }
     *got = bytes;
@@ -195,7 +196,7 @@ void block_free(int device, void *p, size_t bytes)
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
-        (void)hipFree(p);
+        (void)metered_free(p);
         if (cur != device) (void)hipSetDevice(cur);
         return;
     }
@@ -221,7 +222,7 @@ void block_free(int device, void *p, size_t bytes)
     if (drop.empty()) return;
     int cur = 0;
     (void)hipGetDevice(&cur);
-    for (const BlockCache::Blk &b : drop) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    for (const BlockCache::Blk &b : drop) { (void)hipSetDevice(b.dev); (void)metered_free(b.p); }
     (void)hipSetDevice(cur);
 }
 
@@ -237,7 +238,7 @@ void block_cache_release()
     if (all.empty()) return;
     int cur = 0;
     (void)hipGetDevice(&cur);
-    for (const BlockCache::Blk &b : all) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); }
+    for (const BlockCache::Blk &b : all) { (void)hipSetDevice(b.dev); (void)metered_free(b.p); }
     (void)hipSetDevice(cur);
 }
 }  // namespace bsig
@@ -437,7 +438,7 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
         for (int c = 0; c < BSIG_MAX_CLASSES; ++c) R->dev.cls[c] = BsigClassCols{};
         return BSIG_OK;
     }
-    DevPool tmp;
+    DevPool tmp(1e9);          // scratch of this call: any cached block that is large enough will do
     const bool diag = getenv("BSIG_DIAG_DECODE") != nullptr;
     const auto t_diag0 = std::chrono::steady_clock::now();
     auto diag_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_diag0).count(); };
@@ -456,10 +457,9 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
     uint16_t *d_codemap = nullptr;
     if (!(getenv("BAMSIGNALS_PACK") && !strcmp(getenv("BAMSIGNALS_PACK"), "0"))) {
         constexpr uint32_t kKeys = 1u << 20, kPairCap = 16384;
-        // one block for the counters, the pair list, its length and the code map: 4 MB + 128 KB + 2 MB, rounded
-        // up to what the cache of free blocks keeps (a decode's layout finds it there again)
+        // one block for the counters, the pair list, its length and the code map: 4 MB + 128 KB + 2 MB
         uint8_t *blk;
-        HIP_TRY(tmp.alloc(&blk, std::max<size_t>(bsig::kBlockCacheMin, (size_t)kKeys * 4 + kPairCap * 8 + 256 + (size_t)kKeys * 2)));
+        HIP_TRY(tmp.alloc(&blk, (size_t)kKeys * 4 + kPairCap * 8 + 256 + (size_t)kKeys * 2));
         uint32_t *d_hist = (uint32_t *)blk;
         uint2 *d_pairs = (uint2 *)(blk + (size_t)kKeys * 4);
         uint32_t *d_npairs = (uint32_t *)(blk + (size_t)kKeys * 4 + kPairCap * 8);
@@ -585,7 +585,7 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
                                            const_cast<uint32_t *>(R->dev.cls[c].idx), st));
     HIP_TRY(hipStreamSynchronize(st));
     if (diag) fprintf(stderr, "  [layout] scatter + indexes %.1f ms\n", diag_ms());
-    R->info.hbm_bytes = R->pool.bytes;
+    R->info.hbm_bytes = R->pool.footprint();
     return BSIG_OK;
 }
 
@@ -727,7 +727,7 @@ int bsig_reads_clone(const bsig_reads *src, bsig_ctx *dst_ctx, bsig_reads **out)
         return fail(e == hipErrorOutOfMemory ? BSIG_ERR_NOMEM : BSIG_ERR_DEVICE, "copying the reads to GPU %d failed: %s", ddev,
                     hipGetErrorString(e));
     }
-    R->info.hbm_bytes = R->pool.bytes;
+    R->info.hbm_bytes = R->pool.footprint();
     *out = R;
     return BSIG_OK;
 }
@@ -748,7 +748,7 @@ struct DownloadStage {
     int ensure()
     {
         for (int k = 0; k < 2; ++k) {
-            if (!buf[k]) HIP_TRY(hipHostMalloc((void **)&buf[k], kHalf, hipHostMallocDefault));
+            if (!buf[k]) HIP_TRY(bsig::metered_host_malloc((void **)&buf[k], kHalf));
             if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
         }
         return BSIG_OK;
@@ -1126,7 +1126,7 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         R->dev.fmtab = d;
     }
-    R->info.hbm_bytes = R->pool.bytes;
+    R->info.hbm_bytes = R->pool.footprint();
     // what arrived in HBM: indexes the kernels can follow blindly, and the bytes the writer had
     {
         int *d_bad = nullptr, bad = 0;
@@ -1427,6 +1427,28 @@ int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
     if (e != hipSuccess) rc = fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
     return rc;
 }
+
+}  // extern "C"
+int bsig::plan_run_host_timed(bsig_plan *p, int32_t *out_host, double *t_kernels, double *t_download)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    if (!p) return fail(BSIG_ERR_ARG, "plan is NULL");
+    const int64_t cells = p->off.back();
+    if (cells == 0) return BSIG_OK;
+    if (!out_host) return fail(BSIG_ERR_ARG, "output buffer is NULL");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    if (!p->d_out) HIP_TRY(p->pool.alloc(&p->d_out, (size_t)cells));
+    int rc = bsig_plan_run(p, p->d_out);
+    if (rc != BSIG_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    *t_kernels = since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = bsig::download_to_host(p->ctx, p->d_out, out_host, (size_t)cells * sizeof(int32_t));
+    *t_download = since(t1);
+    return rc;
+}
+extern "C" {
 
 int bsig_plan_run_host_async(bsig_plan *p, int32_t *out_host)
 {

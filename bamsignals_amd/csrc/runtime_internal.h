@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -30,7 +32,27 @@ namespace bsig {
 // return to, a per-process cache of free blocks (best fit within `max_waste`), bounded by env
 // BAMSIGNALS_SCRATCH_CACHE_GB per GPU (default 48; above it the largest free blocks are released first);
 // bsig_cache_clear() releases all of it.
-constexpr size_t kBlockCacheMin = (size_t)8 << 20;
+constexpr size_t kBlockCacheMin = (size_t)1 << 20;
+constexpr size_t kSlabBytes = (size_t)1 << 20;       // what a pool carves its small allocations out of
+// Every trip into the driver's allocator (hipMalloc, hipFree, hipHostMalloc, hipHostFree) goes through these and
+// is metered, per process: where a call's time goes when it is not in a kernel or a copy is then a number
+// (bsig_last_call_timing_ex) instead of a guess.
+struct AllocMeter {
+    std::atomic<int64_t> ns{0}, calls{0};
+};
+extern AllocMeter g_alloc_meter;
+struct AllocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocTimer()
+    {
+        g_alloc_meter.ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+        g_alloc_meter.calls.fetch_add(1);
+    }
+};
+inline hipError_t metered_malloc(void **p, size_t bytes) { AllocTimer t; return hipMalloc(p, bytes); }
+inline hipError_t metered_free(void *p) { AllocTimer t; return hipFree(p); }
+inline hipError_t metered_host_malloc(void **p, size_t bytes) { AllocTimer t; return hipHostMalloc(p, bytes, hipHostMallocDefault); }
+inline hipError_t metered_host_free(void *p) { AllocTimer t; return hipHostFree(p); }
 // *got receives the block's real size (>= bytes), which block_free wants back
 hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, size_t *got);
 void block_free(int device, void *p, size_t bytes);
@@ -41,31 +63,82 @@ void arena_reserve(int device);
 }  // namespace bsig
 
 // owns a set of device allocations (all of them through block_alloc: the arena if there is one, the cache of
-// free blocks for large ones, hipMalloc otherwise)
+// free blocks for large ones, hipMalloc otherwise).  Requests below kSmall bytes are carved out of slabs of
+// kSlabBytes (which the cache of free blocks keeps between uses): a layout or a plan makes a dozen
+// allocations of a few hundred bytes each, and every one of them would be a trip into the driver.
+// A pool may adopt a RESERVATION: one block made ahead of time (reads_from_bam_device reserves the resident
+// columns on a side thread while the file is still being inflated); allocations are carved out of it while
+// it lasts.
 struct DevPool {
     struct Blk { void *p; size_t bytes; int device; };
     std::vector<Blk> blks;
     int64_t bytes = 0;
+    double max_waste;                 // how much larger than asked a cached block may be (long-lived data: little)
+    static constexpr size_t kSmall = (size_t)256 << 10;
+    uint8_t *slab = nullptr;          // current slab for small requests (one of blks)
+    size_t slab_left = 0;
+    uint8_t *res = nullptr;           // the adopted reservation (one of blks)
+    size_t res_left = 0;
+    explicit DevPool(double waste = 1.125) : max_waste(waste) {}
+    DevPool(const DevPool &) = delete;
+    DevPool &operator=(const DevPool &) = delete;
+    void adopt(int device, void *p, size_t got)
+    {
+        blks.push_back(Blk{p, got, device});
+        res = (uint8_t *)p;
+        res_left = got;
+    }
     template <typename T>
     hipError_t alloc(T **p, size_t count)
     {
-        void *q = nullptr;
-        const size_t nbytes = std::max<size_t>(count * sizeof(T), 16);
+        const size_t nbytes = (std::max<size_t>(count * sizeof(T), 16) + 255) & ~(size_t)255;
+        bytes += (int64_t)nbytes;
+        if (res && nbytes <= res_left) {
+            *p = (T *)res;
+            res += nbytes;
+            res_left -= nbytes;
+            return hipSuccess;
+        }
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        if (nbytes <= kSmall) {
+            if (nbytes > slab_left) {
+                void *q = nullptr;
+                size_t got = 0;
+                e = bsig::block_alloc(dev, bsig::kSlabBytes, 2.0, &q, &got);
+                if (e != hipSuccess) { *p = nullptr; return e; }
+                blks.push_back(Blk{q, got, dev});
+                slab = (uint8_t *)q;
+                slab_left = got;
+            }
+            *p = (T *)slab;
+            slab += nbytes;
+            slab_left -= nbytes;
+            return hipSuccess;
+        }
+        void *q = nullptr;
         size_t got = 0;
-        if (e == hipSuccess) e = bsig::block_alloc(dev, nbytes, 1.125, &q, &got);      // long-lived: little slack
+        e = bsig::block_alloc(dev, nbytes, max_waste, &q, &got);
         if (e != hipSuccess) { *p = nullptr; return e; }
         blks.push_back(Blk{q, got, dev});
-        bytes += (int64_t)nbytes;
         *p = (T *)q;
         return hipSuccess;
+    }
+    // device bytes this pool holds (slabs and an over-sized reservation included: what the cache budgets count)
+    int64_t footprint() const
+    {
+        int64_t t = 0;
+        for (const Blk &b : blks) t += (int64_t)b.bytes;
+        return t;
     }
     void release()
     {
         for (const Blk &b : blks) bsig::block_free(b.device, b.p, b.bytes);
         blks.clear();
         bytes = 0;
+        slab = res = nullptr;
+        slab_left = res_left = 0;
     }
     ~DevPool() { release(); }
 };
@@ -103,6 +176,9 @@ hipError_t warm_decode_module(hipStream_t st);      // devdecode.hip
 hipError_t warm_collect_module(hipStream_t st);     // collect.hip
 // hands the device-side decode's cached scratch back to the driver (devdecode.hip)
 void release_decode_scratch();
+// the calling thread's last whole-file decode: bytes reserved ahead of time for the resident columns, and the
+// seconds the layout waited for that reservation (devdecode.hip)
+void decode_reservation_info(double *bytes, double *wait_s);
 // > 0: the file (or this build's limits) needs another decode path; nothing was allocated
 constexpr int kNeedsCpuPath = 1;
 // Whole BAM -> resident reads on every listed GPU: each GPU decodes one share of the BGZF blocks, the
@@ -117,5 +193,7 @@ int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::s
 // a device buffer to (pageable or page-locked) host memory, staged through page-locked halves where
 // that is faster (runtime.hip)
 int download_to_host(bsig_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes);
+// bsig_plan_run_host with the kernels' and the download's seconds told apart (runtime.hip)
+int plan_run_host_timed(bsig_plan *p, int32_t *out_host, double *t_kernels, double *t_download);
 }  // namespace bsig
 #endif

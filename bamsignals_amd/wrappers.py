@@ -145,11 +145,15 @@ def coverage_core(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1
 
 
 def last_call_timing():
-    """Stage seconds of this thread's last bamCount/bamProfile/bamCoverage call."""
-    t = (C.c_double * 6)()
-    _lib.load().bsig_last_call_timing(t)
+    """Stage seconds of this thread's last bamCount/bamProfile/bamCoverage call, and where the stages' time went
+    (``alloc_*``: seconds inside the driver's allocator -- hipMalloc, hipFree, hipHostMalloc -- metered per
+    process; ``plan`` / ``kernels`` / ``download``: the parts of ``plan_run_download`` on one GPU)."""
+    t = (C.c_double * 16)()
+    _lib.load().bsig_last_call_timing_ex(t, 16)
     return dict(open=t[0], decode=t[1], upload_and_layout=t[2], plan_run_download=t[3], total=t[4],
-                bam_was_resident=bool(t[5]))
+                bam_was_resident=bool(t[5]), alloc_in_decode_and_layout=t[6], alloc_in_plan_run_download=t[7],
+                alloc_total=t[8], plan=t[9], kernels=t[10], download=t[11], alloc_calls=int(t[12]),
+                reserved_bytes=int(t[14]), reservation_wait=t[15])
 
 
 def last_call_route():

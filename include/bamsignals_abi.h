@@ -115,7 +115,7 @@ typedef struct bsig_reads bsig_reads;
 #define BSIG_N_CLASSES 5
 typedef struct {
     int64_t n_reads;
-    int64_t hbm_bytes;              /* resident bytes: class columns + bucket indexes            */
+    int64_t hbm_bytes;              /* device bytes held: class columns + bucket indexes (blocks as allocated) */
     int32_t n_classes;              /* classes in use                                            */
     int32_t n_codes;                /* (flag, mapq) pairs in the packed class's table            */
     int64_t class_n[BSIG_N_CLASSES];
@@ -334,6 +334,17 @@ const char *bsig_last_call_route(void);
  * BAI), decode, upload + HBM layout, plan + kernels + download, total; t6[5] = 1 if the BAM was
  * already resident in HBM                                                                      */
 void bsig_last_call_timing(double *t6);
+/* the same (slots 0..5) and where the stages' time went, n <= 16 slots:
+ *   6  seconds inside the driver's allocator (hipMalloc / hipFree / hipHostMalloc ...) during decode + layout
+ *   7  ... during plan + kernels + download          8  ... during the whole call
+ *   9  plan creation (ranges -> tiles in HBM, heavy-tile probe)   10  kernels (launch .. stream idle; includes the
+ *      result buffer's allocation)   11  download of the result to host memory   (9-11: one GPU; 0 with several)
+ *   12 driver allocation calls of the whole call
+ *   13 reserved
+ *   14 bytes reserved for the resident columns while the file was still being inflated (0: no reservation)
+ *   15 seconds the layout waited for that reservation
+ * The allocator meter is per process: calls made by other threads at the same time are counted too.         */
+void bsig_last_call_timing_ex(double *t, int32_t n);
 
 /* ------------------------------------------------------------------------------------------
  * Reassembly of sharded results (multi-GPU): segment k of src (src_off[k] .. src_off[k+1]) is

@@ -41,9 +41,12 @@ for k in range(sessions):
         sys.stderr = _real_stderr
     c = child["calls"][0]
     runs.append((c["call_s"], c["stages_s"], child.get("stderr", "")))
-    print(variants[k % len(variants)] or "", "session %d: call %.3f s, decode %.3f s (its timed stages %.3f s), plan + run + download %.3f s" % (
-        k, c["call_s"], c["stages_s"]["decode"], sum(v for kk, v in c["stages_s"]["decode_stages_s"].items() if kk not in ("total",)),
-        c["stages_s"]["plan_run_download"]), flush=True)
+    st = c["stages_s"]
+    print(variants[k % len(variants)] or "", "session %d: call %.3f s = decode %.3f + layout %.3f + plan %.3f + kernels %.3f + download %.3f; "
+          "in the driver's allocator %.3f s (%d calls; decode+layout %.3f, run %.3f), reserved %.2f GB (waited %.3f s)" % (
+              k, c["call_s"], st["decode"], st["upload_and_layout"], st.get("plan", 0), st.get("kernels", 0), st.get("download", 0),
+              st.get("alloc_total", 0), st.get("alloc_calls", 0), st.get("alloc_in_decode_and_layout", 0), st.get("alloc_in_plan_run_download", 0),
+              st.get("reserved_bytes", 0) / 2**30, st.get("reservation_wait", 0)), flush=True)
 med = float(np.median([r[0] for r in runs]))
 print("median %.3f s, min %.3f, max %.3f" % (med, min(r[0] for r in runs), max(r[0] for r in runs)))
 if len(variants) > 1:

@@ -105,3 +105,9 @@ def expected_packed(pos, end, flag, mapq, ref_off, ref_len, n_codes=512):
     rid = np.searchsorted(np.asarray(ref_off)[1:], np.arange(n), side="right")
     ref_bp = ((np.asarray(ref_len, np.int64) >> 16) + 1) << 16
     return cand & (pos < ref_bp[rid]) & np.isin(key, table), len(table)
+
+
+def layout_info(reads):
+    """What two layouts of the same reads must agree on: the classes, their sizes, spans, bucket widths and the pair
+    table's size -- not the bytes held on the device, which depend on which cached blocks a layout was given."""
+    return {k: v for k, v in reads.info().items() if k != "hbm_bytes"}

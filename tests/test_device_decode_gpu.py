@@ -11,7 +11,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, layout_info
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +25,7 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
 
 
 def _bgzf(data, sizes, levels=((1, 0),)):
@@ -97,7 +98,7 @@ def _both_ways(ctx, path, monkeypatch, expect_device=True):
     monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
     cpu = Reads.from_bam(ctx, bam)
     assert Reads.device_decode_timing()["total"] == 0
-    assert dev.info() == cpu.info()
+    assert layout_info(dev) == layout_info(cpu)
     for a, b in zip(_results(ctx, dev, bam.ref_len), _results(ctx, cpu, bam.ref_len)):
         assert np.array_equal(a, b)
     if not expect_device:
@@ -116,7 +117,7 @@ def test_fixture_bam(ctx, monkeypatch, fixture_reads):
     from bamsignals_amd.device import Context
     ctx2 = Context(0)                                  # a second context: the multi-GPU replication path
     twin = dev.clone(ctx2)
-    assert twin.info() == dev.info()
+    assert layout_info(twin) == layout_info(dev)
     for a, b in zip(_results(ctx2, twin, bam.ref_len), _results(ctx, dev, bam.ref_len)):
         assert np.array_equal(a, b)
     twin.close()
@@ -490,7 +491,7 @@ def _regions_both_ways(ctx, bam, rg, monkeypatch, expect_device=True):
     assert (Reads.device_decode_timing()["total"] > 0) == expect_device
     monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
     cpu = Reads.from_bam_regions(ctx, bam, rg["rid"], beg, end)
-    assert dev.info() == cpu.info()
+    assert layout_info(dev) == layout_info(cpu)
     host = bam.decode(rg["rid"], beg, end)
     assert dev.n_reads == len(host["pos"])
     out = []
@@ -614,12 +615,12 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         n_sharded += bool(was_sharded)
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "0")
         cpu = Reads.from_bam(ctx, bam)
-        assert dev.n_reads == n_placed and dev.info() == cpu.info(), case
+        assert dev.n_reads == n_placed and layout_info(dev) == layout_info(cpu), case
         want = _results(ctx, cpu, bam.ref_len.astype(np.int64), seed=case)
         for a, b in zip(_results(ctx, dev, bam.ref_len.astype(np.int64), seed=case), want):
             assert np.array_equal(a, b), case
         for k, sh in enumerate(shares):
-            assert sh.info() == cpu.info(), (case, k)
+            assert layout_info(sh) == layout_info(cpu), (case, k)
         for a, b in zip(_results(shares[-1].ctx, shares[-1], bam.ref_len.astype(np.int64), seed=case), want):
             assert np.array_equal(a, b), case
         for sh in shares:
