@@ -133,6 +133,8 @@ def load():
     lib.bsig_bam_decode_timing.restype = None
     lib.bsig_pileup_core.argtypes = core_head + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]
     lib.bsig_coverage_core.argtypes = core_head + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
+    lib.bsig_pileup_core_into.argtypes = core_head + [C.c_int32] * 9 + [C.c_void_p]
+    lib.bsig_coverage_core_into.argtypes = core_head + [C.c_int32] * 6 + [C.c_void_p]
     lib.bsig_write_sam_as_bam_and_index.argtypes = [C.c_char_p, C.c_char_p]
     lib.bsig_write_columns_as_bam.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(Columns),
                                               C.c_int32]

@@ -278,6 +278,44 @@ int grow_pinned(Slots &sl, int device, int32_t **p, size_t *cap, size_t want)
     return BSIG_OK;
 }
 
+// segment k of src goes to range which[k] of the destination (the body of bsig_scatter_segments; the destination
+// may be one flat buffer or one vector per range)
+int scatter_segments_to(int64_t n, const int32_t *src, const int64_t *src_off, const bsig::HostDest &dst, const int64_t *which)
+{
+    if (n > 0 && (!src_off || !dst.off || !which)) return fail(BSIG_ERR_ARG, "NULL argument");
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t len = src_off[k + 1] - src_off[k];
+        const int64_t i = which[k];
+        if (len < 0 || i < 0) return fail(BSIG_ERR_ARG, "bad segment %lld", (long long)k);
+        if (len != dst.off[i + 1] - dst.off[i]) return fail(BSIG_ERR_ARG, "segment %lld does not fit its destination", (long long)k);
+    }
+    if (n <= 0) return BSIG_OK;
+    auto copy_range = [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const int64_t len = src_off[k + 1] - src_off[k];
+            if (len) memcpy(dst.range(which[k]), src + src_off[k], (size_t)len * sizeof(int32_t));
+        }
+    };
+    // the destinations are disjoint (each range owns its cells): big results are moved by a few
+    // threads, each taking a contiguous share of the source
+    const int64_t cells = src_off[n] - src_off[0];
+    int n_thr = cells * (int64_t)sizeof(int32_t) >= (16 << 20) ? 8 : 1;
+    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    n_thr = (int)std::min<int64_t>(n_thr, n);
+    if (n_thr <= 1) { copy_range(0, n); return BSIG_OK; }
+    std::vector<int64_t> cut((size_t)n_thr + 1, n);
+    cut[0] = 0;
+    for (int t = 1; t < n_thr; ++t) {
+        const int64_t target = src_off[0] + cells * t / n_thr;
+        cut[(size_t)t] = std::lower_bound(src_off, src_off + n, target) - src_off;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; ++t) th.emplace_back(copy_range, cut[(size_t)t], cut[(size_t)t + 1]);
+    copy_range(cut[0], cut[1]);
+    for (auto &x : th) x.join();
+    return BSIG_OK;
+}
+
 // ---- several GPUs: ranges are independent (each owns its output, ref: src/bamsignals.cpp:164,181,186)
 // The (rid, loc)-sorted ranges (ref: :222-226,246) are dealt round-robin to the GPUs; every GPU plans
 // and runs its shard on its own stream, driven by its own host thread, into a shard buffer the slot
@@ -292,9 +330,10 @@ int grow_pinned(Slots &sl, int device, int32_t **p, size_t *cap, size_t want)
 //                 buffer, put in place by host threads (bsig_scatter_segments).
 // All device and page-locked buffers are kept in the Slots: a call on a resident BAM allocates nothing here.
 int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, const int32_t *rid, const int32_t *loc,
-                 const int32_t *width, const int32_t *strand, const bsig_params &prm, int32_t *out, const int64_t *off,
+                 const int32_t *width, const int32_t *strand, const bsig_params &prm, const bsig::HostDest &dest,
                  std::string &gather_name)
 {
+    const int64_t *off = dest.off;
     std::lock_guard<std::mutex> run_lock(sl.run_mu);
     const double t0 = now_s();
     const size_t nd = sl.ctx.size();
@@ -312,15 +351,50 @@ int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, c
         const size_t cap = (size_t)n / nd + 1;
         sh[k].which.reserve(cap); sh[k].rid.reserve(cap); sh[k].loc.reserve(cap); sh[k].len.reserve(cap); sh[k].strand.reserve(cap);
     }
+    // the sorted ranges are dealt in BLOCKS of consecutive ranges (block b to GPU b mod N; at least eight blocks per
+    // GPU, at most 4,096 ranges per block): still balanced over the genome, and where the caller's order is the
+    // sorted order -- tilings, sorted peaks -- a block is one contiguous slice of the caller's result, which its GPU
+    // can deliver over its own PCIe link without any reassembly ("blocks" below)
+    int64_t block = n / (int64_t)(nd * 8);
+    block = std::max<int64_t>(1, std::min<int64_t>(block, 4096));
+    if (const char *e = getenv("BAMSIGNALS_SHARD_BLOCK")) block = std::max<int64_t>(1, atoll(e));      // (1 = round-robin, range by range)
     for (int64_t k = 0; k < n; ++k) {
-        Shard &S = sh[(size_t)(k % (int64_t)nd)];
+        Shard &S = sh[(size_t)((k / block) % (int64_t)nd)];
         const int64_t i = order[(size_t)k];
         S.which.push_back(i);
         S.rid.push_back(rid[i]); S.loc.push_back(loc[i]);
         S.len.push_back(width[i]); S.strand.push_back(strand[i]);
     }
+    // runs of a shard whose ranges are consecutive in the caller's order: contiguous slices of the caller's result
+    struct Run { int64_t j0, j1; };                // segments [j0, j1) of the shard
+    std::vector<std::vector<Run>> runs(nd);
+    int64_t n_runs = 0;
+    for (size_t k = 0; k < nd; ++k) {
+        const std::vector<int64_t> &w = sh[k].which;
+        for (size_t j = 0; j < w.size();) {
+            size_t e = j + 1;
+            while (e < w.size() && w[e] == w[e - 1] + 1) ++e;
+            runs[k].push_back(Run{(int64_t)j, (int64_t)e});
+            j = e;
+        }
+        n_runs += (int64_t)runs[k].size();
+    }
+    // "blocks": by request, or by itself where the slices are long (64 ranges or more on average) and the result
+    // is large enough for the route to matter
+    const char *genv = getenv("BAMSIGNALS_GATHER");
+    if (genv && !*genv) genv = nullptr;
+    const bool blocks = genv ? !strcmp(genv, "blocks") : (n_runs * 64 <= n && off[n] * (int64_t)sizeof(int32_t) >= ((int64_t)32 << 20));
     const bool pcie = env_is("BAMSIGNALS_GATHER", "pcie");
-    gather_name = pcie ? "pcie" : "xgmi";
+    gather_name = blocks ? "pcie/blocks" : pcie ? "pcie" : "xgmi";
+    // host threads that move page-locked halves on, per GPU: all GPUs download at once (slots that name the same
+    // GPU take turns on its staging halves, each with the device's full share of threads)
+    std::vector<int> distinct(sl.devices);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    int copy_total = 16;
+    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) copy_total = std::max(1, std::min(64, atoi(e)));
+    const int copy_thr = std::max(2, copy_total / (int)std::max<size_t>(distinct.size(), 1));
+    std::vector<double> t_run_done(nd, 0.0);
     auto cleanup = [&]() {
         for (Shard &S : sh)
             if (S.plan) { bsig_plan_free(S.plan); S.plan = nullptr; }
@@ -344,6 +418,18 @@ int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, c
         if (r) return r;
         r = bsig_plan_run(S.plan, X.d_shard);
         if (r) return r;
+        if (blocks) {
+            // every contiguous slice of the caller's result this GPU owns leaves over this GPU's own PCIe link,
+            // straight to its place: no gather on one GPU, no reassembly pass on the host
+            r = bsig_ctx_sync(sl.ctx[k]);
+            if (r) return r;
+            t_run_done[k] = now_s();
+            std::vector<int64_t> s0, d0, nc;
+            for (const Run &q : runs[k]) {
+                s0.push_back(po[q.j0]); d0.push_back(off[S.which[(size_t)q.j0]]); nc.push_back(po[q.j1] - po[q.j0]);
+            }
+            return bsig::download_slices_to_dest(sl.ctx[k], X.d_shard, (int64_t)s0.size(), s0.data(), d0.data(), nc.data(), dest, copy_thr);
+        }
         if (pcie && S.cells) {
             r = grow_pinned(sl, sl.devices[k], &X.h_shard, &X.h_cap, (size_t)S.cells);
             if (r) return r;
@@ -358,11 +444,19 @@ int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, c
     for (size_t k = 0; k < nd; ++k) cells += sh[k].cells;
     const int64_t total = off[n];
     if (cells != total) { cleanup(); return fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters"); }
-    char times[96];
+    char times[128];
+    if (blocks) {
+        cleanup();
+        double t_run = t0;
+        for (double t : t_run_done) t_run = std::max(t_run, t);
+        snprintf(times, sizeof times, " (plan+run %.3f s, download in %lld slices %.3f s)", t_run - t0, (long long)n_runs, t1 - t_run);
+        gather_name += times;
+        return BSIG_OK;
+    }
     if (pcie) {
         for (size_t k = 0; k < nd && rc == BSIG_OK; ++k)
-            rc = bsig_scatter_segments((int64_t)sh[k].which.size(), sl.scratch[k].h_shard, bsig_plan_offsets(sh[k].plan), out, off,
-                                       sh[k].which.data());
+            rc = scatter_segments_to((int64_t)sh[k].which.size(), sl.scratch[k].h_shard, bsig_plan_offsets(sh[k].plan), dest,
+                                     sh[k].which.data());
         cleanup();
         snprintf(times, sizeof times, " (plan+run+d2h %.3f s, host scatter %.3f s)", t1 - t0, now_s() - t1);
         gather_name += times;
@@ -439,7 +533,7 @@ int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, c
         HIP_TRY(hipStreamSynchronize(st));
         use.release();
         t2 = now_s();
-        r = bsig::download_to_host(sl.ctx[0], G.d_final, out, (size_t)total * sizeof(int32_t));
+        r = bsig::download_to_dest(sl.ctx[0], G.d_final, dest, total);
         t3 = now_s();
         return r;
     };
@@ -503,12 +597,12 @@ bool regions_covered(const Resident &R, int64_t n, const int32_t *rid, const int
 // the common body of pileup_core / coverage_core
 int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
                const char *const *levels, const int32_t *start, const int32_t *width,
-               const int32_t *strand, const bsig_params &prm, int32_t device, int32_t *out,
-               const int64_t *off)
+               const int32_t *strand, const bsig_params &prm, int32_t device, const bsig::HostDest &dest)
 {
     if (!bampath) return fail(BSIG_ERR_ARG, "bampath is NULL");
     if (n < 0 || (n > 0 && (!seq_code || !start || !width || !strand || !levels)))
         return fail(BSIG_ERR_ARG, "range arrays missing");
+    const int64_t *off = dest.off;
     if (!off) return fail(BSIG_ERR_ARG, "offsets missing");
     double *T = g_call_timing, *X = g_call_timing_ex;
     for (int k = 0; k < 6; ++k) T[k] = 0;
@@ -780,10 +874,10 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         X[3] = now_s() - t_run;
         if (rc == BSIG_OK && memcmp(off, bsig_plan_offsets(plan), (size_t)(n + 1) * sizeof(int64_t)) != 0)
             rc = fail(BSIG_ERR_ARG, "offsets do not match bsig_layout() for these parameters");
-        if (rc == BSIG_OK) rc = bsig::plan_run_host_timed(plan, out, &X[4], &X[5]);
+        if (rc == BSIG_OK) rc = bsig::plan_run_host_timed(plan, dest, &X[4], &X[5]);
         if (plan) bsig_plan_free(plan);
     } else {
-        rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, out, off, gather);
+        rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, dest, gather);
     }
     T[3] = now_s() - t_run;
     X[1] = AllocSnap::now().seconds_since(a_run);
@@ -965,12 +1059,12 @@ void bsig_bam_decode_timing(double *t6)
     for (int k = 0; k < 6; ++k) t6[k] = bsig::g_decode_timing[k];
 }
 
-int bsig_pileup_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
-                     const char *const *levels, const int32_t *start, const int32_t *width,
-                     const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
-                     int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss, int32_t requiredF,
-                     int32_t filteredF, int32_t pe_mid, int32_t maxgap, int32_t device, int32_t *out,
-                     const int64_t *off)
+static int pileup_core_impl(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                            const char *const *levels, const int32_t *start, const int32_t *width,
+                            const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                            int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss, int32_t requiredF,
+                            int32_t filteredF, int32_t pe_mid, int32_t maxgap, int32_t device, int32_t *out,
+                            const int64_t *off, int32_t *const *dst)
 {
     (void)maxgap;
     bsig_params p;
@@ -981,14 +1075,48 @@ int bsig_pileup_core(const char *bampath, int64_t n, const int32_t *seq_code, in
     if (n_tlen_filter != 0 && n_tlen_filter != 2) return fail(BSIG_ERR_ARG, "tlen_filter must have 0 or 2 elements");
     p.n_tlen_filter = n_tlen_filter;
     for (int k = 0; k < n_tlen_filter; ++k) p.tlen_filter[k] = tlen_filter[k];
-    return file_level(bampath, n, seq_code, n_levels, levels, start, width, strand, p, device, out, off);
+    bsig::HostDest D;
+    std::vector<int64_t> own_off;
+    if (dst) {
+        // in place: the layout is computed here (bsig_layout); bamCount's is one vector, dst[0]
+        if (n < 0 || (n > 0 && !width)) return fail(BSIG_ERR_ARG, "range arrays missing");
+        own_off.resize((size_t)n + 1);
+        bsig_layout(n, width, binsize, ss, own_off.data());
+        D.off = own_off.data(); D.n = n;
+        if (binsize <= 0) D.flat = dst[0]; else D.ptrs = dst;
+    } else {
+        D.flat = out; D.off = off; D.n = n;
+    }
+    return file_level(bampath, n, seq_code, n_levels, levels, start, width, strand, p, device, D);
 }
 
-int bsig_coverage_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
-                       const char *const *levels, const int32_t *start, const int32_t *width,
-                       const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
-                       int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
-                       int32_t maxgap, int32_t device, int32_t *out, const int64_t *off)
+int bsig_pileup_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                     const char *const *levels, const int32_t *start, const int32_t *width,
+                     const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                     int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss, int32_t requiredF,
+                     int32_t filteredF, int32_t pe_mid, int32_t maxgap, int32_t device, int32_t *out,
+                     const int64_t *off)
+{
+    return pileup_core_impl(bampath, n, seq_code, n_levels, levels, start, width, strand, tlen_filter, n_tlen_filter, mapqual, binsize,
+                            shift, ss, requiredF, filteredF, pe_mid, maxgap, device, out, off, nullptr);
+}
+
+int bsig_pileup_core_into(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                          const char *const *levels, const int32_t *start, const int32_t *width,
+                          const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                          int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss, int32_t requiredF,
+                          int32_t filteredF, int32_t pe_mid, int32_t maxgap, int32_t device, int32_t *const *dst)
+{
+    if (!dst) return fail(BSIG_ERR_ARG, "destinations missing");
+    return pileup_core_impl(bampath, n, seq_code, n_levels, levels, start, width, strand, tlen_filter, n_tlen_filter, mapqual, binsize,
+                            shift, ss, requiredF, filteredF, pe_mid, maxgap, device, nullptr, nullptr, dst);
+}
+
+static int coverage_core_impl(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                              const char *const *levels, const int32_t *start, const int32_t *width,
+                              const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                              int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
+                              int32_t maxgap, int32_t device, int32_t *out, const int64_t *off, int32_t *const *dst)
 {
     (void)maxgap;
     bsig_params p;
@@ -998,7 +1126,38 @@ int bsig_coverage_core(const char *bampath, int64_t n, const int32_t *seq_code, 
     if (n_tlen_filter != 0 && n_tlen_filter != 2) return fail(BSIG_ERR_ARG, "tlen_filter must have 0 or 2 elements");
     p.n_tlen_filter = n_tlen_filter;
     for (int k = 0; k < n_tlen_filter; ++k) p.tlen_filter[k] = tlen_filter[k];
-    return file_level(bampath, n, seq_code, n_levels, levels, start, width, strand, p, device, out, off);
+    bsig::HostDest D;
+    std::vector<int64_t> own_off;
+    if (dst) {
+        if (n < 0 || (n > 0 && !width)) return fail(BSIG_ERR_ARG, "range arrays missing");
+        own_off.resize((size_t)n + 1);
+        bsig_layout(n, width, 1, 0, own_off.data());
+        D.off = own_off.data(); D.n = n; D.ptrs = dst;
+    } else {
+        D.flat = out; D.off = off; D.n = n;
+    }
+    return file_level(bampath, n, seq_code, n_levels, levels, start, width, strand, p, device, D);
+}
+
+int bsig_coverage_core(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                       const char *const *levels, const int32_t *start, const int32_t *width,
+                       const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                       int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
+                       int32_t maxgap, int32_t device, int32_t *out, const int64_t *off)
+{
+    return coverage_core_impl(bampath, n, seq_code, n_levels, levels, start, width, strand, tlen_filter, n_tlen_filter, mapqual,
+                              requiredF, filteredF, tspan, maxgap, device, out, off, nullptr);
+}
+
+int bsig_coverage_core_into(const char *bampath, int64_t n, const int32_t *seq_code, int32_t n_levels,
+                            const char *const *levels, const int32_t *start, const int32_t *width,
+                            const int32_t *strand, const int32_t *tlen_filter, int32_t n_tlen_filter,
+                            int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
+                            int32_t maxgap, int32_t device, int32_t *const *dst)
+{
+    if (!dst) return fail(BSIG_ERR_ARG, "destinations missing");
+    return coverage_core_impl(bampath, n, seq_code, n_levels, levels, start, width, strand, tlen_filter, n_tlen_filter, mapqual,
+                              requiredF, filteredF, tspan, maxgap, device, nullptr, nullptr, dst);
 }
 
 int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath)
@@ -1074,38 +1233,9 @@ void bsig_fast_width(int64_t n, const int64_t *length, int32_t ss, int32_t *widt
 int bsig_scatter_segments(int64_t n, const int32_t *src, const int64_t *src_off, int32_t *dst,
                           const int64_t *dst_off, const int64_t *which)
 {
-    if (n > 0 && (!src_off || !dst_off || !which)) return fail(BSIG_ERR_ARG, "NULL argument");
-    for (int64_t k = 0; k < n; ++k) {
-        const int64_t len = src_off[k + 1] - src_off[k];
-        const int64_t i = which[k];
-        if (len < 0 || i < 0) return fail(BSIG_ERR_ARG, "bad segment %lld", (long long)k);
-        if (len != dst_off[i + 1] - dst_off[i]) return fail(BSIG_ERR_ARG, "segment %lld does not fit its destination", (long long)k);
-    }
-    if (n <= 0) return BSIG_OK;
-    auto copy_range = [&](int64_t k0, int64_t k1) {
-        for (int64_t k = k0; k < k1; ++k) {
-            const int64_t len = src_off[k + 1] - src_off[k];
-            if (len) memcpy(dst + dst_off[which[k]], src + src_off[k], (size_t)len * sizeof(int32_t));
-        }
-    };
-    // the destinations are disjoint (each range owns its cells): big results are moved by a few
-    // threads, each taking a contiguous share of the source
-    const int64_t cells = src_off[n] - src_off[0];
-    int n_thr = cells * (int64_t)sizeof(int32_t) >= (16 << 20) ? 8 : 1;
-    if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
-    n_thr = (int)std::min<int64_t>(n_thr, n);
-    if (n_thr <= 1) { copy_range(0, n); return BSIG_OK; }
-    std::vector<int64_t> cut((size_t)n_thr + 1, n);
-    cut[0] = 0;
-    for (int t = 1; t < n_thr; ++t) {
-        const int64_t target = src_off[0] + cells * t / n_thr;
-        cut[(size_t)t] = std::lower_bound(src_off, src_off + n, target) - src_off;
-    }
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_thr; ++t) th.emplace_back(copy_range, cut[(size_t)t], cut[(size_t)t + 1]);
-    copy_range(cut[0], cut[1]);
-    for (auto &x : th) x.join();
-    return BSIG_OK;
+    bsig::HostDest D;
+    D.flat = dst; D.off = dst_off; D.n = 0;
+    return scatter_segments_to(n, src, src_off, D, which);
 }
 
 struct bsig_segmap {

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -773,7 +774,13 @@ bool is_pinned_host(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
-int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t *dst, size_t bytes)
+// One or more slices of device memory to host memory through the two page-locked halves: the slices are laid
+// back to back into chunks of one half each (several DMA copies per chunk where slices are short), and while one
+// half crosses PCIe a few threads move the other on -- sink(first cell of the flat result, source, cells) is
+// called by several threads at once, on disjoint pieces.
+struct DlSlice { const uint8_t *src; size_t bytes; int64_t dst_c0; };      // bytes: a multiple of 4
+typedef std::function<void(int64_t, const int32_t *, int64_t)> DownloadSink;
+int download_staged(int device, hipStream_t st, const std::vector<DlSlice> &slices, const DownloadSink &sink, int copy_threads = 0)
 {
     DownloadStage &g_download = download_for(device);
     std::lock_guard<std::mutex> lock(g_download.mu);
@@ -781,22 +788,52 @@ int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t 
     const int rc = g_download.ensure();
     if (rc) return rc;
     const size_t half = DownloadStage::kHalf;
-    const size_t n_chunks = (bytes + half - 1) / half;
+    struct Part { size_t at; const uint8_t *src; size_t len; int64_t dst_c0; };      // `at`: offset in the half
+    struct Chunk { size_t p0, p1, len; };                                              // parts [p0, p1)
+    std::vector<Part> parts;
+    std::vector<Chunk> chunks;
+    {
+        size_t fill = 0, first = 0;
+        for (const DlSlice &sl : slices) {
+            size_t done_b = 0;
+            while (done_b < sl.bytes) {
+                if (fill == half) { chunks.push_back(Chunk{first, parts.size(), fill}); first = parts.size(); fill = 0; }
+                const size_t take = std::min(sl.bytes - done_b, half - fill);
+                parts.push_back(Part{fill, sl.src + done_b, take, sl.dst_c0 + (int64_t)(done_b / 4)});
+                fill += take;
+                done_b += take;
+            }
+        }
+        if (fill) chunks.push_back(Chunk{first, parts.size(), fill});
+    }
+    const size_t n_chunks = chunks.size();
+    if (n_chunks == 0) return BSIG_OK;
     int n_thr = 8;
     if (const char *e = getenv("BAMSIGNALS_COPY_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    if (copy_threads > 0) n_thr = copy_threads;
     std::atomic<int64_t> ready(-1);                 // chunks 0..ready are in their half
     std::vector<std::atomic<int>> done(n_chunks);   // workers finished with chunk c
     for (auto &d : done) d.store(0);
     std::atomic<bool> abort(false);
+    // thread t's share of chunk c: bytes [len * t / n, len * (t + 1) / n) of the half, cut at 4-byte cells
+    auto share = [&](size_t c, int t) {
+        const Chunk &C = chunks[c];
+        const size_t a = (C.len * (size_t)t / (size_t)n_thr) & ~(size_t)3;
+        const size_t b = t + 1 == n_thr ? C.len : (C.len * (size_t)(t + 1) / (size_t)n_thr) & ~(size_t)3;
+        const uint8_t *buf = g_download.buf[c & 1];
+        for (size_t p = C.p0; p < C.p1 && a < b; ++p) {
+            const Part &P = parts[p];
+            const size_t lo = std::max(a, P.at), hi = std::min(b, P.at + P.len);
+            if (lo < hi) sink(P.dst_c0 + (int64_t)((lo - P.at) / 4), (const int32_t *)(buf + lo), (int64_t)((hi - lo) / 4));
+        }
+    };
     auto worker = [&](int t) {
         for (size_t c = 0; c < n_chunks; ++c) {
             while (ready.load(std::memory_order_acquire) < (int64_t)c) {
                 if (abort.load()) return;
                 std::this_thread::yield();
             }
-            const size_t len = std::min(half, bytes - c * half);
-            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * (size_t)(t + 1) / (size_t)n_thr;
-            if (b > a) memcpy(dst + c * half + a, g_download.buf[c & 1] + a, b - a);
+            share(c, t);
             done[c].fetch_add(1, std::memory_order_release);
         }
     };
@@ -804,8 +841,9 @@ int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t 
     for (int t = 1; t < n_thr; ++t) th.emplace_back(worker, t);
     hipError_t e = hipSuccess;
     auto issue = [&](size_t c) {
-        const size_t len = std::min(half, bytes - c * half);
-        e = hipMemcpyAsync(g_download.buf[c & 1], src_dev + c * half, len, hipMemcpyDeviceToHost, st);
+        const Chunk &C = chunks[c];
+        for (size_t p = C.p0; p < C.p1 && e == hipSuccess; ++p)
+            e = hipMemcpyAsync(g_download.buf[c & 1] + parts[p].at, parts[p].src, parts[p].len, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(g_download.ev[c & 1], st);
     };
     for (size_t c = 0; c < std::min<size_t>(2, n_chunks) && e == hipSuccess; ++c) issue(c);
@@ -813,12 +851,8 @@ int download_staged(int device, hipStream_t st, const uint8_t *src_dev, uint8_t 
         e = hipEventSynchronize(g_download.ev[c & 1]);
         if (e != hipSuccess) break;
         ready.store((int64_t)c, std::memory_order_release);
-        {   // the calling thread is worker 0 of this chunk
-            const size_t len = std::min(half, bytes - c * half);
-            const size_t b = len / (size_t)n_thr;
-            if (b) memcpy(dst + c * half, g_download.buf[c & 1], b);
-            done[c].fetch_add(1, std::memory_order_release);
-        }
+        share(c, 0);                              // the calling thread is worker 0 of this chunk
+        done[c].fetch_add(1, std::memory_order_release);
         while (done[c].load(std::memory_order_acquire) < n_thr) std::this_thread::yield();
         if (c + 2 < n_chunks) issue(c + 2);       // this half is free again
     }
@@ -838,12 +872,75 @@ int bsig::download_to_host(bsig_ctx *ctx, const void *src_dev, void *dst_host, s
 {
     if (bytes == 0) return BSIG_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (bytes >= (8u << 20) && !is_pinned_host(dst_host))
-        return download_staged(ctx->device, ctx->stream, (const uint8_t *)src_dev, (uint8_t *)dst_host, bytes);
+    if (bytes >= (8u << 20) && !is_pinned_host(dst_host) && bytes % 4 == 0) {
+        int32_t *dst = (int32_t *)dst_host;
+        return download_staged(ctx->device, ctx->stream, {DlSlice{(const uint8_t *)src_dev, bytes, 0}},
+                               [dst](int64_t c0, const int32_t *src, int64_t cells) { memcpy(dst + c0, src, (size_t)cells * 4); });
+    }
     hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
     return BSIG_OK;
+}
+
+void bsig::HostDest::put(int64_t c0, const int32_t *src, int64_t count) const
+{
+    if (count <= 0) return;
+    if (flat) { memcpy(flat + c0, src, (size_t)count * sizeof(int32_t)); return; }
+    // the range that holds cell c0: the last i with off[i] <= c0 (empty ranges in between are skipped by the loop)
+    int64_t i = (int64_t)(std::upper_bound(off, off + n + 1, c0) - off) - 1;
+    while (count > 0 && i < n) {
+        const int64_t end = off[i + 1];
+        if (end <= c0) { ++i; continue; }
+        const int64_t take = std::min(count, end - c0);
+        memcpy(ptrs[i] + (c0 - off[i]), src, (size_t)take * sizeof(int32_t));
+        c0 += take; src += take; count -= take;
+        ++i;
+    }
+}
+
+// The result straight into its final place: into one flat buffer, or range by range into the vectors the
+// caller made for them (no flat staging copy of the result in host memory: the reference counts into the R
+// vectors themselves, ref: src/bamsignals.cpp:172-190,361-362).  Large results cross PCIe by DMA into two
+// page-locked halves, and a few threads move each half on -- range by range where the destination is one.
+int bsig::download_to_dest(bsig_ctx *ctx, const int32_t *src_dev, const HostDest &dst, int64_t cells)
+{
+    return download_slice_to_dest(ctx, src_dev, dst, 0, cells, 0);
+}
+
+int bsig::download_slices_to_dest(bsig_ctx *ctx, const int32_t *src_dev, int64_t n_slices, const int64_t *src_c0, const int64_t *dst_c0,
+                                  const int64_t *cells, const HostDest &dst, int copy_threads)
+{
+    std::vector<DlSlice> sl;
+    int64_t total = 0;
+    for (int64_t k = 0; k < n_slices; ++k)
+        if (cells[k] > 0) { sl.push_back(DlSlice{(const uint8_t *)(src_dev + src_c0[k]), (size_t)cells[k] * 4, dst_c0[k]}); total += cells[k]; }
+    if (sl.empty()) return BSIG_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (dst.flat && sl.size() == 1 && copy_threads == 0) return download_to_host(ctx, sl[0].src, dst.flat + sl[0].dst_c0, sl[0].bytes);
+    if ((size_t)total * 4 < (1u << 20)) {
+        // a small result: through a buffer of its own (the runtime stages a copy into pageable memory anyway)
+        std::vector<int32_t> tmp((size_t)total);
+        hipError_t e = hipSuccess;
+        int64_t at = 0;
+        for (const DlSlice &q : sl) {
+            if (e == hipSuccess) e = hipMemcpyAsync(tmp.data() + at, q.src, q.bytes, hipMemcpyDeviceToHost, ctx->stream);
+            at += (int64_t)(q.bytes / 4);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
+        at = 0;
+        for (const DlSlice &q : sl) { dst.put(q.dst_c0, tmp.data() + at, (int64_t)(q.bytes / 4)); at += (int64_t)(q.bytes / 4); }
+        return BSIG_OK;
+    }
+    const HostDest *D = &dst;
+    return download_staged(ctx->device, ctx->stream, sl, [D](int64_t c0, const int32_t *src, int64_t n) { D->put(c0, src, n); }, copy_threads);
+}
+
+int bsig::download_slice_to_dest(bsig_ctx *ctx, const int32_t *src_dev, const HostDest &dst, int64_t c0, int64_t cells, int copy_threads)
+{
+    const int64_t zero = 0;
+    return download_slices_to_dest(ctx, src_dev, 1, &zero, &c0, &cells, dst, copy_threads);
 }
 
 extern "C" {
@@ -1421,7 +1518,7 @@ int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
     if (rc != BSIG_OK) return rc;
     const size_t bytes = (size_t)cells * sizeof(int32_t);
     if (bytes >= (8u << 20) && !is_pinned_host(out_host))
-        return download_staged(p->ctx->device, p->ctx->stream, (const uint8_t *)p->d_out, (uint8_t *)out_host, bytes);
+        return bsig::download_to_host(p->ctx, p->d_out, out_host, bytes);
     hipError_t e = hipMemcpyAsync(out_host, p->d_out, bytes, hipMemcpyDeviceToHost, p->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
     if (e != hipSuccess) rc = fail(BSIG_ERR_DEVICE, "result download failed: %s", hipGetErrorString(e));
@@ -1429,14 +1526,14 @@ int bsig_plan_run_host(bsig_plan *p, int32_t *out_host)
 }
 
 }  // extern "C"
-int bsig::plan_run_host_timed(bsig_plan *p, int32_t *out_host, double *t_kernels, double *t_download)
+int bsig::plan_run_host_timed(bsig_plan *p, const HostDest &dst, double *t_kernels, double *t_download)
 {
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     if (!p) return fail(BSIG_ERR_ARG, "plan is NULL");
     const int64_t cells = p->off.back();
     if (cells == 0) return BSIG_OK;
-    if (!out_host) return fail(BSIG_ERR_ARG, "output buffer is NULL");
+    if (!dst.flat && !dst.ptrs) return fail(BSIG_ERR_ARG, "output buffer is NULL");
     HIP_TRY(hipSetDevice(p->ctx->device));
     if (!p->d_out) HIP_TRY(p->pool.alloc(&p->d_out, (size_t)cells));
     int rc = bsig_plan_run(p, p->d_out);
@@ -1444,7 +1541,7 @@ int bsig::plan_run_host_timed(bsig_plan *p, int32_t *out_host, double *t_kernels
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     *t_kernels = since(t0);
     const auto t1 = std::chrono::steady_clock::now();
-    rc = bsig::download_to_host(p->ctx, p->d_out, out_host, (size_t)cells * sizeof(int32_t));
+    rc = bsig::download_to_dest(p->ctx, p->d_out, dst, cells);
     *t_download = since(t1);
     return rc;
 }

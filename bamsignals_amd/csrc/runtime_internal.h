@@ -193,7 +193,27 @@ int reads_from_regions_sharded(const std::vector<bsig_ctx *> &ctxs, const std::s
 // a device buffer to (pageable or page-locked) host memory, staged through page-locked halves where
 // that is faster (runtime.hip)
 int download_to_host(bsig_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes);
+// Where a call's result goes in host memory: ONE flat buffer (range i at flat + off[i]), or one destination per
+// range (ptrs[i]: the payload of the R vector allocateList made for range i, ref: src/bamsignals.cpp:172-190).
+// `off` (n + 1 entries) is the flat layout either way.
+struct HostDest {
+    int32_t *flat = nullptr;
+    int32_t *const *ptrs = nullptr;
+    const int64_t *off = nullptr;
+    int64_t n = 0;
+    int32_t *range(int64_t i) const { return flat ? flat + off[i] : ptrs[i]; }
+    // cells [c0, c0 + count) of the flat layout, wherever their ranges live
+    void put(int64_t c0, const int32_t *src, int64_t count) const;
+};
+// a device buffer of `cells` int32 in the flat layout to the destination (runtime.hip)
+int download_to_dest(bsig_ctx *ctx, const int32_t *src_dev, const HostDest &dst, int64_t cells);
+// ... a slice of the result: `cells` int32 at src_dev belong at cell dst_cell0 of the flat layout.  copy_threads
+// host threads move the page-locked halves on (0: the default, env BAMSIGNALS_COPY_THREADS)
+int download_slice_to_dest(bsig_ctx *ctx, const int32_t *src_dev, const HostDest &dst, int64_t dst_cell0, int64_t cells, int copy_threads);
+// ... several slices as ONE pipelined stream: slice k = cells[k] int32 at src_dev + src_c0[k], bound for cell dst_c0[k]
+int download_slices_to_dest(bsig_ctx *ctx, const int32_t *src_dev, int64_t n_slices, const int64_t *src_c0, const int64_t *dst_c0,
+                            const int64_t *cells, const HostDest &dst, int copy_threads);
 // bsig_plan_run_host with the kernels' and the download's seconds told apart (runtime.hip)
-int plan_run_host_timed(bsig_plan *p, int32_t *out_host, double *t_kernels, double *t_download);
+int plan_run_host_timed(bsig_plan *p, const HostDest &dst, double *t_kernels, double *t_download);
 }  // namespace bsig
 #endif

@@ -112,8 +112,11 @@ static SEXP int_matrix2(R_xlen_t ncol, SEXP dimnames)
     return m;
 }
 
-/* flat result -> list of vectors / 2 x w matrices, element i <-> range i (ref :172-190) */
-static SEXP wrap_signals(const int32_t *flat, const int64_t *off, R_xlen_t n, int ss)
+/* allocateList (ref: src/bamsignals.cpp:139-192): the list of per-range vectors / 2 x w matrices, made BEFORE
+ * the counting, element i <-> range i; dst[i] = the payload of element i (where the native side counts into, as
+ * the reference's GArray.array does, ref :164,181,186).  R zero-initialises nothing: the native side writes every
+ * cell of every element. */
+static SEXP alloc_signals(const int64_t *off, R_xlen_t n, int ss, int32_t **dst)
 {
     SEXP res = PROTECT(Rf_allocVector(VECSXP, n));
     SEXP dn = PROTECT(ss ? sense_dimnames() : R_NilValue);
@@ -121,7 +124,7 @@ static SEXP wrap_signals(const int32_t *flat, const int64_t *off, R_xlen_t n, in
         const int64_t cells = off[i + 1] - off[i];
         SEXP v = ss ? int_matrix2(cells / 2, dn) : Rf_allocVector(INTSXP, cells);
         SET_VECTOR_ELT(res, i, v);
-        if (cells) memcpy(INTEGER(v), flat + off[i], (size_t)cells * sizeof(int32_t));
+        dst[i] = cells ? INTEGER(v) : NULL;
     }
     UNPROTECT(2);
     return res;
@@ -152,25 +155,29 @@ SEXP bamsignals_pileup_core(SEXP bampath, SEXP gr, SEXP tlen_filter, SEXP mapqua
     int ntf;
     int32_t *tf = tlen_vec(tlen_filter, &ntf, &keep);
     int64_t *off = (int64_t *)R_alloc((size_t)f.n + 1, sizeof(int64_t));
-    const int64_t cells = bsig_layout(f.n, f.width, bs, strand_specific, off);
-    /* R_alloc'ed: released by R when the .Call returns, also on an R error (no leak on longjmp) */
-    int32_t *flat = (int32_t *)R_alloc((size_t)(cells > 0 ? cells : 1), sizeof(int32_t));
-    const int rc = bsig_pileup_core(path, f.n, f.seq_code, f.n_levels, f.levels,
-                                    f.start, f.width, f.strand, tf, ntf, int_arg(mapqual, "mapqual"), bs,
-                                    int_arg(shift, "shift"), strand_specific, int_arg(requiredF, "requiredF"),
-                                    int_arg(filteredF, "filteredF"), mid,
-                                    int_arg(maxgap, "maxgap"), -1, flat, off);
-    if (rc != BSIG_OK) Rf_error("%s", bsig_last_error());
+    bsig_layout(f.n, f.width, bs, strand_specific, off);
+    /* the result is allocated first and counted into in place (ref: allocateList, then the pileup, :451-459): one
+     * copy of the result in host memory, no flat staging buffer.  The list stays protected across the native call;
+     * on an error Rf_error unwinds and R collects it. */
     SEXP res;
+    int32_t **dst;
     if (bs <= 0) {                                    /* bamCount: list(vector) or list(2 x n) (ref :148-169) */
         res = PROTECT(Rf_allocVector(VECSXP, 1));
         SEXP v = strand_specific ? int_matrix2(f.n, PROTECT(sense_dimnames())) : Rf_allocVector(INTSXP, f.n);
         SET_VECTOR_ELT(res, 0, v);
         if (strand_specific) UNPROTECT(1);
-        if (cells) memcpy(INTEGER(v), flat, (size_t)cells * sizeof(int32_t));
+        dst = (int32_t **)R_alloc(1, sizeof(int32_t *));
+        dst[0] = INTEGER(v);
     } else {
-        res = PROTECT(wrap_signals(flat, off, f.n, strand_specific));
+        dst = (int32_t **)R_alloc((size_t)f.n + 1, sizeof(int32_t *));
+        res = PROTECT(alloc_signals(off, f.n, strand_specific, dst));
     }
+    const int rc = bsig_pileup_core_into(path, f.n, f.seq_code, f.n_levels, f.levels,
+                                         f.start, f.width, f.strand, tf, ntf, int_arg(mapqual, "mapqual"), bs,
+                                         int_arg(shift, "shift"), strand_specific, int_arg(requiredF, "requiredF"),
+                                         int_arg(filteredF, "filteredF"), mid,
+                                         int_arg(maxgap, "maxgap"), -1, dst);
+    if (rc != BSIG_OK) Rf_error("%s", bsig_last_error());
     UNPROTECT(2);
     return res;
 }
@@ -186,15 +193,14 @@ SEXP bamsignals_coverage_core(SEXP bampath, SEXP gr, SEXP tlen_filter, SEXP mapq
     int ntf;
     int32_t *tf = tlen_vec(tlen_filter, &ntf, &keep);
     int64_t *off = (int64_t *)R_alloc((size_t)f.n + 1, sizeof(int64_t));
-    const int64_t cells = bsig_layout(f.n, f.width, 1, 0, off);
-    /* R_alloc'ed: released by R when the .Call returns, also on an R error (no leak on longjmp) */
-    int32_t *flat = (int32_t *)R_alloc((size_t)(cells > 0 ? cells : 1), sizeof(int32_t));
-    const int rc = bsig_coverage_core(path, f.n, f.seq_code, f.n_levels, f.levels,
-                                      f.start, f.width, f.strand, tf, ntf, int_arg(mapqual, "mapqual"),
-                                      int_arg(requiredF, "requiredF"), int_arg(filteredF, "filteredF"),
-                                      span, int_arg(maxgap, "maxgap"), -1, flat, off);
+    bsig_layout(f.n, f.width, 1, 0, off);
+    int32_t **dst = (int32_t **)R_alloc((size_t)f.n + 1, sizeof(int32_t *));
+    SEXP res = PROTECT(alloc_signals(off, f.n, 0, dst));      /* allocated first, counted into in place (ref :481-492) */
+    const int rc = bsig_coverage_core_into(path, f.n, f.seq_code, f.n_levels, f.levels,
+                                           f.start, f.width, f.strand, tf, ntf, int_arg(mapqual, "mapqual"),
+                                           int_arg(requiredF, "requiredF"), int_arg(filteredF, "filteredF"),
+                                           span, int_arg(maxgap, "maxgap"), -1, dst);
     if (rc != BSIG_OK) Rf_error("%s", bsig_last_error());
-    SEXP res = PROTECT(wrap_signals(flat, off, f.n, 0));
     UNPROTECT(2);
     return res;
 }

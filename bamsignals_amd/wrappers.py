@@ -144,6 +144,57 @@ def coverage_core(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1
     return _split(out, off, False)
 
 
+def _alloc_signals(width, binsize, ss):
+    """allocateList (ref: src/bamsignals.cpp:139-192): the per-range vectors / 2 x w matrices, made before the
+    counting; returns (list as the caller sees it, the arrays the native side writes into)."""
+    mult = 2 if ss else 1
+    if binsize <= 0:
+        v = np.empty(len(width) * mult, dtype=np.int32)
+        return [v.reshape(-1, 2).T if ss else v], [v]
+    cells = [0 if w <= 0 else mult * ((int(w) + binsize - 1) // binsize) for w in width]
+    vs = [np.empty(c, dtype=np.int32) for c in cells]
+    return [v.reshape(-1, 2).T if ss else v for v in vs], vs
+
+
+def _dest_pointers(vs):
+    return (C.c_void_p * max(len(vs), 1))(*[v.ctypes.data if v.size else None for v in vs])
+
+
+def pileup_core_into(bampath, gr, tlen_filter, mapqual=0, binsize=1, shift=0, ss=False, requiredF=0,
+                     filteredF=-1, pe_mid=False, maxgap=16385, device=None):
+    """pileup_core with the result delivered in place (bsig_pileup_core_into, what the R shim binds): the
+    per-range arrays are allocated first, as allocateList does, and the native side writes straight into them."""
+    _check_gr(gr)
+    lib = _lib.load()
+    levels, codes, start, width, strand = gr.flatten()
+    out, vs = _alloc_signals(width, int(binsize), bool(ss))
+    tf = np.asarray([int(x) for x in tlen_filter], dtype=np.int32)
+    names = (C.c_char_p * max(len(levels), 1))(*[s.encode() for s in levels])
+    _lib.check(lib.bsig_pileup_core_into(os.path.expanduser(str(bampath)).encode(), len(gr), codes.ctypes.data, len(levels),
+                                         names, start.ctypes.data, width.ctypes.data, strand.ctypes.data,
+                                         tf.ctypes.data, len(tf), int(mapqual), int(binsize), int(shift),
+                                         int(bool(ss)), int(requiredF), int(filteredF), int(bool(pe_mid)),
+                                         int(maxgap), _dev(device), _dest_pointers(vs)))
+    return out
+
+
+def coverage_core_into(bampath, gr, tlen_filter, mapqual=0, requiredF=0, filteredF=-1, tspan=False,
+                       maxgap=16385, device=None):
+    """coverage_core with the result delivered in place (bsig_coverage_core_into)."""
+    _check_gr(gr)
+    lib = _lib.load()
+    levels, codes, start, width, strand = gr.flatten()
+    out, vs = _alloc_signals(width, 1, False)
+    tf = np.asarray([int(x) for x in tlen_filter], dtype=np.int32)
+    names = (C.c_char_p * max(len(levels), 1))(*[s.encode() for s in levels])
+    _lib.check(lib.bsig_coverage_core_into(os.path.expanduser(str(bampath)).encode(), len(gr), codes.ctypes.data,
+                                           len(levels), names, start.ctypes.data, width.ctypes.data,
+                                           strand.ctypes.data, tf.ctypes.data, len(tf), int(mapqual),
+                                           int(requiredF), int(filteredF), int(bool(tspan)), int(maxgap),
+                                           _dev(device), _dest_pointers(vs)))
+    return out
+
+
 def last_call_timing():
     """Stage seconds of this thread's last bamCount/bamProfile/bamCoverage call, and where the stages' time went
     (``alloc_*``: seconds inside the driver's allocator -- hipMalloc, hipFree, hipHostMalloc -- metered per

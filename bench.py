@@ -721,11 +721,14 @@ def in_process_block(a, world, ngpu, cols, cfg, rg, want_flat):
         want = result_fingerprint(want_flat)
         call = dict(tlen_filter=(), device=-1)
         env = {"BAMSIGNALS_DEVICES": devices, "BAMSIGNALS_DECODE": "all", "BAMSIGNALS_GATHER": "xgmi"}
-        kinds = ["cold", "warm", "warm", "warm", "warm", "warm", "warm"]
-        gathers = ["xgmi", "xgmi", "xgmi", "direct", "direct", "pcie", "pcie"]
+        # ("auto": no request -- what the library picks by itself; the strong block's ranges come in random order, so a
+        # second pair of calls passes them sorted, as a tiling or a sorted peak list would be: "auto_sorted", "blocks")
+        kinds = ["cold", "warm", "warm", "warm", "warm", "warm", "warm", "warm", "warm", "warm"]
+        gathers = ["xgmi", "xgmi", "xgmi", "direct", "direct", "pcie", "pcie", "blocks", "blocks", "auto"]
         try:
             child, _ = cold_call_in_fresh_process(d, "inproc", bam, names, rg, call, -1, env=env, reps=len(kinds),
-                                                  per_rep_env=[{"BAMSIGNALS_GATHER": g} for g in gathers], want_result=False, timeout=240)
+                                                  per_rep_env=[{"BAMSIGNALS_GATHER": "" if g == "auto" else g} for g in gathers], want_result=False,
+                                                  timeout=240)
         except subprocess.TimeoutExpired:
             out["error"] = "the in-process session did not finish within 240 s and was stopped"
             return out
@@ -1032,7 +1035,7 @@ def main():
                         slots = a.in_process_slots or world
                         res["in_process"] = in_process_block(a, slots, ngpu, cols5, c5, rg5, want5)
                         log("in_process: " + "; ".join(f"{g} " + "/".join(f"{r['call_s']:.3f}" for r in res["in_process"][g])
-                                                        for g in ("xgmi", "direct", "pcie")))
+                                                        for g in ("xgmi", "direct", "pcie", "blocks", "auto") if g in res["in_process"]))
                     except SystemExit:
                         raise
                     except Exception as exc:

@@ -292,6 +292,26 @@ int bsig_coverage_core(const char *bampath, int64_t n_ranges, const int32_t *seq
                        const int32_t *tlen_filter, int32_t n_tlen_filter,
                        int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
                        int32_t maxgap, int32_t device, int32_t *out, const int64_t *off);
+/* The same two calls with the result delivered IN PLACE, as the reference delivers it: allocateList (ref:
+ * src/bamsignals.cpp:139-192) makes the R vectors first and the pileup counts straight into them (:361-362,
+ * :423-436) -- ONE copy of the result in host memory.  dst[i] = where range i's cells go (the payload of its
+ * vector / 2 x width matrix: (off[i+1] - off[i]) int32 of bsig_layout(); never touched for an empty range);
+ * bamCount's layout (binsize <= 0) is one vector: dst[0] receives the n (ss: 2 x n) counts.  Large results
+ * cross PCIe by DMA into two page-locked halves and are moved on range by range by a few threads: no flat
+ * staging copy of the result exists in host memory.                                                     */
+int bsig_pileup_core_into(const char *bampath, int64_t n_ranges, const int32_t *seq_code,
+                          int32_t n_seq_levels, const char *const *seq_levels, const int32_t *start,
+                          const int32_t *width, const int32_t *strand,
+                          const int32_t *tlen_filter, int32_t n_tlen_filter,
+                          int32_t mapqual, int32_t binsize, int32_t shift, int32_t ss,
+                          int32_t requiredF, int32_t filteredF, int32_t pe_mid, int32_t maxgap,
+                          int32_t device, int32_t *const *dst);
+int bsig_coverage_core_into(const char *bampath, int64_t n_ranges, const int32_t *seq_code,
+                            int32_t n_seq_levels, const char *const *seq_levels, const int32_t *start,
+                            const int32_t *width, const int32_t *strand,
+                            const int32_t *tlen_filter, int32_t n_tlen_filter,
+                            int32_t mapqual, int32_t requiredF, int32_t filteredF, int32_t tspan,
+                            int32_t maxgap, int32_t device, int32_t *const *dst);
 /* replaces bamsignals_writeSamAsBamAndIndex (ref: src/bamsignals.cpp:496-534): text SAM ->
  * BAM + <bampath>.bai                                                                          */
 int bsig_write_sam_as_bam_and_index(const char *sampath, const char *bampath);

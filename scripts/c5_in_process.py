@@ -29,22 +29,28 @@ bam = "/tmp/c5_synth.bam"
 t = time.time(); write_columns_as_bam(bam, names, cols, level=1); print("write", round(time.time() - t, 1), os.path.getsize(bam), flush=True)
 cols.pop("cigar"); cols.pop("cigar_off")
 rg = synth_ranges(n_ranges, 1000, HG38, seed=0xC6)
+if os.environ.get("C5_SORTED", "1") != "0":
+    # the caller's ranges in (chromosome, start) order, as a tiling or a sorted peak list comes: the order in which
+    # every block of the sharding is one contiguous slice of the result ("blocks")
+    o = np.lexsort((rg["loc"], rg["rid"]))
+    rg = {k: v[o] for k, v in rg.items()}
 t = time.time()
 gr = GRanges([names[r] for r in rg["rid"]], rg["loc"] + 1, width=rg["len"], strand=[{1: "+", -1: "-", 0: "*"}[int(s)] for s in rg["strand"]])
 print("GRanges", round(time.time() - t, 1), flush=True)
 os.environ["BAMSIGNALS_DEVICES"] = ",".join(["0"] * slots)
 os.environ["BAMSIGNALS_DECODE"] = "all"
 res = {}
-for gather in ("xgmi", "pcie"):          # (same-device slots: "xgmi" = the first GPU reads the shards in place)
+want = None
+for gather in ("xgmi", "pcie", "blocks", ""):   # (same-device slots: "xgmi" = the first GPU reads the shards in place; "": the library's own choice)
     os.environ["BAMSIGNALS_GATHER"] = gather
-    for rep in ("cold", "resident", "resident"):
+    for rep in (("cold", "resident", "resident") if gather == "xgmi" else ("resident", "resident")):
         if rep == "cold":
             _lib.load().bsig_cache_clear()
         t = time.time(); sig = bamProfile(bam, gr, verbose=False); dt = time.time() - t
         print(gather, rep, round(dt, 3), "s", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last_call_timing().items()}, "|", last_call_route(), flush=True)
         res[gather] = sig
     flat = np.concatenate(res[gather].as_list())
-    if gather == "xgmi":
+    if want is None:
         t = time.time()
         orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
         want, _ = oracle_c.pileup_core(orc, rg, binsize=1)

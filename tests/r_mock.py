@@ -47,11 +47,18 @@ class MockR:
             ("mock_call", P, [C.c_char_p, C.POINTER(P), C.c_int, C.POINTER(C.c_int)]), ("mock_init", None, []),
             ("mock_n_registered", C.c_int, []), ("mock_registered_name", C.c_char_p, [C.c_int]),
             ("mock_registered_arity", C.c_int, [C.c_int]), ("mock_dynamic_symbols", C.c_int, []),
+            ("mock_last_call_bytes", None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         ):
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         L.mock_init()
         self.nil = L.mock_nil()
+
+    def last_call_bytes(self):
+        """(payload bytes of the vectors the last .Call allocated, bytes it took from R_alloc)"""
+        v, r = C.c_longlong(0), C.c_longlong(0)
+        self.L.mock_last_call_bytes(C.byref(v), C.byref(r))
+        return v.value, r.value
 
     # ---- building R objects -------------------------------------------------------------------
     def int(self, v):

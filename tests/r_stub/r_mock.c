@@ -48,6 +48,9 @@ static char err_msg[2048];
 static void *arena[65536];
 static int n_arena = 0;
 static int n_poisoned_total = 0;
+/* payload bytes of the vectors allocated during the current / last .Call, and the bytes it took from R_alloc:
+ * tests check that a result is held ONCE (the vectors) and not a second time in a flat staging buffer */
+static long long call_vec_bytes = 0, call_ralloc_bytes = 0;
 
 static void die(const char *why)
 {
@@ -97,6 +100,7 @@ static SEXP new_obj(int type, R_xlen_t len, size_t elt)
     o->type = type;
     o->len = len;
     o->data = calloc((size_t)(len > 0 ? len : 1), elt ? elt : 1);
+    if (in_call && (type == INTSXP || type == REALSXP || type == LGLSXP)) call_vec_bytes += (long long)(len > 0 ? len : 0) * (long long)elt;
     o->epoch = in_call ? cur_epoch : 0;
     o->all_next = all_objs;
     all_objs = o;
@@ -290,6 +294,7 @@ char *R_alloc(size_t n, int size)
 {
     if (n_arena >= 65536) die("too many R_alloc blocks");
     void *p = calloc(n ? n : 1, (size_t)(size > 0 ? size : 1));
+    call_ralloc_bytes += (long long)n * (long long)(size > 0 ? size : 1);
     arena[n_arena++] = p;
     return (char *)p;
 }
@@ -349,6 +354,7 @@ SEXP mock_list_get(SEXP x, R_xlen_t i) { return ((SEXP *)x->data)[i]; }
 const char *mock_string(SEXP x, R_xlen_t i) { return (const char *)((SEXP *)x->data)[i]->data; }
 const char *mock_error(void) { return err_msg; }
 int mock_protect_depth(void) { return ptop; }
+void mock_last_call_bytes(long long *vectors, long long *r_alloc) { *vectors = call_vec_bytes; *r_alloc = call_ralloc_bytes; }
 int mock_poisoned(void) { return n_poisoned_total; }
 
 /* Runs the registered routine `name` on args; returns its value, or NULL after an R error (1) or a
@@ -360,6 +366,7 @@ SEXP mock_call(const char *name, SEXP *args, int n_args, int *status)
 {
     *status = 0;
     err_msg[0] = 0;
+    call_vec_bytes = call_ralloc_bytes = 0;
     const R_CallMethodDef *m = NULL;
     for (int i = 0; registered && registered[i].name; ++i)
         if (!strcmp(registered[i].name, name)) m = &registered[i];

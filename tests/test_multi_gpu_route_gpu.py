@@ -144,7 +144,10 @@ def _want(cols, rg):
             oracle_c.coverage_core(orc, rg, mapqual=5)[0])
 
 
-@pytest.mark.parametrize("gather", ["xgmi", "copy", "pcie"])
+ROUTE_OF = {"xgmi": "result: xgmi/direct", "copy": "result: xgmi/peer", "pcie": "result: pcie (", "blocks": "result: pcie/blocks"}
+
+
+@pytest.mark.parametrize("gather", ["xgmi", "copy", "pcie", "blocks"])
 @pytest.mark.parametrize("devices", ["0,0,0", "0,0,0,0,0,0,0,0"])
 def test_file_level_route_over_several_slots(synth_bam, devices, gather, monkeypatch):
     from bamsignals_amd import _lib
@@ -166,9 +169,17 @@ def test_file_level_route_over_several_slots(synth_bam, devices, gather, monkeyp
         assert route.startswith("%d GPU slot(s); reads: resident" % len(devices.split(",")))
         # same-device slots: the first GPU reads the shard buffers in place ("direct"); "copy" forces the
         # gather into a receive buffer (what RCCL does with distinct GPUs), here with peer copies
-        assert {"xgmi": "result: xgmi/direct", "copy": "result: xgmi/peer", "pcie": "result: pcie"}[gather] in route, route
+        assert ROUTE_OF[gather] in route, route
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
+        # ... and delivered in place, range by range (bsig_*_core_into: what the R shim binds), over the same route
+        from bamsignals_amd.wrappers import coverage_core_into, pileup_core_into
+        p_in = pileup_core_into(bam, gr, (), binsize=1, ss=True, shift=33)
+        c_in = pileup_core_into(bam, gr, (30, 700), binsize=-1, pe_mid=True, requiredF=66)
+        v_in = coverage_core_into(bam, gr, (), mapqual=5)
+        assert ROUTE_OF[gather] in last_call_route()
+        assert np.array_equal(np.concatenate([m.T.reshape(-1) for m in p_in]), want[0])
+        assert np.array_equal(c_in[0], want[1]) and np.array_equal(np.concatenate(v_in), want[2])
         # a call on a resident BAM with shapes seen before allocates nothing for the result path
         before = _lib.load().bsig_debug_scratch_allocs()
         assert before > 0
@@ -373,7 +384,55 @@ def test_concurrent_host_threads(synth_bam, tmp_path, monkeypatch):
         _lib.load().bsig_cache_clear()
 
 
-@pytest.mark.parametrize("gather", ["xgmi", "pcie"])
+def test_sorted_ranges_leave_in_contiguous_slices(synth_bam, monkeypatch):
+    """The (rid, loc)-sorted ranges are dealt to the GPUs in blocks of consecutive ranges (ref: each range owns its
+    output, src/bamsignals.cpp:164,181,186; sorted as :246 sorts them).  A caller whose ranges ARE in that order -- a
+    tiling, sorted peaks -- owns, per block, one contiguous slice of the result: with a large result the library then
+    lets every GPU download its slices over its own PCIe link straight into place ("pcie/blocks": no gather, no
+    reassembly) without being asked; ranges in any other order keep the gather on the first GPU."""
+    from bamsignals_amd import GRanges, _lib, bamCoverage, bamProfile
+    from bamsignals_amd.wrappers import last_call_route, pileup_core_into
+    bam, names, ref_len, cols, rg, gr = synth_bam
+    # 2-kb tiles over all five references, every 500 bp: 4,840 ranges, 77 MB strand-split
+    chrom, start = [], []
+    for nm, ln in zip(names, ref_len):
+        s0 = np.arange(1, ln - 2000, 500)
+        chrom += [nm] * len(s0); start += s0.tolist()
+    tiles = GRanges(chrom, start, width=2000, strand=["+", "-", "*", "+"] * (len(start) // 4) + ["+"] * (len(start) % 4))
+    monkeypatch.setenv("BAMSIGNALS_DECODE", "all")
+    monkeypatch.setenv("BAMSIGNALS_DEVICES", "0")
+    _lib.load().bsig_cache_clear()
+    try:
+        want = np.concatenate([m.T.reshape(-1) for m in bamProfile(bam, tiles, ss=True, shift=-20, verbose=False)])
+        want_cov = np.concatenate(bamCoverage(bam, tiles[list(range(1000))], verbose=False).as_list())
+        monkeypatch.setenv("BAMSIGNALS_DEVICES", "0,0,0,0,0")
+        monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "2")
+        got = np.concatenate([m.T.reshape(-1) for m in bamProfile(bam, tiles, ss=True, shift=-20, verbose=False)])
+        route = last_call_route()
+        assert "result: pcie/blocks" in route and np.array_equal(got, want), route
+        n_slices = int(route.split("download in ")[1].split(" slices")[0])
+        assert n_slices <= len(tiles) // 64                      # blocks of consecutive ranges, not single ranges
+        got = np.concatenate([m.T.reshape(-1) for m in pileup_core_into(bam, tiles, (), binsize=1, ss=True, shift=-20)])
+        assert "result: pcie/blocks" in last_call_route() and np.array_equal(got, want)
+        # a small result, or ranges out of order: the gather on the first GPU
+        got = np.concatenate(bamCoverage(bam, tiles[list(range(1000))], verbose=False).as_list())
+        assert "result: xgmi/" in last_call_route() and np.array_equal(got, want_cov)
+        perm = np.random.default_rng(4).permutation(len(tiles))
+        got = bamProfile(bam, tiles[perm.tolist()], ss=True, shift=-20, verbose=False)
+        assert "result: xgmi/" in last_call_route()
+        back = np.empty_like(want).reshape(len(tiles), -1)
+        for k, i in enumerate(perm):
+            back[i] = got[k].T.reshape(-1)
+        assert np.array_equal(back.reshape(-1), want)
+        # range by range (the round-robin of rounds 1-3) on request
+        monkeypatch.setenv("BAMSIGNALS_SHARD_BLOCK", "1")
+        got = np.concatenate([m.T.reshape(-1) for m in bamProfile(bam, tiles, ss=True, shift=-20, verbose=False)])
+        assert "result: xgmi/" in last_call_route() and np.array_equal(got, want)
+    finally:
+        _lib.load().bsig_cache_clear()
+
+
+@pytest.mark.parametrize("gather", ["xgmi", "pcie", "blocks"])
 def test_fewer_ranges_than_slots(synth_bam, gather, monkeypatch):
     """No range at all, one range, and one zero-width range over four slots: empty shards everywhere."""
     from bamsignals_amd import GRanges, _lib, bamCount, bamCoverage, bamProfile

@@ -94,3 +94,45 @@ def test_rle_runs_zero_width_and_binned(R, gr):
     assert len(out) == len(g2) and out[3].shape == (2, 0)
     for a, b in zip(out, want):
         assert np.array_equal(a, b)
+
+
+def test_the_result_is_held_once(R, gr, expected_grid):
+    """The reference allocates the R vectors first (allocateList, ref: src/bamsignals.cpp:139-192) and counts straight
+    into them: one copy of the result in host memory.  So does the shim (bsig_pileup_core_into /
+    bsig_coverage_core_into): the vectors of a call add up to the result, and what the call takes from R_alloc is
+    the offsets and the destination pointers -- no flat staging buffer the size of the result."""
+    from bamsignals_amd import GRanges
+    g = R.granges(gr, seq_levels=["chr1", "chr3", "chr2"])
+    n = len(gr)
+    width = int(np.sum(gr.width))
+    for ss in (False, True):
+        key = f"profile|shift=0,mapq=0,ss={int(ss)},pe=ignore,tf=NULL"
+        a = core_args("profile", parse_key(key)[1])
+        res = R.call("bamsignals_pileup_core", *_pileup_args(R, g, a))
+        vec, ralloc = R.last_call_bytes()
+        cells = width * (2 if ss else 1)
+        assert 4 * cells <= vec <= 4 * cells + 16 * n + 4096, (ss, vec, cells)       # (+ dims, dimnames, the coerced tlen filter)
+        assert ralloc <= 64 * (n + 2) and ralloc < vec // 20, (ss, ralloc, vec)
+        out = R.to_py(res)
+        flat = np.concatenate([v.T.reshape(-1) for v in out]) if ss else np.concatenate(out)
+        assert np.array_equal(flat, expected_grid[key])
+    res = R.call("bamsignals_coverage_core", R.str(BAM), g, R.int([]), R.int([0]), R.int([0]), R.int([-1]), R.lgl(False), R.int([16385]))
+    vec, ralloc = R.last_call_bytes()
+    assert 4 * width <= vec <= 4 * width + 4096 and ralloc <= 64 * (n + 2)
+    assert np.array_equal(np.concatenate(R.to_py(res)), expected_grid["coverage|mapq=0,pe=ignore,tf=NULL"])
+    # a large result takes the staged route (page-locked halves, several threads moving them on range by range):
+    # 6,000 x 3 kb ranges tiled over the fixture's three references = 72 MB, compared with the Python host's call
+    from bamsignals_amd import bamProfile
+    rng = np.random.default_rng(8)
+    m = 6000
+    chrom = rng.choice(["chr1", "chr2", "chr3"], m)
+    big = GRanges(list(chrom), rng.integers(1, 7000, m), width=np.where(np.arange(m) % 97 == 0, 0, 3000), strand=list(rng.choice(["+", "-", "*"], m)))
+    res = R.call("bamsignals_pileup_core", R.str(BAM), R.granges(big, seq_levels=["chr1", "chr3", "chr2"]), R.int([]), R.int([0]), R.int([1]),
+                 R.int([0]), R.lgl(True), R.int([0]), R.int([-1]), R.lgl(False), R.int([16385]))
+    vec, ralloc = R.last_call_bytes()
+    cells = 2 * int(np.sum(big.width))
+    assert 4 * cells <= vec <= 4 * cells + 16 * m + 4096 and ralloc <= 64 * (m + 2) and 4 * cells > (64 << 20)
+    want = bamProfile(BAM, big, ss=True, verbose=False)
+    for a_, b_ in zip(R.to_py(res), want):
+        assert np.array_equal(a_, b_)
+    assert R.L.mock_protect_depth() == 0
