@@ -356,21 +356,69 @@ struct MappedFile {
     {
         // Tearing down the page tables of a large populated mapping takes as long as filling them (70 ms for
         // the north star's 3-GB file, measured as the difference between the call and its decode stages):
-        // nobody waits for that -- a detached thread unmaps.
+        // nobody waits for that -- the library's unmap thread does it (Unmapper below: ONE thread, joined when
+        // the library is unloaded; a detached thread could still be running this code when R's dyn.unload or a
+        // dlclose takes the text away).
         void *p = (void *)data;
         const size_t n = size;
         const int f = fd;
-        if (p && n >= ((size_t)64 << 20)) {
-            try {
-                std::thread([p, n, f] { munmap(p, n); if (f >= 0) ::close(f); }).detach();
-                return;
-            } catch (const std::system_error &) {
-            }
-        }
+        if (p && n >= ((size_t)64 << 20) && unmap_later(p, n, f)) return;
         if (p) munmap(p, n);
         if (f >= 0) ::close(f);
     }
+    static bool unmap_later(void *p, size_t n, int f);
 };
+
+// the mappings handed over for unmapping, and the one thread that works them off; its destructor (static: run at
+// exit and when the shared object is unloaded) finishes the queue and joins the thread
+struct Unmapper {
+    struct Job { void *p; size_t n; int fd; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Job> jobs;
+    bool quit = false, started = false;
+    std::thread th;
+    bool push(void *p, size_t n, int fd)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (quit) return false;
+        if (!started) {
+            try { th = std::thread([this] { run(); }); } catch (const std::system_error &) { return false; }
+            started = true;
+        }
+        jobs.push_back(Job{p, n, fd});
+        cv.notify_one();
+        return true;
+    }
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return quit || !jobs.empty(); });
+            if (jobs.empty()) return;                    // (quit: only once the queue is empty)
+            const Job j = jobs.back();
+            jobs.pop_back();
+            lk.unlock();
+            munmap(j.p, j.n);
+            if (j.fd >= 0) ::close(j.fd);
+            lk.lock();
+        }
+    }
+    ~Unmapper()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_one();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+bool MappedFile::unmap_later(void *p, size_t n, int f)
+{
+    static Unmapper u;
+    return u.push(p, n, f);
+}
 
 using Block = BgzfBlock;
 
@@ -1414,7 +1462,7 @@ int csi_load(const std::string &csi_path, BaiIndex &idx)
         int got;
         while ((got = gzread(g, buf, sizeof buf)) > 0) {
             d.insert(d.end(), buf, buf + got);
-            if (d.size() > (4ull << 30)) break;
+            if (d.size() > (1ull << 30)) { gzclose(g); return fail(BSIG_ERR_FORMAT, "%s: CSI index larger than 1 GB", csi_path.c_str()); }
         }
         gzclose(g);
         if (got < 0) return fail(BSIG_ERR_FORMAT, "%s is not a CSI index (inflate failed)", csi_path.c_str());
@@ -1458,21 +1506,8 @@ int csi_load(const std::string &csi_path, BaiIndex &idx)
 
 namespace {
 
-// bins overlapping [beg, end) (SAM spec 5.3 reg2bins; CSIv1 spec for any min_shift / depth)
-void reg2bins(int64_t beg, int64_t end, int min_shift, int depth, std::vector<uint32_t> &out)
-{
-    out.clear();
-    if (beg >= end) return;
-    --end;
-    int s = min_shift + 3 * depth;
-    int64_t t = 0;
-    for (int l = 0; l <= depth; ++l, s -= 3) {
-        const int64_t b = t + (beg >> s), e = t + (end >> s);
-        for (int64_t k = b; k <= e; ++k) out.push_back((uint32_t)k);
-        t += 1ll << (3 * l);
-    }
-}
-
+// (the bins overlapping [beg, end) -- SAM spec 5.3 reg2bins, CSIv1 spec for any min_shift / depth -- are walked level
+// by level in bai_region_chunks below)
 uint32_t reg2bin(int64_t beg, int64_t end)
 {
     --end;
@@ -1490,7 +1525,6 @@ std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<R
 {
     // candidate chunks of every region (htslib's iterator: bins + linear-index lower bound)
     std::vector<BaiChunk> chunks;
-    std::vector<uint32_t> bins;
     for (const Region &rg : regions) {
         if (rg.rid < 0 || rg.rid >= (int)idx.refs.size()) continue;
         const BaiRef &R = idx.refs[(size_t)rg.rid];
@@ -1536,12 +1570,21 @@ std::vector<BaiChunk> bai_region_chunks(const BaiIndex &idx, const std::vector<R
                 break;
             }
         }
-        reg2bins(beg, end, ms, depth, bins);
-        for (uint32_t b : bins) {
-            auto it = std::lower_bound(R.bins.begin(), R.bins.end(), b, [](const auto &x, uint32_t v) { return x.first < v; });
-            if (it == R.bins.end() || it->first != b) continue;
-            for (const BaiChunk &c : it->second)
-                if (c.end > min_off && c.beg < max_off) chunks.push_back(BaiChunk{c.beg, std::min(c.end, max_off)});
+        // the bins that overlap [beg, end) (reg2bins above) are, level by level, one run of consecutive bin numbers:
+        // the reference's PRESENT bins inside each run are walked, instead of every candidate being looked up -- a CSI
+        // index may have a min_shift of 1, and one wide range would then list 2^30 candidate bins (the index file is
+        // untrusted input on the same footing as the BAM)
+        {
+            int sft = ms + 3 * depth;
+            int64_t t = 0;
+            for (int l = 0; l <= depth; ++l, sft -= 3) {
+                const int64_t b0 = t + (beg >> sft), b1 = t + ((end - 1) >> sft);
+                auto it = std::lower_bound(R.bins.begin(), R.bins.end(), b0, [](const auto &x, int64_t v) { return (int64_t)x.first < v; });
+                for (; it != R.bins.end() && (int64_t)it->first <= b1; ++it)
+                    for (const BaiChunk &c : it->second)
+                        if (c.end > min_off && c.beg < max_off) chunks.push_back(BaiChunk{c.beg, std::min(c.end, max_off)});
+                t += 1ll << (3 * l);
+            }
         }
     }
     std::sort(chunks.begin(), chunks.end(), [](const BaiChunk &a, const BaiChunk &b) { return a.beg < b.beg; });

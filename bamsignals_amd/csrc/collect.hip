@@ -89,6 +89,26 @@ std::vector<std::shared_ptr<Exchange>> g_ex;
             return fail(BSIG_ERR_DEVICE, "RCCL error %d (%s) at %s:%d", (int)r_, rccl().GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+// ncclGroupStart .. ncclGroupEnd: a failure of a Send / Recv in between must still close the group -- the depth
+// is per THREAD, and a thread that leaves it open runs every later RCCL call (a communicator for another device
+// list, say) inside a dangling group, where it hangs or fails.  The guard ends the group on every way out; the
+// result of that ncclGroupEnd is only looked at on the good path (end()).
+struct GroupGuard {
+    bool open = false;
+    ncclResult_t start()
+    {
+        const ncclResult_t r = rccl().GroupStart();
+        open = r == ncclSuccess;
+        return r;
+    }
+    ncclResult_t end()
+    {
+        open = false;
+        return rccl().GroupEnd();
+    }
+    ~GroupGuard() { if (open) (void)rccl().GroupEnd(); }
+};
+
 // peer copies go direct over xGMI where the link allows it ("already enabled" is fine)
 void enable_peer_access(Exchange &E)
 {
@@ -203,14 +223,15 @@ int exchange_allgather(ExchangeUse &use, const std::vector<uint8_t *> &bufs, con
         return fail(BSIG_ERR_ARG, "exchange_allgather: bad shapes");
     if (!E->comms.empty()) {
         auto queue = [&]() -> int {
-            NCCL_TRY(rccl().GroupStart());
+            GroupGuard grp;
+            NCCL_TRY(grp.start());
             for (size_t k = 0; k < n; ++k)
                 for (size_t g = 0; g < n; ++g) {
                     if (g == k) continue;
                     if (len[g]) NCCL_TRY(rccl().Recv(bufs[k] + off[g], len[g], ncclUint8, (int)g, E->comms[k], use.streams[k]));
                     if (len[k]) NCCL_TRY(rccl().Send(bufs[k] + off[k], len[k], ncclUint8, (int)g, E->comms[k], use.streams[k]));
                 }
-            NCCL_TRY(rccl().GroupEnd());
+            NCCL_TRY(grp.end());
             return BSIG_OK;
         };
         if (queue() == BSIG_OK) return BSIG_OK;
@@ -240,13 +261,14 @@ int exchange_gather(ExchangeUse &use, const std::vector<const uint8_t *> &src, c
     if (!E->comms.empty()) {
         // the peers send straight to the root over their own links (ingress 7 links x ~153 GB/s)
         auto queue = [&]() -> int {
-            NCCL_TRY(rccl().GroupStart());
+            GroupGuard grp;
+            NCCL_TRY(grp.start());
             for (size_t k = 1; k < n; ++k) {
                 if (!len[k]) continue;
                 NCCL_TRY(rccl().Recv(dst_root + off[k], len[k], ncclUint8, (int)k, E->comms[0], use.streams[0]));
                 NCCL_TRY(rccl().Send(src[k], len[k], ncclUint8, 0, E->comms[k], use.streams[k]));
             }
-            NCCL_TRY(rccl().GroupEnd());
+            NCCL_TRY(grp.end());
             return BSIG_OK;
         };
         if (queue() == BSIG_OK) return BSIG_OK;

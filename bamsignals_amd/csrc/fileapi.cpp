@@ -545,7 +545,43 @@ int run_on_slots(Slots &sl, const std::vector<bsig_reads *> &reads, int64_t n, c
     return rc;
 }
 
-// size + mtime of every index file a BAM may be opened with (<bam>.bai, <stem>.bai, <bam>.csi, <stem>.csi;
+// Out of device memory: what the cache can spare goes back to the driver -- the index-driven decodes it keeps, the
+// result-path buffers of device lists nobody is running on (never those of `keep`, the caller's own), and the free
+// blocks.  What a running call holds stays (shared_ptr, run_mu).
+void drop_spare_device_memory(const Slots *keep)
+{
+    std::list<std::shared_ptr<Resident>> drop;
+    std::vector<std::shared_ptr<Slots>> sets;
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        drop.swap(g_cache.regional);
+        sets = g_cache.slot_sets;
+    }
+    drop.clear();
+    for (auto &sp : sets) {
+        if (sp.get() == keep) continue;
+        std::unique_lock<std::mutex> run(sp->run_mu, std::try_to_lock);
+        if (!run.owns_lock()) continue;
+        Slots &S = *sp;
+        for (size_t k = 0; k < S.scratch.size(); ++k) {
+            (void)hipSetDevice(S.devices[k]);
+            if (S.scratch[k].d_shard) bsig::block_free(S.devices[k], S.scratch[k].d_shard, S.scratch[k].shard_cap * sizeof(int32_t));
+            if (S.scratch[k].h_shard) (void)hipHostFree(S.scratch[k].h_shard);
+            S.scratch[k] = SlotScratch{};
+        }
+        if (!S.devices.empty()) {
+            (void)hipSetDevice(S.devices[0]);
+            if (S.root.d_gather) bsig::block_free(S.devices[0], S.root.d_gather, S.root.gather_cap * sizeof(int32_t));
+            if (S.root.d_final) bsig::block_free(S.devices[0], S.root.d_final, S.root.final_cap * sizeof(int32_t));
+            for (int k = 0; k < 3; ++k)
+                if (S.root.d_tab[k]) bsig::block_free(S.devices[0], S.root.d_tab[k], S.root.tab_cap[k] * sizeof(int64_t));
+            S.root = RootScratch{};
+        }
+    }
+    bsig::block_cache_release();
+}
+
+// size + mtime of every index file a BAM may be opened with (<bam>.csi, <stem>.csi, <bam>.bai, <stem>.bai;
 // bsig_bam_open tries them in this order): whichever one is used, replacing, adding or removing it
 // changes the stamp, so cached headers, resident reads and reads files are never tied to a stale index
 std::string index_stamps(const std::string &bam)
@@ -766,6 +802,9 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             });
         };
         double t6[6] = {0, 0, 0, 0, 0, 0};
+        // (a lambda: out of device memory, the decode is tried once more after the cache has given up what it can spare)
+        auto decode_once = [&]() -> int {
+        for (bsig_reads *&r : res->reads) { if (r) bsig_reads_free(r); r = nullptr; }
         if (whole) {
             const std::string side = key.empty() ? std::string() : sidecar_path(bampath);
             // (the reads file is tied to the CONTENT it was made from -- size and mtime of the BAM and of its
@@ -828,6 +867,16 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             if (rc) return rc;
             set_coverage(*res, n, rid.data(), qbeg.data(), qend.data());
         }
+        return BSIG_OK;
+        };
+        rc = decode_once();
+        if (rc == BSIG_ERR_NOMEM) {
+            // the cache may be what fills the device: the index-driven decodes it keeps, the result buffers of idle
+            // device lists and the free blocks go back to the driver, and the decode is tried once more
+            drop_spare_device_memory(slots.get());
+            rc = decode_once();
+        }
+        if (rc) return rc;
         T[2] = t6[5];
         T[1] = now_s() - t_dec - T[2];
         // driver allocation calls of the decode stage, layout included (they run on this thread and on the helper
@@ -840,24 +889,32 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
             std::lock_guard<std::mutex> lock(g_cache.mu);
             bool still = false;                            // (bsig_cache_clear may have run meanwhile)
             for (auto &sp : g_cache.slot_sets) still = still || sp == slots;
+            // ONE budget (env BAMSIGNALS_CACHE_GB per GPU) for whole files and index-driven decodes alike; above it
+            // the index-driven decodes go first, oldest first, then the least recently used whole files.  A budget
+            // of 0 keeps nothing but the entry in use.
+            const int64_t budget = cache_budget_bytes();
             if (still && whole) {
                 for (auto it = g_cache.resident.begin(); it != g_cache.resident.end();)
                     it = (*it)->key == rkey ? g_cache.resident.erase(it) : std::next(it);
                 g_cache.resident.push_front(res);
-                const int64_t budget = cache_budget_bytes();
-                int64_t held = 0;
-                for (auto it = g_cache.resident.begin(); it != g_cache.resident.end();) {
-                    held += (*it)->bytes;
-                    if (held > budget && it != g_cache.resident.begin()) it = g_cache.resident.erase(it);
-                    else ++it;
-                }
             } else if (still) {
-                // index-driven decodes are small by construction (less than a third of the genome): keep the
-                // last few (env BAMSIGNALS_REGION_CACHE, default 8; 0 = the reference's behaviour, none)
+                // index-driven decodes: the last few (env BAMSIGNALS_REGION_CACHE, default 8; 0 = the reference's
+                // behaviour, none), inside the same byte budget
                 size_t keep = 8;
                 if (const char *e = getenv("BAMSIGNALS_REGION_CACHE")) keep = (size_t)std::max(0, atoi(e));
+                if (budget <= 0) keep = 0;
                 if (keep) g_cache.regional.push_front(res);
                 while (g_cache.regional.size() > keep) g_cache.regional.pop_back();
+            }
+            if (still) {
+                auto held = [&]() {
+                    int64_t t = 0;
+                    for (auto &r : g_cache.resident) t += r->bytes;
+                    for (auto &r : g_cache.regional) t += r->bytes;
+                    return t;
+                };
+                while (held() > budget && !g_cache.regional.empty() && g_cache.regional.back() != res) g_cache.regional.pop_back();
+                while (held() > budget && !g_cache.resident.empty() && g_cache.resident.back() != res) g_cache.resident.pop_back();
             }
         }
         }
@@ -867,6 +924,8 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
     const double t_run = now_s();
     const AllocSnap a_run = AllocSnap::now();
     std::string gather;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt) drop_spare_device_memory(slots.get());        // (out of device memory: once more with the cache's spare memory given back)
     if (!many) {
         // plan (ranges -> tiles in HBM), kernels, download -- timed apart
         bsig_plan *plan = nullptr;
@@ -878,6 +937,8 @@ int file_level(const char *bampath, int64_t n, const int32_t *seq_code, int32_t 
         if (plan) bsig_plan_free(plan);
     } else {
         rc = run_on_slots(*slots, res->reads, n, rid.data(), loc.data(), width, strand, prm, dest, gather);
+    }
+    if (rc != BSIG_ERR_NOMEM) break;
     }
     T[3] = now_s() - t_run;
     X[1] = AllocSnap::now().seconds_since(a_run);
@@ -900,16 +961,17 @@ extern "C" {
 }  // extern "C"
 
 namespace {
-// the index files htslib's bam_index_load tries (ref: src/bamsignals.cpp:207), in its order: <bam>.bai,
-// <stem>.bai, <bam>.csi, <stem>.csi
+// the index files htslib's bam_index_load tries (ref: src/bamsignals.cpp:207), in its order (hts_idx_load looks for a
+// CSI index first -- htslib is not vendored in the reference; this is its documented search order): <bam>.csi,
+// <stem>.csi, <bam>.bai, <stem>.bai
 std::vector<std::pair<std::string, bool>> index_candidates(const std::string &bam)
 {
     std::string stem = bam;
     if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".bam") == 0) stem.erase(stem.size() - 4);
-    std::vector<std::pair<std::string, bool>> c = {{bam + ".bai", false}};
-    if (stem != bam) c.push_back({stem + ".bai", false});
-    c.push_back({bam + ".csi", true});
+    std::vector<std::pair<std::string, bool>> c = {{bam + ".csi", true}};
     if (stem != bam) c.push_back({stem + ".csi", true});
+    c.push_back({bam + ".bai", false});
+    if (stem != bam) c.push_back({stem + ".bai", false});
     return c;
 }
 

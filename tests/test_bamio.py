@@ -526,6 +526,27 @@ def test_csi_index_is_read_and_queried(tmp_path, fixture_reads, depth):
     b.close(); ref.close()
 
 
+def test_a_csi_index_is_preferred_to_a_bai(tmp_path, fixture_reads):
+    """htslib's index search looks for <bam>.csi (and <stem>.csi) before the .bai files (ref: bam_index_load,
+    src/bamsignals.cpp:207): with both present the CSI is the index -- a damaged BAI next to it is never read --
+    and without the CSI the damaged BAI is reported."""
+    import shutil
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import BamFile
+    p = tmp_path / "both.bam"
+    shutil.copy(BAM, p)
+    (tmp_path / "both.bam.bai").write_bytes(b"BAI\x01" + b"\xff" * 40)
+    with pytest.raises(_lib.BsigError):
+        BamFile(str(p))
+    (tmp_path / "both.csi").write_bytes(_bai_to_csi(open(BAM + ".bai", "rb").read(), 5))      # <stem>.csi
+    b = BamFile(str(p))
+    got = b.decode(rid=np.asarray([1], np.int32), beg=np.asarray([100], np.int64), end=np.asarray([4000], np.int64))
+    ref = BamFile(BAM)
+    want = ref.decode(rid=np.asarray([1], np.int32), beg=np.asarray([100], np.int64), end=np.asarray([4000], np.int64))
+    assert len(got["pos"]) > 0 and np.array_equal(got["pos"], want["pos"])
+    b.close(); ref.close()
+
+
 def test_csi_index_of_a_multibin_bam(tmp_path):
     """The same on a BAM whose index spans many windows and every bin level (this repo's writer)."""
     from bamsignals_amd.bamio import BamFile, write_columns_as_bam

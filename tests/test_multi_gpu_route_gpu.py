@@ -560,6 +560,31 @@ def test_region_decodes_are_remembered(synth_bam, monkeypatch):
         for rep in range(2):
             assert np.array_equal(bamCount(bam, gr[pick], verbose=False), want_c)
             assert not last_call_timing()["bam_was_resident"]
+        # the index-driven decodes count against the same byte budget as whole files (BAMSIGNALS_CACHE_GB): with room
+        # for one of them the older one goes when a second is decoded, and a budget of 0 keeps none
+        monkeypatch.delenv("BAMSIGNALS_REGION_CACHE")
+        from bamsignals_amd.bamio import BamFile
+        from bamsignals_amd.device import Context, Reads
+        ctx = Context(0)
+        bf = BamFile(bam)
+        sizes = []
+        for idx in (pick, other):
+            beg = rg["loc"][idx].astype(np.int64)
+            r = Reads.from_bam_regions(ctx, bf, rg["rid"][idx], beg, beg + rg["len"][idx])
+            sizes.append(r.info()["hbm_bytes"])
+            r.close()
+        bf.close(); ctx.close()
+        assert min(sizes) > 0.2 * max(sizes)
+        monkeypatch.setenv("BAMSIGNALS_CACHE_GB", repr(1.1 * max(sizes) / 2**30))
+        _lib.load().bsig_cache_clear()
+        def count(idx):
+            bamCount(bam, gr[idx], verbose=False)
+            return last_call_timing()["bam_was_resident"]
+        assert [count(pick), count(pick), count(other), count(other)] == [False, True, False, True]
+        assert count(pick) is False                       # evicted by `other`'s decode: the budget holds one of them
+        monkeypatch.setenv("BAMSIGNALS_CACHE_GB", "0")
+        _lib.load().bsig_cache_clear()
+        assert [count(pick), count(pick)] == [False, False]
     finally:
         _lib.load().bsig_cache_clear()
 
