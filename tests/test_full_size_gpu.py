@@ -1,6 +1,8 @@
 """GPU: the BASELINE.json configurations at (or near) their full sizes, bit-exact against the C
 oracle — it needs only ~0.05-2 s per configuration on read columns — plus the size-independent
 properties of the domain."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,4 +94,28 @@ def test_config4_paired_end_strand_split_100k_ranges(ctx):
         want, _ = oracle_c.pileup_core(orc, rg, **a)
         assert np.array_equal(got, want), pe_mid
         assert st["cells"] == 400_000_000 and st["bytes_per_visit_short"] == 12
+    reads.close()
+
+
+@pytest.mark.fullsize
+@pytest.mark.skipif(os.environ.get("BAMSIGNALS_FULLSIZE") != "1", reason="opt-in: set BAMSIGNALS_FULLSIZE=1 (40 GB of host memory, 2 minutes)")
+@pytest.mark.timeout(900)
+def test_config4_at_its_full_5e8_paired_end_reads(ctx):
+    """BASELINE config 4 at FULL size: 5e8 paired-end reads on 10 x 250 Mbp, 100k x 2 kb ranges, tlenFilter=c(50,500),
+    shift=75, ss=TRUE, paired.end "filter" and "midpoint": all 4e8 cells of each call against the C oracle."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_ranges, synth_reads
+    from oracle import oracle_c
+    ref_len = [250_000_000] * 10
+    cols = synth_reads(500_000_000, ref_len, seed=0xC4, paired=True, with_cigar=False)
+    rg = synth_ranges(100_000, 2000, ref_len, seed=0xC5)
+    reads = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
+    orc = oracle_c.OracleReads(cols["ref_off"], cols["pos"], cols["end"], cols["flag"], cols["mapq"], cols["tlen"])
+    for pe_mid in (False, True):
+        a = dict(binsize=1, ss=True, shift=75, requiredF=66, tlen_filter=(50, 500), pe_mid=pe_mid)
+        got, st = _run(ctx, reads, rg, _lib.MODE_PROFILE, **a)
+        want, _ = oracle_c.pileup_core(orc, rg, **a)
+        assert np.array_equal(got, want), pe_mid
+        assert st["cells"] == 400_000_000 and st["bytes_per_visit_packed"] == 8 and st["visits_packed"] > 0.8 * st["visits"]
     reads.close()
