@@ -278,6 +278,10 @@ static int64_t g_resolve_min_override = -1;     // bsig_debug_set_knob(4, n): tw
 static bool plan_two_launches(const bsig_plan *p)
 {
     static const int64_t resolve_min = getenv("BAMSIGNALS_RESOLVE_MIN_TILES") ? atoll(getenv("BAMSIGNALS_RESOLVE_MIN_TILES")) : (int64_t)32768;
+    // (the count family walks four tiles per wave and looks their windows up side by side: a launch of its own
+    // for them measured the same or slower there -- 0.1469 fused, 0.1476 in two launches on config 3's tiling --
+    // so bamCount keeps the fused form unless the knob asks)
+    if (g_resolve_min_override < 0 && p->kernel_mode == BSIG_MODE_COUNT) return false;
     return p->n_items > 0 && p->n_items >= (g_resolve_min_override >= 0 ? g_resolve_min_override : resolve_min);
 }
 

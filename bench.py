@@ -207,7 +207,7 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         # slower -- first touches of its memory -- and it is only insurance against rare allocation stalls)
         arena_gb = 0
         # three sessions, the median one reported: a session's first call now and then catches an allocation stall
-        # of the driver (r03: one run in three to five, 0.5 s instead of 0.28 s) -- all three are listed
+        # of the driver (r03: one run in three to five, 0.5 s instead of 0.28 s; profiles/NOTES_r01_r03.md) -- all three are listed
         child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device, arena_gb=arena_gb)
         if not np.array_equal(flat, want_flat):
             raise SystemExit("file-level result differs from the resident-column result")
