@@ -249,7 +249,7 @@ __device__ __forceinline__ void four_packed(const uint4 &w, const int4 &t, uint3
 // (kPre * 4 * NT reads) of the packed class, where nearly all reads live, and the first pass of classes 0
 // and 1.  Longer windows and the two long-span classes continue in plain loops.
 // (The packed class's later chunks -- windows wider than kPackChunk bases -- are walked by packed_later_chunks.)
-template <int NT, int kPre = 4, typename F>
+template <int NT, int kPre = 2, typename F>
 __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
                                               const uint2 (&win)[BSIG_MAX_CLASSES], int pbase,
                                               const uint8_t *__restrict__ ptab, int tid, F &&one)
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
 // A tile that is not cut into slices has at most 32,767 reads in its windows (bsig_plan_create's
 // ceiling for coverage), so every cell stays inside [-32767, 32767].  4 KiB instead of 8 KiB of
 // LDS per 2,048-cell tile: 24 instead of 18 single-wave workgroups per CU.
-template <int NT>
+template <int NT, int PRE, bool RES>
 __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
                                                  int32_t *__restrict__ out,
                                                  const uint2 *__restrict__ windows,
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
     const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES], clip;
     PackedWin pk;
-    load_windows(R, P, BSIG_MODE_COVERAGE, w, items, windows, win, tile, pk, clip);
+    load_windows<RES>(R, P, BSIG_MODE_COVERAGE, w, items, windows, win, tile, pk, clip);
     int4 *lds4 = reinterpret_cast<int4 *>(lds);
     for (int v = tid; v < img_vec; v += NT) lds4[v] = make_int4(0, 0, 0, 0);
     // the packed class's filter table: behind the image and the scan totals (16-B aligned)
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
             atomicAdd(&lds[kb >> 1], (kb & 1) ? -65536 : -1);
         }
     };
-    for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
+    for_each_read<NT, PRE>(R, P, win, pk.base, ptab, tid, one);
     if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_COVERAGE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();
 
@@ -1295,7 +1295,10 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
 #undef BSIG_KP
     } else if (mode == BSIG_MODE_COVERAGE) {
         const size_t lds = (size_t)((tile_cells + 8 + 7) / 8) * 16 + (size_t)((NT / 64 + 3) / 4) * 16 + BSIG_PACK_CODES;   // signed 16-bit cells, scan totals, the packed class's table
-        hipLaunchKernelGGL((k_coverage<NT>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
+        // (the packed class's passes hold 256 reads each: two in flight cover a 2-kb tile at 100-fold coverage; the form
+        // for resolved windows has no lookup code in it)
+        if (P.resolved) hipLaunchKernelGGL((k_coverage<NT, 2, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
+        else hipLaunchKernelGGL((k_coverage<NT, 2, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (NT == kWave && (!windows || P.resolved) && count_tiles > 1) {
         // several consecutive tiles per wave (the slices of heavy tiles, which come with fixed windows, and
         // the wider workgroups keep the one-tile kernel)

@@ -162,6 +162,37 @@ def cold_call_in_fresh_process(workdir, tag, bam, names, rg, call, device, env=N
     return out, flat
 
 
+def driver_reclaim_probe(gb=96):
+    """Plain HIP in a process of its own (ctypes on libamdhip64, nothing of this repository): 8-GB hipMalloc calls up to
+    `gb` GB, timed one by one, then freed.  On this platform the memory that EXITED processes had allocated is reclaimed
+    lazily, and the next process to allocate pays for it inside one of its hipMalloc calls (scripts/hipmalloc_after_exit.py:
+    3.6 s once after a process that had used 120 GB) -- the GPU test suite or a profiler run in front of the bench leaves
+    such a debt, and the first cold-call session would pay it inside its decode's allocations (it did: 0.83 / 0.52 / 0.28 s
+    for three otherwise identical sessions).  The probe shows whether there was a debt (its slowest call) and settles it,
+    so that the sessions below measure a session's first call and not the previous tenant's clean-up."""
+    import subprocess
+    code = (
+        "import ctypes as C, time, json\n"
+        "h = C.CDLL('libamdhip64.so')\n"
+        "h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; h.hipFree.argtypes = [C.c_void_p]\n"
+        "ps, ts = [], []\n"
+        "p = C.c_void_p(); h.hipMalloc(C.byref(p), 256); h.hipFree(p)\n"
+        f"for _ in range({int(gb) // 8}):\n"
+        "    p = C.c_void_p(); t = time.perf_counter(); rc = h.hipMalloc(C.byref(p), 8 << 30); ts.append(time.perf_counter() - t)\n"
+        "    if rc != 0: break\n"
+        "    ps.append(p)\n"
+        "for p in ps: h.hipFree(p)\n"
+        "print(json.dumps(dict(calls=len(ts), bytes_per_call=8 << 30, slowest_s=max(ts), total_s=sum(ts))))\n")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["what"] = ("plain hipMalloc calls in a process of their own, in front of the cold-call sessions: a slowest call of "
+                       "seconds is the driver reclaiming what earlier processes freed")
+        return out
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def _settle(path):
     """A BAM the bench has just written is still dirty in the page cache and its pages have never been read;
     the timed calls are meant to see a file that has been on disk for a while and has been used before (cached,
@@ -206,6 +237,10 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         # (no arena: measured on the same file, scripts/cold_call_scan_ab.py, a 44-GB arena makes the call 0.04 s
         # slower -- first touches of its memory -- and it is only insurance against rare allocation stalls)
         arena_gb = 0
+        # whatever ran on this GPU before the bench (the GPU tests, a profiler) left freed memory for the driver to reclaim:
+        # shown, and settled, by plain hipMalloc calls in a process of their own
+        reclaim = driver_reclaim_probe()
+        log(f"end_to_end: driver reclaim probe {reclaim}")
         # three sessions, the median one reported: a session's first call now and then catches an allocation stall
         # of the driver (r03: one run in three to five, 0.5 s instead of 0.28 s; profiles/NOTES_r01_r03.md) -- all three are listed
         child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device, arena_gb=arena_gb)
@@ -223,10 +258,11 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         # a stage of one session well above the same stage of the others names where that session's time went
         # (alloc_*: seconds inside the driver's allocator, metered by the library)
         stage_keys = ("open", "decode", "upload_and_layout", "plan", "kernels", "download", "alloc_total")
-        med_stage = {k: float(np.median([c["calls"][0]["stages_s"].get(k, 0.0) for c in sessions])) for k in stage_keys}
-        outliers = [dict(session=i, stage=k, seconds=c["calls"][0]["stages_s"].get(k, 0.0), median=med_stage[k])
+        # (against the FASTEST session's stage: with three sessions a median is itself an outlier when two of them stall)
+        min_stage = {k: float(min(c["calls"][0]["stages_s"].get(k, 0.0) for c in sessions)) for k in stage_keys}
+        outliers = [dict(session=i, stage=k, seconds=c["calls"][0]["stages_s"].get(k, 0.0), fastest_session=min_stage[k])
                     for i, c in enumerate(sessions) for k in stage_keys
-                    if c["calls"][0]["stages_s"].get(k, 0.0) > max(3 * med_stage[k], 0.02)]
+                    if c["calls"][0]["stages_s"].get(k, 0.0) > max(2 * min_stage[k], min_stage[k] + 0.03)]
         child = sorted(sessions, key=lambda c: c["calls"][0]["call_s"])[1]
         t_cold, t_warm = child["calls"][0]["call_s"], child["calls"][1]["call_s"]
         stages = child["calls"][0]["stages_s"]
@@ -250,7 +286,7 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
                    cold_call_median_s=float(np.median(cold_samples)), cold_call_max_s=max(cold_samples),
                    cold_call_sessions_stages_s=[{k: c["calls"][0]["stages_s"].get(k) for k in stage_keys + ("alloc_calls", "reserved_bytes", "reservation_wait")}
                                                 for c in sessions],
-                   stages_above_3x_their_median=outliers,
+                   stages_well_above_the_fastest_session=outliers, driver_reclaim_probe=reclaim,
                    cold_call_stages_s=stages, warm_call_s=t_warm,
                    # the compressed file's trip into HBM: what the call waited for it, and the file size over the
                    # whole decode (block scan + copies + inflate + parse), i.e. the ingest rate the cold call sees
