@@ -565,7 +565,7 @@ thread_local double g_reserved_bytes = 0, g_reserve_wait = 0;
 struct ScratchPool {
     int device;
     hipStream_t st;
-    struct Blk { void *p; size_t bytes; };
+    struct Blk { void *p; size_t bytes; bool slab; };
     std::vector<Blk> mine;
     // requests of up to kSmall bytes are carved out of slabs (a share makes some twenty allocations of a few
     // bytes to a few hundred KB -- status words, tables, per-reference arrays -- and each would be a trip into
@@ -584,7 +584,7 @@ struct ScratchPool {
                 size_t got = 0;
                 const hipError_t e = bsig::block_alloc(device, bsig::kSlabBytes, 2.0, &q, &got);
                 if (e != hipSuccess) { *p = nullptr; return e; }
-                mine.push_back(Blk{q, got});
+                mine.push_back(Blk{q, got, true});
                 slab = (uint8_t *)q;
                 slab_left = got;
             }
@@ -597,17 +597,18 @@ struct ScratchPool {
         size_t got = 0;
         const hipError_t e = bsig::block_alloc(device, bytes, 2.0, &q, &got);
         if (e != hipSuccess) { *p = nullptr; return e; }
-        mine.push_back(Blk{q, got});
+        mine.push_back(Blk{q, got, false});
         *p = (T *)q;
         return hipSuccess;
     }
-    // a block of its own (not one carved from a slab) that nothing queued on the stream uses any more goes back
-    // to the cache of free blocks now: whoever allocates next -- the resident layout's temporaries -- finds it
+    // a block of its own that nothing queued on the stream uses any more goes back to the cache of free blocks now:
+    // whoever allocates next -- the resident layout's temporaries -- finds it.  (An allocation carved from a slab
+    // stays: the slab holds others, also when the allocation happens to sit at the slab's first byte.)
     void give_back(void *p)
     {
         if (!p) return;
         for (size_t k = 0; k < mine.size(); ++k)
-            if (mine[k].p == p) {
+            if (mine[k].p == p && !mine[k].slab) {
                 bsig::block_free(device, mine[k].p, mine[k].bytes);
                 mine.erase(mine.begin() + (long)k);
                 return;
