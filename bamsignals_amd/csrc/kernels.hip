@@ -594,6 +594,83 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
 #endif
 }
 
+// k_profile for T consecutive tiles per wave (large launches, windows from k_resolve_tiles): lane t fetches the work
+// item and the windows of tile t of its group -- ONE round trip for the T tiles -- and parks them in LDS; the wave then
+// works the tiles off one after the other through one image, which the store loop of a tile clears for the next.  From
+// its second tile on a wave pays neither a workgroup launch, nor the item / windows trip, nor the filter table.
+template <bool SS, int PRE, int WAVES, int T>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_profile_multi(
+    const BsigWorkItem *__restrict__ items, uint32_t n_tiles, int32_t *__restrict__ out, const uint2 *__restrict__ windows,
+    const BsigReadsDev R, const BsigKParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    constexpr int S = SS ? 2 : 1;
+    constexpr int kStage = 20;                               // dwords per tile: 8 of the item, 12 of its windows
+    const int tid = threadIdx.x;
+    const uint32_t n_groups = (n_tiles + T - 1) / T;
+    const uint32_t first = tile_of_block(blockIdx.x, n_groups) * T;
+    const uint32_t n_here = n_tiles - first < (uint32_t)T ? n_tiles - first : (uint32_t)T;      // uniform
+    int4 *lds4 = reinterpret_cast<int4 *>(lds);
+    const int img_vec = (P.tile_cells * S + 8 + 7) / 8;
+    uint8_t *ptab = reinterpret_cast<uint8_t *>(lds4 + img_vec);
+    uint32_t *stage = reinterpret_cast<uint32_t *>(ptab + BSIG_PACK_CODES);
+    if ((uint32_t)tid < n_here) {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(items + first + tid);
+        const uint4 *rp = reinterpret_cast<const uint4 *>(reinterpret_cast<const BsigResolved *>(windows) + first + tid);
+        const uint4 a = ip[0], b = ip[1], c = rp[0], d = rp[1], e = rp[2];
+        uint4 *sp = reinterpret_cast<uint4 *>(stage + kStage * tid);
+        sp[0] = a; sp[1] = b; sp[2] = c; sp[3] = d; sp[4] = e;
+    }
+    for (int v = tid; v < img_vec; v += kWave) lds4[v] = make_int4(0, 0, 0, 0);
+    build_ptab<kWave>(ptab, R, P, tid);
+    block_sync<kWave>();
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
+    uint2 *lds2 = reinterpret_cast<uint2 *>(lds);
+#pragma unroll 1
+    for (uint32_t t = 0; t < n_here; ++t) {
+        const uint32_t *sg = stage + kStage * t;
+        auto sc = [&](int k) { return __builtin_amdgcn_readfirstlane((int)sg[k]); };
+        BsigWorkItem w;
+        w.loc = sc(0); w.len = sc(1); w.c0 = sc(2); w.nc = sc(3);
+        w.out_off = (int64_t)(((uint64_t)(uint32_t)sc(5) << 32) | (uint32_t)sc(4));
+        w.ref_unit0 = (uint32_t)sc(6); w.units_strand = (uint32_t)sc(7);
+        uint2 win[BSIG_MAX_CLASSES];
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) win[c] = make_uint2((uint32_t)sc(8 + 2 * c), (uint32_t)sc(9 + 2 * c));
+        const int pbase = sc(18), pchunks = sc(19);
+        const int nv = w.nc * S;
+        const int sh = (int)(w.out_off & 3);
+        const int nvec = (sh + nv + 3) >> 2;
+        const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
+        auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
+            if (!valid || rej || tlen_rejected(P, tl)) return;
+            const int a = tl < 0 ? -tl : tl;
+            const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
+            const int p5 = neg ? e - offset : p + offset;
+            int rel = p5 - w.loc;
+            if ((unsigned)rel >= (unsigned)w.len) return;
+            int anti = neg ? 1 : 0;
+            if (neg_range) { rel = w.len - rel - 1; anti ^= 1; }
+            const int cell = P.binsize == 1 ? rel : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
+            const int lc = cell - w.c0;
+            if ((unsigned)lc < (unsigned)w.nc) {
+                const int k = sh + lc * S + (SS ? anti : 0);
+                atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
+            }
+        };
+        for_each_read<kWave, PRE>(R, P, win, pbase, ptab, tid, one);
+        if (pchunks > 1) packed_later_chunks<kWave>(R, P, BSIG_MODE_PROFILE, w, pchunks, make_uint2(0u, 0xFFFFFFFFu), ptab, tid, one);
+        block_sync<kWave>();
+        int32_t *gbase = out + (w.out_off - sh);
+        for (int v = tid; v < nvec; v += kWave) {
+            const uint2 d = lds2[v];
+            lds2[v] = make_uint2(0u, 0u);                    // the image is the next tile's
+            store_vec(gbase, v, make_int4((int)(d.x & 0xFFFFu), (int)(d.x >> 16), (int)(d.y & 0xFFFFu), (int)(d.y >> 16)), sh, nv);
+        }
+        block_sync<kWave>();
+    }
+}
+
 // Wide bins (binsize >~ 64): a tile has few cells and thousands of reads, and the position-sorted
 // reads of one wave instruction fall into one or two bins, so plain LDS atomics serialise on a
 // bank.  Here the lanes add into replicas of the tile image (up to 32, odd stride:
@@ -1241,11 +1318,12 @@ namespace bsig {
 // Tuning knobs (defaults from the environment once, changeable at run time through bsig_debug_set_knob for
 // the sweep scripts): 0 = k_profile class-0 passes in flight (BAMSIGNALS_PROFILE_PRE), 1 = count tiles per
 // wave (BAMSIGNALS_COUNT_TILES), 2 = count passes in flight (BAMSIGNALS_COUNT_PRE).
-static int g_knobs[4] = {-1, -1, -1, -1};
+static int g_knobs[6] = {-1, -1, -1, -1, -1, -1};
 static int knob(int k)
 {
-    static const char *const names[4] = {"BAMSIGNALS_PROFILE_PRE", "BAMSIGNALS_COUNT_TILES", "BAMSIGNALS_COUNT_PRE", "BAMSIGNALS_KNOB3"};
-    static const int dflt[4] = {2, 4, 2, 0};
+    static const char *const names[6] = {"BAMSIGNALS_PROFILE_PRE", "BAMSIGNALS_COUNT_TILES", "BAMSIGNALS_COUNT_PRE", "BAMSIGNALS_KNOB3",
+                                         "BAMSIGNALS_KNOB4", "BAMSIGNALS_PROFILE_TILES"};
+    static const int dflt[6] = {2, 4, 2, 0, 0, 0};
     if (g_knobs[k] < 0) {
         const char *e = getenv(names[k]);
         g_knobs[k] = e ? atoi(e) : dflt[k];
@@ -1290,6 +1368,22 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
         // 2-kb tiles lose (same bases in 500 / 1,000 / 1,500 / 2,000-cell tiles, two launches, 7 -> 8 waves:
         // 354 -> 316, 227 -> 215, 212 -> 212, 187 -> 192 us).  knob 3: 8 = always, 1 = never, 0 = by the tile image
         const bool w8 = NT == kWave && P.resolved && (knob(3) == 8 || (knob(3) == 0 && lds <= 3072));
+        // consecutive tiles per wave of a large launch (k_profile_multi).  One workgroup per tile, refilled by the
+        // hardware as workgroups retire, is the better schedule down to 1-kb tiles (same bases, 7-8 waves, 1 / 2 / 4 tiles
+        // per wave: 2-kb tiles 188 / 199 / 213 us, config 5's 1-kb tiles 145 / 155 / 166, config 4 398 / 420 / 431); for
+        // 500-bp tiles four per wave win (317 / 299 / 282).  knob 5: 0 = four per wave for images of up to 2 KB
+        // (about 760 cells), 1 = never, 2 / 4 = always
+        const int pt = knob(5) == 0 ? (lds <= 2048 ? 4 : 1) : knob(5);
+        if (NT == kWave && P.resolved && !P.accumulate && pt > 1) {
+            const int T = pt >= 4 ? 4 : 2;
+            const dim3 g2((unsigned)((n_items + T - 1) / T));
+            const size_t lds_m = lds + (size_t)T * 20 * sizeof(uint32_t);
+#define BSIG_KM(SS_, W_, T_) hipLaunchKernelGGL((k_profile_multi<SS_, 2, W_, T_>), g2, dim3(kWave), lds_m, st, items, (uint32_t)n_items, out, windows, R, P)
+            if (ss) { if (w8) { if (T == 4) BSIG_KM(true, 8, 4); else BSIG_KM(true, 8, 2); } else { if (T == 4) BSIG_KM(true, 1, 4); else BSIG_KM(true, 1, 2); } }
+            else    { if (w8) { if (T == 4) BSIG_KM(false, 8, 4); else BSIG_KM(false, 8, 2); } else { if (T == 4) BSIG_KM(false, 1, 4); else BSIG_KM(false, 1, 2); } }
+#undef BSIG_KM
+            return hipGetLastError();
+        }
         if (ss) { if (pre <= 2) { if (w8) BSIG_KP(true, 2, 8); else BSIG_KP(true, 2, 1); } else if (pre == 3) BSIG_KP(true, 3, 1); else BSIG_KP(true, 4, 1); }
         else    { if (pre <= 2) { if (w8) BSIG_KP(false, 2, 8); else BSIG_KP(false, 2, 1); } else if (pre == 3) BSIG_KP(false, 3, 1); else BSIG_KP(false, 4, 1); }
 #undef BSIG_KP
@@ -1447,7 +1541,7 @@ extern "C" int bsig_debug_set_resolve_min(long long n_tiles);     // runtime.hip
 extern "C" int bsig_debug_set_knob(int which, int value)
 {
     if (which == 4) return bsig_debug_set_resolve_min(value);
-    if (which < 0 || which >= 4 || value < 0) return -1;
+    if (which < 0 || which >= 6 || value < 0) return -1;
     bsig::g_knobs[which] = value;
     return 0;
 }

@@ -31,14 +31,17 @@ def main():
     lib = _lib.load()
     # (name, class passes in flight, 8-wave build, tiles from which the windows are looked up by a launch of their own)
     never = 1 << 30
-    variants = [("pre3", 3, 1, never), ("pre2", 2, 1, never), ("pre3+resolve-launch", 3, 1, 0), ("pre2+resolve-launch", 2, 1, 0),
-                ("pre4+resolve-launch", 4, 1, 0), ("pre2+8waves+resolve-launch", 2, 8, 0), ("default", 2, 0, -1)]
+    # ... and, last, consecutive tiles per wave (k_profile_multi, knob 5)
+    variants = [("pre2", 2, 1, never, 1), ("pre2+resolve-launch", 2, 1, 0, 1), ("pre2+8waves+resolve-launch", 2, 8, 0, 1),
+                ("resolve-launch+2tiles", 2, 1, 0, 2), ("resolve-launch+4tiles", 2, 1, 0, 4),
+                ("resolve-launch+8waves+2tiles", 2, 8, 0, 2), ("resolve-launch+8waves+4tiles", 2, 8, 0, 4), ("default", 2, 0, -1, 0)]
     if a.only:
         variants = [v for v in variants if v[0] in a.only.split(",")]
     ref = None
     for rnd in range(2):
-        for name, pre, w8, rmin in variants:
+        for name, pre, w8, rmin, pt in variants:
             assert lib.bsig_debug_set_knob(0, pre) == 0 and lib.bsig_debug_set_knob(3, w8) == 0 and lib.bsig_debug_set_knob(4, rmin) == 0
+            assert lib.bsig_debug_set_knob(5, pt) == 0
             _, ms = w.timed(a.steps, 10, stream, lambda: None)
             got = [o.clone() for o in w.outs]
             if ref is None:

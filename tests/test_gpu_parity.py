@@ -273,6 +273,37 @@ def test_packed_class_and_what_stays_outside_it(ctx, synth, monkeypatch):
     monkeypatch.delenv("BAMSIGNALS_PACK")
 
 
+@pytest.mark.parametrize("width,what", [(600, "four tiles per wave, 8 waves per SIMD"), (1000, "one tile per workgroup, 8 waves per SIMD"),
+                                        (2000, "one tile per workgroup")])
+def test_large_launches_look_their_windows_up_in_a_launch_of_their_own(ctx, synth, width, what):
+    """From 32,768 tiles on, a step is two launches: k_resolve_tiles (the index lookup of every tile, one lane per tile)
+    and the pileup kernel, which comes in forms of its own for that case (no lookup code; narrow tiles: 8 waves per SIMD;
+    very narrow ones: four consecutive tiles per wave through one image).  40,000 ranges of each kind against the oracle --
+    ragged widths, all strands, ranges hanging over reference ends, duplicates, zero widths."""
+    from bamsignals_amd.synth import synth_ranges
+    from oracle import oracle_c
+    for which, a in (("se", dict(binsize=1)), ("pe", dict(binsize=1, ss=True, shift=-30, requiredF=66, tlen_filter=(50, 500))),
+                     ("se", dict(binsize=3, ss=True, mapqual=20))):
+        gpu, orc, cols, _, _ = synth[which]
+        rg = synth_ranges(40_000, width, cols["ref_len"], seed=width, jitter=width // 4)
+        rg["len"][::97] = 0
+        rg["loc"][::41] -= width // 2
+        for k in ("rid", "loc", "len", "strand"):
+            rg[k][5::1000] = rg[k][4::1000][:len(rg[k][5::1000])]
+        want, woff = oracle_c.pileup_core(orc, rg, **a)
+        got, off = _gpu(ctx, gpu, rg, "pileup", **dict(a))
+        assert np.array_equal(off, woff) and np.array_equal(got, want), (what, a)
+    gpu, orc, cols, _, _ = synth["pe"]
+    rg = synth_ranges(40_000, width, cols["ref_len"], seed=width + 1, jitter=width // 4)
+    for a in (dict(), dict(requiredF=66, tlen_filter=(0, 1000), tspan=True)):
+        want, _ = oracle_c.coverage_core(orc, rg, **a)
+        got, _ = _gpu(ctx, gpu, rg, "coverage", **dict(a))
+        assert np.array_equal(got, want), (what, "coverage", a)
+    want, _ = oracle_c.pileup_core(orc, rg, binsize=-1, ss=True)
+    got, _ = _gpu(ctx, gpu, rg, "pileup", binsize=-1, ss=True)
+    assert np.array_equal(got, want), (what, "count")
+
+
 @pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
 def test_pileup_vs_oracle(ctx, synth, which, cases):
     from oracle import oracle_c
