@@ -18,7 +18,7 @@ CASES = {
     "ns": ("k_profile<64, false", "python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also"),
     "c2": ("k_profile<64, false", "python3 bench.py --config C2 --steps 64 --warmup 16 --no-cpu-baseline --no-e2e"),
     "c5": ("k_profile<64, false", "python3 bench.py --config C5 --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also"),
-    "c3": ("k_coverage<64>", "python3 scripts/profile_case.py C3"),
+    "c3": ("k_coverage<64", "python3 scripts/profile_case.py C3"),
     "c4": ("k_profile<64, true", "python3 scripts/profile_case.py C4"),
     "count": ("k_count", "python3 scripts/profile_case.py count"),
 }
