@@ -1012,6 +1012,7 @@ int BgzfFile::map(const std::string &path)
     p_->blocks.clear();
     return 0;
 }
+void BgzfFile::append_blocks(const BgzfBlock *b, size_t n) { p_->blocks.insert(p_->blocks.end(), b, b + n); }
 bool BgzfFile::block_at(uint64_t off, BgzfBlock &b) const { return parse_block(p_->f, off, b); }
 void BgzfFile::populate(const std::vector<std::pair<uint64_t, uint64_t>> &spans) const { populate_spans(p_->f, spans); }
 bool BgzfFile::read_span(uint64_t off, size_t len, uint8_t *dst) const

@@ -102,6 +102,8 @@ public:
     bool complete() const;                                    // is blocks() the whole table?
     int finish();
     int map(const std::string &path);                         // maps the file only (index-driven access)
+    // ... whose table then grows in file order as somebody else reads the headers (devdecode.hip: RawStream)
+    void append_blocks(const BgzfBlock *b, size_t n);
     const std::vector<BgzfBlock> &blocks() const;
     const uint8_t *data() const;                              // the mapped (compressed) file
     size_t size() const;

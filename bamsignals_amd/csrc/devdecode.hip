@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -492,6 +493,28 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
     return hipGetLastError();
 }
 
+// a launch of nothing (n = 0: every lane leaves at once) on the streams a decode is about to use: a session's first
+// launch of k_inflate costs 9 ms beyond the kernel (the queue's first use, the kernel's first dispatch) -- time a
+// streamed decode has anyway while the head of the file travels
+void warm_inflate(hipStream_t st, hipStream_t crc_st, const uint32_t *crc_tables)
+{
+    const int lanes = inflate_lanes_per_wave();
+    const size_t lds_pad = inflate_lds_pad();
+    const int64_t n = 0;
+    switch (lanes) {
+    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3(1), dim3(64), 64 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
+    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3(1), dim3(32), 32 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
+    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3(1), dim3(16), 16 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
+    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3(1), dim3(4), 4 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
+    default: hipLaunchKernelGGL(k_inflate<8>, dim3(1), dim3(8), 8 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
+    }
+    // (k_crc32 stages its tables before its lanes look at n: they must be there)
+    if (crc_st && crc_tables) hipLaunchKernelGGL(k_crc32, dim3(1), dim3(64), 0, crc_st, nullptr, nullptr, n, crc_tables, nullptr);
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(st);
+    if (crc_st) (void)hipStreamSynchronize(crc_st);
+}
+
 inline double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -511,6 +534,17 @@ struct Staging {
     // made and destroyed six of them (two shares x three)
     hipStream_t s_copy = nullptr, s_inflate = nullptr, s_crc = nullptr;
     hipEvent_t ev_inflated[2] = {nullptr, nullptr}, ev_crc_done[2] = {nullptr, nullptr};
+    uint32_t *d_crc_tables = nullptr;      // the 8 x 256 CRC32 tables on this device: uploaded once
+    int ensure_crc_tables(hipStream_t st)
+    {
+        if (d_crc_tables) return BSIG_OK;
+        uint32_t *p = nullptr;
+        HIP_TRY(bsig::metered_malloc((void **)&p, 8 * 256 * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(p, bsig::crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        d_crc_tables = p;
+        return BSIG_OK;
+    }
     int ensure_streams()
     {
         if (!s_copy) HIP_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
@@ -536,6 +570,28 @@ struct Staging {
             if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
         }
         cap = bytes;
+        return BSIG_OK;
+    }
+    // the raw file stream of a streamed decode (RawStream below): a page-locked pair, events and a stream of its
+    // own, held (raw_mu) by one streamed decode at a time -- beside whoever holds `mu` for a share
+    std::mutex raw_mu;
+    uint8_t *raw_buf[2] = {nullptr, nullptr};
+    size_t raw_cap = 0;
+    hipEvent_t raw_ev[2] = {nullptr, nullptr};
+    hipStream_t s_raw = nullptr;
+    int ensure_raw(size_t bytes)
+    {
+        if (!s_raw) HIP_TRY(hipStreamCreateWithFlags(&s_raw, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k)
+            if (!raw_ev[k]) HIP_TRY(hipEventCreateWithFlags(&raw_ev[k], hipEventDisableTiming));
+        if (raw_cap >= bytes) return BSIG_OK;
+        for (int k = 0; k < 2; ++k) {
+            if (raw_buf[k]) (void)bsig::metered_host_free(raw_buf[k]);
+            raw_buf[k] = nullptr;
+        }
+        raw_cap = 0;
+        for (int k = 0; k < 2; ++k) HIP_TRY(bsig::metered_host_malloc((void **)&raw_buf[k], bytes));
+        raw_cap = bytes;
         return BSIG_OK;
     }
 };
@@ -678,6 +734,209 @@ int copy_deflate_data(Staging &S, const bsig::BgzfFile &f, const bsig::BgzfBlock
     }
     return 0;
 }
+
+
+// ---- the compressed file as ONE device buffer, streamed ---------------------------------------------------------
+// What a large file's decode waited for on the host, pass after pass (north star, 3.07 GB, 327,000 blocks): the walk
+// over the head of the block table before anything else could start (12 ms), the first pass's compressed bytes
+// (21 ms), the rest of the table (20 ms), the next share's first bytes (13 ms) ... some 75 ms of a 240-ms decode in
+// which the GPU had nothing to do.  All of it is the same bytes fetched twice -- once for the headers, 96 bytes at
+// a time, once for the data -- and fetched in the order of the passes' needs.  RawStream reads the file ONCE, front
+// to back, in 32-MB chunks through a page-locked pair (pread: page cache -> staging), sends every chunk to its FILE
+// OFFSET in one device buffer the size of the file, and reads the block headers off the chunk that was sent last
+// while the pool reads the next one.  Consumers ask for "n blocks tabulated" and "the file up to byte x is in
+// HBM"; a block's deflate data is at d_file + coff + doff, nothing is packed.  The GPU's first round of blocks
+// can start when 0.5 GB has arrived, and from then on the passes follow the stream.
+struct RawStream {
+    using BgzfBlock = bsig::BgzfBlock;
+    using BgzfFile = bsig::BgzfFile;
+    static constexpr int kNeedsCpuPath = bsig::kNeedsCpuPath;
+    // the serial walk over the block headers, fed with consecutive chunks of the file
+    struct Walk {
+        uint64_t next = 0;                    // file offset of the next block's header
+        std::vector<uint8_t> carry;           // file bytes [carry_off, end of the chunks seen) while a block spans chunks
+        uint64_t carry_off = 0;
+        static uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+        static uint32_t rd32(const uint8_t *p) { return rd16(p) | (rd16(p + 2) << 16); }
+        // the block whose header is at p (file offset off, `avail` bytes there): 0 = b filled, 1 = more bytes needed,
+        // -1 = not something this walk takes (the mapped walk of the ordinary path owns the odd cases and the errors)
+        static int parse(const uint8_t *p, uint64_t avail, uint64_t off, uint64_t size, BgzfBlock &b)
+        {
+            if (avail < 18) return 1;
+            if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return -1;
+            const uint32_t xlen = rd16(p + 10);
+            if (xlen > 64) return -1;
+            if (avail < 12 + xlen) return 1;
+            uint32_t bsize = 0;
+            bool found = false;
+            for (uint32_t x = 0; x + 4 <= xlen;) {
+                const uint8_t *s = p + 12 + x;
+                const uint32_t slen = rd16(s + 2);
+                if (s[0] == 'B' && s[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = rd16(s + 4); found = true; }
+                x += 4 + slen;
+            }
+            if (!found) return -1;
+            b.coff = off;
+            b.csize = bsize + 1;
+            if (off + b.csize > size || b.csize < 12 + xlen + 8) return -1;
+            if (avail < b.csize) return 1;
+            b.doff = 12 + xlen;
+            b.dlen = b.csize - b.doff - 8;
+            b.crc = rd32(p + b.csize - 8);
+            b.isize = rd32(p + b.csize - 4);
+            return b.isize > 65536u ? -1 : 0;
+        }
+        // the chunk [c0, c0 + len) of the file; the blocks that end inside it are appended to `out`
+        int chunk(const uint8_t *buf, uint64_t c0, uint64_t len, uint64_t size, std::vector<BgzfBlock> &out)
+        {
+            const uint64_t c1 = c0 + len;
+            BgzfBlock b;
+            if (next < c0) {
+                // a block begun in an earlier chunk: completed with the head of this one
+                const uint64_t take = std::min<uint64_t>(len, 65536u + 128u);
+                carry.insert(carry.end(), buf, buf + take);
+                while (next < c0) {
+                    const int r = parse(carry.data() + (next - carry_off), carry_off + carry.size() - next, next, size, b);
+                    if (r < 0) return -1;
+                    if (r > 0) {
+                        // (chunks smaller than a block -- tests: the carry then holds everything up to c1)
+                        if (c1 == size || take != len) return -1;
+                        carry.erase(carry.begin(), carry.begin() + (long)(next - carry_off));
+                        carry_off = next;
+                        return 0;
+                    }
+                    out.push_back(b);
+                    next += b.csize;
+                }
+                carry.clear();
+            }
+            while (next < c1) {
+                const int r = parse(buf + (next - c0), c1 - next, next, size, b);
+                if (r < 0) return -1;
+                if (r > 0) {
+                    if (c1 == size) return -1;                      // the file ends inside a block
+                    carry.assign(buf + (next - c0), buf + len);
+                    carry_off = next;
+                    return 0;
+                }
+                out.push_back(b);
+                next += b.csize;
+            }
+            return 0;
+        }
+    };
+
+    const BgzfFile &f;
+    const int device, threads;
+    Staging &S;
+    const size_t chunk;
+    uint8_t *const d_file;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<BgzfBlock> blocks;      // tabulated so far, in file order
+    uint64_t on_device = 0;             // file bytes [0, on_device) have landed in d_file
+    bool done = false;                  // the table is complete and the whole file has landed
+    int rc = 0;                         // != 0: the stream gave up (kNeedsCpuPath, or an error)
+    std::atomic<bool> stop{false};
+    std::thread th;
+    double t_read = 0, t_half = 0;      // the stream's own time: reading chunks, waiting for a free half
+
+    RawStream(const BgzfFile &file, int dev, int thr, Staging &st, size_t chunk_bytes, uint8_t *dst)
+        : f(file), device(dev), threads(thr), S(st), chunk(chunk_bytes), d_file(dst) {}
+    ~RawStream() { halt(); }
+    void start()
+    {
+        // (no thread to be had -- std::system_error must not cross the C ABI: the stream runs here, ahead of its readers)
+        try { th = std::thread([this] { run(); }); } catch (const std::system_error &) { run(); }
+    }
+    // ends the stream (nothing is in flight into d_file afterwards)
+    void halt()
+    {
+        stop.store(true);
+        if (th.joinable()) th.join();
+    }
+    void run()
+    {
+        (void)hipSetDevice(device);
+        const uint64_t size = f.size();
+        const uint64_t n_chunks = (size + chunk - 1) / chunk;
+        const size_t per_run = std::min<size_t>(chunk, (size_t)1 << 20);          // a pool task reads about this much
+        bool used[2] = {false, false};
+        uint64_t end_of[2] = {0, 0};
+        Walk w;
+        std::vector<BgzfBlock> fresh;
+        int bad_rc = 0;
+        // iteration k reads chunk k into half k & 1 and, beside the reads, walks the headers of chunk k - 1 in the
+        // other half (one more iteration walks the last chunk)
+        for (uint64_t k = 0; k <= n_chunks && !bad_rc && !stop.load(); ++k) {
+            const int h = (int)(k & 1);
+            const uint64_t c0 = k * chunk, len = k < n_chunks ? std::min<uint64_t>(chunk, size - c0) : 0;
+            uint64_t landed = 0;
+            if (len && used[h]) {
+                const double t0 = now_s();
+                const hipError_t e = hipEventSynchronize(S.raw_ev[h]);
+                t_half += now_s() - t0;
+                if (e != hipSuccess) { bad_rc = fail(BSIG_ERR_DEVICE, "streaming the file to the device failed: %s", hipGetErrorString(e)); break; }
+                landed = end_of[h];
+            }
+            const int64_t n_runs = (int64_t)((len + per_run - 1) / per_run);
+            const int walk_prev = k > 0 ? 1 : 0;
+            const uint64_t p0 = walk_prev ? (k - 1) * chunk : 0, plen = walk_prev ? std::min<uint64_t>(chunk, size - p0) : 0;
+            fresh.clear();
+            std::atomic<int> bad(0);
+            int walk_rc = 0;
+            const double t0 = now_s();
+            bsig::pool_for(n_runs + walk_prev, threads, [&](int64_t q) {
+                if (walk_prev && q == 0) { walk_rc = w.chunk(S.raw_buf[h ^ 1], p0, plen, size, fresh); return; }
+                const uint64_t at = (uint64_t)(q - walk_prev) * per_run;
+                if (!f.read_span(c0 + at, (size_t)std::min<uint64_t>(per_run, len - at), S.raw_buf[h] + at)) bad.store(1);
+            });
+            t_read += now_s() - t0;
+            if (bad.load() || walk_rc) { bad_rc = kNeedsCpuPath; break; }        // (the ordinary path reports what is wrong)
+            if (len) {
+                hipError_t e = hipMemcpyAsync(d_file + c0, S.raw_buf[h], len, hipMemcpyHostToDevice, S.s_raw);
+                if (e == hipSuccess) e = hipEventRecord(S.raw_ev[h], S.s_raw);
+                if (e != hipSuccess) { bad_rc = fail(BSIG_ERR_DEVICE, "streaming the file to the device failed: %s", hipGetErrorString(e)); break; }
+                used[h] = true;
+                end_of[h] = c0 + len;
+            }
+            if (used[h ^ 1] && hipEventQuery(S.raw_ev[h ^ 1]) == hipSuccess) landed = std::max(landed, end_of[h ^ 1]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                blocks.insert(blocks.end(), fresh.begin(), fresh.end());
+                on_device = std::max(on_device, landed);
+            }
+            cv.notify_all();
+        }
+        const hipError_t e = hipStreamSynchronize(S.s_raw);            // whatever happened: nothing is in flight any more
+        if (!bad_rc && e != hipSuccess) bad_rc = fail(BSIG_ERR_DEVICE, "streaming the file to the device failed: %s", hipGetErrorString(e));
+        if (!bad_rc && !stop.load() && w.next != size) bad_rc = kNeedsCpuPath;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (bad_rc) rc = bad_rc;
+            else if (stop.load()) rc = kNeedsCpuPath;
+            else { on_device = size; done = true; }
+        }
+        cv.notify_all();
+    }
+    // waits until n blocks are tabulated or the table is complete; the blocks [from, have) are appended to `to`
+    int wait_blocks(size_t n, size_t from, std::vector<BgzfBlock> &to, bool &complete)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return rc || done || blocks.size() >= n; });
+        if (rc) return rc;
+        to.insert(to.end(), blocks.begin() + (long)std::min(from, blocks.size()), blocks.end());
+        complete = done;
+        return BSIG_OK;
+    }
+    // waits until the file's bytes [0, end) are in d_file
+    int wait_bytes(uint64_t end)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return rc || on_device >= end; });
+        return rc;
+    }
+};
 
 }  // namespace
 
@@ -877,12 +1136,15 @@ constexpr size_t kOverlapBlocks = 4;
 // Returns BSIG_OK, kNeedsCpuPath (this file / this split cannot be proven on the device), or an error.
 // more_follow: f.blocks() is only the head of the file's table (BgzfFile::open_progressive): the share cannot be
 // the stream's last, whatever its end.
+// raw: see RawStream.
 // after_first_pass(reads, stream bytes): called once, when the share's first pass knows how many reads its bytes held
 // (the whole-file decode sizes its reservation of the resident columns by it).
 int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const std::vector<uint64_t> &uoff, size_t Bbeg,
                  size_t Bend, int threads, bool gpu_inflate, ShareOut &R, bool more_follow = false, bool no_ramp = false,
-                 const std::function<void(int64_t, uint64_t)> *after_first_pass = nullptr)
+                 const std::function<void(int64_t, uint64_t)> *after_first_pass = nullptr, RawStream *raw = nullptr)
 {
+    // raw: the compressed file is (being) streamed into raw->d_file at its file offsets (GPU inflate only): nothing
+    // is packed or copied here, a pass waits until the stream has passed its last block
     const std::vector<BgzfBlock> &blocks = f.blocks();
     const size_t nb = blocks.size();
     const bool first_share = Bbeg == 0, last_share = Bend == nb && !more_follow;
@@ -971,8 +1233,9 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     const bool two_views = gpu_inflate && n_pass > 1 && getenv("BAMSIGNALS_TWO_VIEWS") && !strcmp(getenv("BAMSIGNALS_TWO_VIEWS"), "1");
     if (two_views) HIP_TRY(tmp.alloc(&d_view2[1], view_bytes));
     uint8_t *const d_data2[2] = {d_view2[0] + carry_cap, d_view2[1] + carry_cap};     // where every chunk's own bytes begin
+    if (raw && !gpu_inflate) return fail(BSIG_ERR_ARG, "a streamed file is inflated on the GPU");
     if (gpu_inflate) {
-        HIP_TRY(tmp.alloc(&d_comp2[0], (size_t)max_comp + 64));
+        if (!raw) HIP_TRY(tmp.alloc(&d_comp2[0], (size_t)max_comp + 64));
         HIP_TRY(tmp.alloc(&d_lens2[0], max_blk * (size_t)bsig_inflate::kLensBytes));
         HIP_TRY(tmp.alloc(&d_jobs2[0], max_blk));
         d_lens2[1] = d_lens2[0]; d_jobs2[1] = d_jobs2[0];
@@ -982,19 +1245,21 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         }
         HIP_TRY(tmp.alloc(&d_status, 4));
         HIP_TRY(hipMemsetAsync(d_status, 0, 4 * sizeof(int), st));
-        if (crc_check_enabled()) {
-            HIP_TRY(tmp.alloc(&d_crc_tables, 8 * 256));
-            HIP_TRY(hipMemcpyAsync(d_crc_tables, crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        }
         d_comp2[1] = d_comp2[0];
-        if (n_pass > 1) HIP_TRY(tmp.alloc(&d_comp2[1], (size_t)max_comp + 64));     // several passes: two buffers
+        if (n_pass > 1 && !raw) HIP_TRY(tmp.alloc(&d_comp2[1], (size_t)max_comp + 64));     // several passes: two buffers
+        if (raw) d_comp2[0] = d_comp2[1] = raw->d_file;
     }
 
     diag_mark("  scratch allocations");
     Staging &S = staging_for(ctx->device);
     std::lock_guard<std::mutex> lock(S.mu);
-    int rc = S.ensure(batch_bytes);
+    int rc = S.ensure(raw ? 0 : batch_bytes);            // (a streamed file has its own page-locked pair)
     if (rc) return rc;
+    if (gpu_inflate && crc_check_enabled()) {
+        rc = S.ensure_crc_tables(st);
+        if (rc) return rc;
+        d_crc_tables = S.d_crc_tables;
+    }
     diag_mark("  page-locked staging");
     volatile int *status2 = S.h_flags;           // [q]: k_inflate's status word of the pass in view q
     status2[0] = status2[1] = 0;
@@ -1045,6 +1310,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     bool crc_pending = false;
     int pass = 0;
     auto start_prefetch = [&](size_t b0, int which) {
+        if (raw) return;
         pf.B0 = b0;
         pf.B1 = view_end(chunk_end(b0));
         auto body = [&, which] {
@@ -1136,6 +1402,16 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
             // read-back of the status word, nothing is waited for.
             auto join_bytes = [&](size_t b0, size_t bv, int p) -> int {
                 const double tj = now_s();
+                if (raw) {
+                    const int r = raw->wait_bytes(blocks[bv - 1].coff + blocks[bv - 1].csize);
+                    R.t_wait += now_s() - tj;
+                    if (r) return r;
+                    in_off.resize(bv - b0);
+                    for (size_t k = b0; k < bv; ++k) in_off[k - b0] = blocks[k].coff + blocks[k].doff;
+                    if (getenv("BSIG_DIAG_DECODE"))
+                        fprintf(stderr, "pass %d: %zu blocks, waited %.1f ms for the stream to pass them\n", p, bv - b0, (now_s() - tj) * 1e3);
+                    return BSIG_OK;
+                }
                 pf.join();
                 R.t_wait += now_s() - tj;
                 if (pf.rc) return pf.rc < 0 ? pf.rc : fail(BSIG_ERR_DEVICE, "copying the compressed bytes failed (HIP error %d)", pf.rc);
@@ -1155,11 +1431,14 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
                 jobs.resize(bv - b0);
                 for (size_t k = b0; k < bv; ++k)
                     jobs[k - b0] = InflateJob{in_off[k - b0], uoff[k] - uoff[b0], blocks[k].dlen, blocks[k].isize, blocks[k].crc, 0};
+                const double ti = now_s();
                 hipError_t e = hipMemcpyAsync(d_jobs2[q], jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice, crc.inf);
+                if (getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "pass %d: job list built and queued in %.2f ms\n", p, (now_s() - ti) * 1e3);
                 if (e == hipSuccess)
                     e = launch_inflate(d_comp2[p & 1], d_jobs2[q], (int64_t)jobs.size(), d_data2[q], d_lens2[q], d_status, d_crc_tables, crc.inf,
                                        crc.st, crc.inflated[q], d_status + 1, crc.done[q]);
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)&status2[q], d_status, sizeof(int), hipMemcpyDeviceToHost, crc.inf);
+                if (getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "pass %d: inflate + CRC queued %.2f ms after the job list\n", p, (now_s() - ti) * 1e3);
                 return e;
             };
             if (pass == 0) {
@@ -1349,8 +1628,10 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
     pf.join();
     if (d_view2[1] != d_view2[0]) tmp.give_back(d_view2[1]);
     tmp.give_back(d_view2[0]);
-    if (d_comp2[1] != d_comp2[0]) tmp.give_back(d_comp2[1]);
-    tmp.give_back(d_comp2[0]);
+    if (!raw) {
+        if (d_comp2[1] != d_comp2[0]) tmp.give_back(d_comp2[1]);
+        tmp.give_back(d_comp2[0]);
+    }
     if (d_lens2[1] != d_lens2[0]) tmp.give_back(d_lens2[1]);
     tmp.give_back(d_lens2[0]);
     if (d_jobs2[1] != d_jobs2[0]) tmp.give_back(d_jobs2[1]);
@@ -1421,6 +1702,212 @@ int finish_scan(const std::string &path, FileScan &F)
     return rc;
 }
 
+
+// A large file through RawStream (above): shares of ONE round of inflate lanes each (57,344 blocks: a launch of
+// k_inflate lasts a block's latency per round however full, so a round is the smallest pass that wastes nothing),
+// every share decoded as soon as the stream has tabulated its blocks and carried their bytes past; the shares are
+// joined like the shares of several GPUs -- every chain must end where the next begins, the reads must stay in
+// order.  taken = false (and BSIG_OK): not a file for this route (small, huge, CPU inflate, switched off) -- the
+// caller takes the ordinary one; so it does on kNeedsCpuPath.
+int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads, bsig_reads **out, bool &taken, double *T)
+{
+    taken = false;
+    if (const char *e = getenv("BAMSIGNALS_STREAM")) if (!strcmp(e, "0")) return BSIG_OK;
+    if (const char *e = getenv("BAMSIGNALS_INFLATE")) if (strcmp(e, "gpu")) return BSIG_OK;
+    const double t_begin = now_s();
+    FileScan F;
+    if (F.f.map(path)) return BSIG_OK;                                     // (the ordinary route reports it)
+    const uint64_t size = F.f.size();
+    uint64_t min_bytes = (uint64_t)256 << 20;
+    if (const char *e = getenv("BAMSIGNALS_STREAM_MIN_MB")) min_bytes = (uint64_t)std::max(0ll, atoll(e)) << 20;
+    // (the file sits in HBM whole while it is decoded: beyond this the ordinary route's pass-sized buffers)
+    const uint64_t max_bytes = env_mb("BAMSIGNALS_STREAM_MAX_MB", 24576);
+    if (size < min_bytes || size > max_bytes || size < 28) return BSIG_OK;
+    if (bam_read_header(path, F.hdr)) return BSIG_OK;
+    const size_t round_blocks = inflate_round_blocks(ctx->device);
+    if (!round_blocks) return BSIG_OK;
+    size_t chunk = (size_t)32 << 20;
+    if (const char *e = getenv("BAMSIGNALS_STREAM_CHUNK_KB")) if (atoll(e) > 0) chunk = (size_t)atoll(e) << 10;      // (tests: blocks across chunks)
+    HIP_TRY(hipSetDevice(ctx->device));
+    Staging &S = staging_for(ctx->device);
+    std::lock_guard<std::mutex> raw_lock(S.raw_mu);
+    // a session's first decode: the streams of the shares are made (12 ms) and the first launch of k_inflate is paid
+    // (9 ms) by a thread of its own, beside the pinning of the stream's pair and while the head of the file travels
+    // (the shares take S.mu: they wait for it if they must)
+    struct Side {
+        std::thread th;
+        ~Side() { if (th.joinable()) th.join(); }
+    } side;
+    if (!S.s_inflate) {
+        const int dev = ctx->device;
+        auto body = [&S, dev] {
+            (void)hipSetDevice(dev);
+            std::lock_guard<std::mutex> lk(S.mu);
+            if (S.ensure(0) != BSIG_OK || S.ensure_streams() != BSIG_OK) return;
+            const bool crc = crc_check_enabled() && S.ensure_crc_tables(S.s_crc) == BSIG_OK;
+            warm_inflate(S.s_inflate, crc ? S.s_crc : nullptr, S.d_crc_tables);
+            // ... and the first copy between pageable memory and the device on that stream (the shares' job lists):
+            // the runtime sets up its staging on a stream's first such copy, 7 ms.  (The same for the context's own
+            // stream was tried: by then this thread is what the first share waits for.)
+            void *q = nullptr;
+            size_t got = 0;
+            if (bsig::block_alloc(dev, (size_t)1 << 20, 2.0, &q, &got) == hipSuccess) {
+                std::vector<uint8_t> h((size_t)1 << 20, 0);
+                (void)hipMemcpyAsync(q, h.data(), h.size(), hipMemcpyHostToDevice, S.s_inflate);
+                (void)hipMemcpyAsync(h.data(), q, h.size(), hipMemcpyDeviceToHost, S.s_inflate);
+                (void)hipStreamSynchronize(S.s_inflate);
+                bsig::block_free(dev, q, got);
+            }
+            (void)hipGetLastError();
+        };
+        try { side.th = std::thread(body); } catch (const std::system_error &) {}
+    }
+    int rc = S.ensure_raw(chunk);
+    if (rc) return rc;
+    ScratchPool file_pool(ctx->device, ctx->stream);
+    uint8_t *d_file = nullptr;
+    HIP_TRY(file_pool.alloc(&d_file, (size_t)size + 64 + ScratchPool::kSmall));      // (a block of its own: it goes back before the layout)
+    diag_mark("streamed: page-locked pair + the file's device buffer");
+    RawStream rs(F.f, ctx->device, threads, S, chunk, d_file);
+    const double t_stream = now_s();
+    rs.start();
+    double fill_wait_s = 0.010;
+    if (const char *e = getenv("BAMSIGNALS_STREAM_FILL_MS")) fill_wait_s = atof(e) * 1e-3;
+
+    Reservation reserved;
+    g_reserved_bytes = 0;
+    g_reserve_wait = 0;
+    const std::function<void(int64_t, uint64_t)> reserve = [&](int64_t n_first, uint64_t bytes_first) {
+        if (n_first <= 0 || bytes_first == 0 || F.f.blocks().empty()) return;
+        const BgzfBlock &lb = F.f.blocks().back();
+        const double stream_bytes = (double)F.uoff.back() * (double)size / (double)std::max<uint64_t>(lb.coff + lb.csize, 1);
+        const double est_reads = (double)n_first * stream_bytes / (double)bytes_first;
+        if (est_reads < 1e7) return;
+        const size_t want = (size_t)(est_reads * 8.6 * 1.10) + ((size_t)32 << 20);
+        reserved.start(ctx->device, want);
+        if (reserved.started) g_reserved_bytes = (double)want;
+    };
+
+    std::vector<ShareOut> sh;
+    sh.reserve(64);
+    std::vector<BgzfBlock> fresh;
+    F.uoff.assign(1, 0);
+    size_t B = 0;
+    bool last = false;
+    double t_first_table = 0;
+    while (!last) {
+        // A share is what the stream has tabulated by now -- at least a quarter of a round, at most a round (with the
+        // kOverlapBlocks it sees beyond its own).  Where the GPU is the slower side (the north star's small blocks:
+        // 5,000 arrive per ms, a round takes 18 ms) every share is a full round; where the stream is (real-shaped
+        // records, 33-KB blocks: a round arrives in 60 ms and is inflated in 23) the shares follow the stream a
+        // third of a round at a time instead of waiting for rounds to fill.  k_inflate's time follows the number of
+        // blocks, above a floor: 10.5 ms for 14,556 blocks, 11.6 for 25,906, 13.0 for 40,458, 17.8 for 57,344.
+        const size_t max_own = round_blocks > 2 * kOverlapBlocks ? round_blocks - kOverlapBlocks : round_blocks;
+        const size_t min_own = std::max<size_t>(max_own / 4, 1);
+        const size_t want_end = B + max_own;
+        bool complete = false;
+        fresh.clear();
+        const double tw = now_s();
+        rc = rs.wait_blocks(B + min_own + kOverlapBlocks, F.f.blocks().size(), fresh, complete);
+        if (rc) break;
+        F.f.append_blocks(fresh.data(), fresh.size());
+        for (const BgzfBlock &b : fresh) F.uoff.push_back(F.uoff.back() + b.isize);
+        if (!complete && F.f.blocks().size() < want_end + kOverlapBlocks) {
+            // ... unless the round will be full in less than a launch's floor (k_inflate: 10 ms for a quarter of a
+            // round, 18 ms for a whole one): then a launch more costs more than the wait
+            const double per_s = (double)F.f.blocks().size() / std::max(now_s() - t_stream, 1e-4);
+            const double fill_s = (double)(want_end + kOverlapBlocks - F.f.blocks().size()) / per_s;
+            if (fill_s <= fill_wait_s) {
+                fresh.clear();
+                rc = rs.wait_blocks(want_end + kOverlapBlocks, F.f.blocks().size(), fresh, complete);
+                if (rc) break;
+                F.f.append_blocks(fresh.data(), fresh.size());
+                for (const BgzfBlock &b : fresh) F.uoff.push_back(F.uoff.back() + b.isize);
+            }
+        }
+        if (B == 0) t_first_table = now_s() - t_begin; else T[2] += now_s() - tw;
+        const size_t nb = F.f.blocks().size();
+        if (nb == 0 || (complete && F.uoff.back() < 12)) { rc = kNeedsCpuPath; break; }
+        if (B == 0) {
+            // the inflate engine, decided like tabulate() decides it: from the head of the table, scaled to the file
+            if (!getenv("BAMSIGNALS_INFLATE")) {
+                const BgzfBlock &lb = F.f.blocks().back();
+                const double scale = complete ? 1.0 : (double)size / (double)std::max<uint64_t>(lb.coff + lb.csize, 1);
+                uint64_t comp = 0;
+                for (const BgzfBlock &b : F.f.blocks()) comp += b.dlen;
+                if (!gpu_inflate_pays((size_t)((double)nb * scale), (uint64_t)((double)comp * scale), (uint64_t)((double)F.uoff.back() * scale), threads)) {
+                    rs.halt();
+                    return BSIG_OK;                                        // CPU inflate: the ordinary route
+                }
+            }
+            diag_mark("streamed: table of the first round");
+        }
+        // (nothing but empty blocks left -- the end-of-file marker: no share; the check below sees that the last
+        // chain ran to the end of the stream)
+        if (B > 0 && complete && F.uoff[nb] == F.uoff[B]) break;
+        // (a few blocks beyond a round, all in view of this share anyway: they go with it)
+        const size_t Bend = complete ? (nb <= want_end + kOverlapBlocks ? nb : want_end) : std::min(want_end, nb - kOverlapBlocks);
+        last = complete && Bend == nb;
+        sh.emplace_back();
+        rc = decode_share(ctx, F.f, F.hdr, F.uoff, B, Bend, threads, true, sh.back(), !complete, true, B == 0 ? &reserve : nullptr, &rs);
+        if (getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "streamed: share of blocks [%zu, %zu) done (rc %d)\n", B, Bend, rc);
+        if (rc) break;
+        B = Bend;
+    }
+    rs.halt();
+    if (getenv("BSIG_DIAG_DECODE"))
+        fprintf(stderr, "streamed: the stream read for %.1f ms and waited %.1f ms for a free half\n", rs.t_read * 1e3, rs.t_half * 1e3);
+    if (rc) return rc;
+    file_pool.give_back(d_file);
+    T[0] = t_first_table;
+    diag_mark("streamed: all shares");
+    // ---- the shares must meet and stay in order ---------------------------------------------------------------
+    int64_t total = 0;
+    int32_t prev_rid = -1, prev_pos = -1;
+    for (size_t g = 0; g < sh.size(); ++g) {
+        if (g && sh[g - 1].chain_end != sh[g].chain_first) return kNeedsCpuPath;
+        if (sh[g].n_reads) {
+            if (sh[g].first_rid < prev_rid || (sh[g].first_rid == prev_rid && sh[g].first_pos < prev_pos)) return kNeedsCpuPath;
+            prev_rid = sh[g].last_rid;
+            prev_pos = sh[g].last_pos;
+        }
+        if (g + 1 == sh.size() && sh[g].chain_end != F.uoff.back()) return kNeedsCpuPath;      // the stream ends behind its last record
+        total += sh[g].n_reads;
+        T[1] += sh[g].t_inflate;
+        T[2] += sh[g].t_wait;
+        T[3] += sh[g].t_gpu;
+    }
+    // first read of every reference: the first share that knows the reference says, moved behind the reads of the
+    // shares before it (the rule of join_shares)
+    const int32_t n_ref = (int32_t)F.hdr.names.size();
+    std::vector<std::vector<long long>> rf(sh.size(), std::vector<long long>((size_t)n_ref + 1, -1));
+    for (size_t g = 0; g < sh.size(); ++g)
+        HIP_TRY(hipMemcpyAsync(rf[g].data(), sh[g].d_ref_first, rf[g].size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<long long> first((size_t)n_ref + 1, -1);
+    int64_t before = 0;
+    for (size_t g = 0; g < sh.size(); ++g) {
+        for (size_t q = 0; q < first.size(); ++q)
+            if (first[q] < 0 && rf[g][q] >= 0) first[q] = before + rf[g][q];
+        before += sh[g].n_reads;
+    }
+    ShareOut &L = sh.back();
+    HIP_TRY(hipMemcpyAsync(L.d_ref_first, first.data(), first.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<std::unique_ptr<Piece>> pieces;
+    for (ShareOut &g : sh)
+        for (auto &pp : g.pieces) pieces.push_back(std::move(pp));
+    double t_join = 0, t_layout = 0;
+    rc = finish_reads(ctx, ctx->stream, *L.tmp, pieces, total, F.hdr, L.d_ref_first, t_join, t_layout, out, &reserved);
+    g_reserve_wait = reserved.t_wait;
+    if (rc) return rc;
+    T[3] += t_join;
+    T[5] = t_layout;
+    T[4] = now_s() - t_begin;
+    taken = true;
+    return BSIG_OK;
+}
+
 }  // namespace
 
 // Whole BAM -> bsig_reads on ctx's device.  Returns BSIG_OK, kNeedsCpuPath, or an error.
@@ -1436,8 +1923,16 @@ int reads_from_bam_device(bsig_ctx *ctx, const std::string &path, int threads, b
     for (int k = 0; k < 6; ++k) T[k] = 0;
     const double t_begin = now_s();
     *out = nullptr;
-    FileScan F;
     diag_mark(nullptr);
+    {
+        // large files: the file streamed into HBM once, decoded round by round behind the stream
+        bool taken = false;
+        const int rs = reads_from_bam_streamed(ctx, path, threads, out, taken, T);
+        if (taken || (rs != BSIG_OK && rs != kNeedsCpuPath)) return rs;
+        if (rs == kNeedsCpuPath && getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "streamed: declined, the ordinary route\n");
+        for (int k = 0; k < 6; ++k) T[k] = 0;
+    }
+    FileScan F;
     uint64_t head_bytes = env_mb("BAMSIGNALS_SCAN_HEAD_MB", 640);
     {
         const char *e = getenv("BAMSIGNALS_SCAN_HEAD_MB");

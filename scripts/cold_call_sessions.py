@@ -53,7 +53,7 @@ if len(variants) > 1:
     for v in range(len(variants)):
         print(variants[v], "median %.3f s" % float(np.median([r[0] for r in runs[v::len(variants)]])))
 for k, (t, st, err) in enumerate(runs):
-    if t > 1.25 * med:
+    if t > 1.25 * med or (os.environ.get("MARKS") and k < int(os.environ["MARKS"])):      # (MARKS=n: also the first n sessions')
         print("\n== session %d (%.3f s): stage marks" % (k, t))
         print("\n".join(l for l in err.splitlines() if "[decode]" in l or l.startswith("pass ")))
 shutil.rmtree(d, ignore_errors=True)

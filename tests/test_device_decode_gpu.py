@@ -346,6 +346,86 @@ def test_head_of_the_file_decoded_while_the_rest_is_tabulated(ctx, tmp_path, mon
         dev.close()
 
 
+def test_large_files_are_streamed_into_hbm_and_decoded_round_by_round(ctx, tmp_path, monkeypatch, capfd):
+    """Large files (GPU inflate) travel to HBM ONCE, front to back, into a device buffer at their file offsets; the
+    block table is read off the chunks on their way, and every round of inflate lanes is decoded as a share of its own
+    as soon as the stream has passed it (a share is what has been tabulated by then, a quarter of a round to a round)
+    -- the shares joined like the shares of several GPUs.  Forced here on small
+    files (the route starts at 256 MB) with rounds of a few blocks and chunks from smaller than a block (a block then
+    spans several chunks) to larger than the file: htslib's fixture, files whose records cross block borders, a
+    synthetic one with several references and an empty one between them; damaged files still get the CPU path's
+    messages."""
+    import re
+    from bamsignals_amd import _lib
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.bamio import BamFile
+    from bamsignals_amd.device import Reads
+    from bamsignals_amd.synth import synth_reads
+    monkeypatch.setenv("BAMSIGNALS_STREAM_MIN_MB", "0")
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu")
+    monkeypatch.setenv("BSIG_DIAG_DECODE", "1")
+    stream = gzip.decompress(open(BAM, "rb").read())
+    files = [(BAM, 99000)]
+    for k, sizes in enumerate(([4000, 9001, 517, 65000], [65536], [30000])):
+        p = tmp_path / ("straddle%d.bam" % k)
+        p.write_bytes(_bgzf(stream, sizes))
+        _empty_bai(str(p) + ".bai", 3)
+        files.append((str(p), 99000))
+    cols = synth_reads(1_500_000, [900_000, 70_000, 0, 400_000], seed=16, paired=True)
+    path = str(tmp_path / "syn.bam")
+    write_columns_as_bam(path, ["a", "b", "empty", "c"], cols)                # ~1,200 blocks
+    files.append((path, 1_500_000))
+    for f, n_reads in files:
+        for rnd, chunk_kb in ((7, "3"), (40, "100"), (64, "5000"), (100000, None)):
+            monkeypatch.setenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS", str(rnd))
+            if chunk_kb:
+                monkeypatch.setenv("BAMSIGNALS_STREAM_CHUNK_KB", chunk_kb)
+            else:
+                monkeypatch.delenv("BAMSIGNALS_STREAM_CHUNK_KB", raising=False)
+            if f == path and rnd == 7:
+                continue                                                      # (170 shares of seven blocks: slow, nothing new)
+            capfd.readouterr()
+            _, dev = _both_ways(ctx, f, monkeypatch)
+            assert dev.n_reads == n_reads
+            dev.close()
+            err = capfd.readouterr().err
+            assert "streamed: all shares" in err and "the ordinary route" not in err, (f, rnd, chunk_kb, err[-600:])
+            shares = [(int(a), int(b)) for a, b in re.findall(r"streamed: share of blocks \[(\d+), (\d+)\) done", err)]
+            assert shares[0][0] == 0 and all(x[1] == y[0] for x, y in zip(shares, shares[1:])), shares
+            own = rnd - 4 if rnd > 8 else rnd                                 # (a share sees four blocks beyond its own: one round in all)
+            assert all(0 < b - a <= own for a, b in shares[:-1]) and 0 < shares[-1][1] - shares[-1][0] <= own + 4, (rnd, shares)
+    # the engine choice still holds: a few badly compressible blocks are the CPU pool's, whatever the route
+    monkeypatch.delenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS")
+    monkeypatch.delenv("BAMSIGNALS_INFLATE")
+    capfd.readouterr()
+    _, dev = _both_ways(ctx, BAM, monkeypatch)
+    dev.close()
+    assert "streamed: all shares" not in capfd.readouterr().err
+    # damaged files: the stream (or a share) declines, the ordinary route and then the CPU path name the problem
+    monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu")
+    monkeypatch.setenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS", "5")
+    monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "1")
+    p = tmp_path / "trunc.bam"
+    p.write_bytes(_bgzf(stream[:-7], [60000]))
+    _empty_bai(str(p) + ".bai", 3)
+    with pytest.raises(_lib.BsigError, match="truncated"):
+        Reads.from_bam(ctx, BamFile(str(p)))
+    raw = bytearray(open(BAM, "rb").read())
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1
+    b2 = struct.unpack_from("<H", raw, bsize + 16)[0] + 1
+    raw[bsize + b2 - 8] ^= 0x5A
+    p = tmp_path / "crc.bam"
+    p.write_bytes(bytes(raw))
+    _empty_bai(str(p) + ".bai", 3)
+    with pytest.raises(_lib.BsigError, match="CRC"):
+        Reads.from_bam(ctx, BamFile(str(p)))
+    cutoff = tmp_path / "cutoff.bam"                                           # the file ends inside a block
+    cutoff.write_bytes(open(BAM, "rb").read()[:-40])
+    _empty_bai(str(cutoff) + ".bai", 3)
+    with pytest.raises(_lib.BsigError):
+        Reads.from_bam(ctx, BamFile(str(cutoff)))
+
+
 def test_inflate_kernel_keeps_its_state_in_registers(ctx):
     """k_inflate's per-lane state -- bit buffer, code counts, construction slots, deferred match words -- lives in
     registers and LDS.  Twice in round 3 a harmless-looking change (a select chain over eight words, a local array
