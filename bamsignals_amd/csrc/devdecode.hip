@@ -1771,8 +1771,8 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
     RawStream rs(F.f, ctx->device, threads, S, chunk, d_file);
     const double t_stream = now_s();
     rs.start();
-    double fill_wait_s = 0.010;
-    if (const char *e = getenv("BAMSIGNALS_STREAM_FILL_MS")) fill_wait_s = atof(e) * 1e-3;
+    double fill_env = -1;
+    if (const char *e = getenv("BAMSIGNALS_STREAM_FILL_MS")) fill_env = atof(e) * 1e-3;
 
     Reservation reserved;
     g_reserved_bytes = 0;
@@ -1813,11 +1813,18 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
         F.f.append_blocks(fresh.data(), fresh.size());
         for (const BgzfBlock &b : fresh) F.uoff.push_back(F.uoff.back() + b.isize);
         if (!complete && F.f.blocks().size() < want_end + kOverlapBlocks) {
-            // ... unless the round will be full in less than a launch's floor (k_inflate: 10 ms for a quarter of a
-            // round, 18 ms for a whole one): then a launch more costs more than the wait
-            const double per_s = (double)F.f.blocks().size() / std::max(now_s() - t_stream, 1e-4);
-            const double fill_s = (double)(want_end + kOverlapBlocks - F.f.blocks().size()) / per_s;
-            if (fill_s <= fill_wait_s) {
+            // ... unless the round will be full, or the file at its end, in less than a launch costs: a launch lasts
+            // at least one block's latency however few blocks it holds (10 ms for the north star's blocks, 20 ms for
+            // real-shaped ones -- 3,300 blocks left over for a launch of their own cost 21 ms), so what the stream
+            // brings within about half the last launch's time is worth waiting for.
+            const size_t have = F.f.blocks().size();
+            const BgzfBlock &lb = F.f.blocks().back();
+            const uint64_t seen = lb.coff + lb.csize;
+            const double per_s = (double)have / std::max(now_s() - t_stream, 1e-4);
+            const double left = (double)have * (double)(size - std::min(size, seen)) / (double)std::max<uint64_t>(seen, 1);
+            const double fill_s = std::min((double)(want_end + kOverlapBlocks - have), left) / per_s;
+            const double patience = fill_env >= 0 ? fill_env : sh.empty() ? 0.010 : std::max(0.010, 0.6 * sh.back().t_inflate);
+            if (fill_s <= patience) {
                 fresh.clear();
                 rc = rs.wait_blocks(want_end + kOverlapBlocks, F.f.blocks().size(), fresh, complete);
                 if (rc) break;
