@@ -1822,8 +1822,10 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
             const uint64_t seen = lb.coff + lb.csize;
             const double per_s = (double)have / std::max(now_s() - t_stream, 1e-4);
             const double left = (double)have * (double)(size - std::min(size, seen)) / (double)std::max<uint64_t>(seen, 1);
-            const double fill_s = std::min((double)(want_end + kOverlapBlocks - have), left) / per_s;
-            const double patience = fill_env >= 0 ? fill_env : sh.empty() ? 0.010 : std::max(0.010, 0.6 * sh.back().t_inflate);
+            const double to_round = (double)(want_end + kOverlapBlocks - have);
+            const double fill_s = std::min(to_round, left) / per_s;
+            // (the end of the file saves a whole launch: worth nearly a launch's time; a fuller round saves less)
+            const double patience = fill_env >= 0 ? fill_env : sh.empty() ? 0.010 : std::max(0.010, (left <= to_round ? 0.9 : 0.6) * sh.back().t_inflate);
             if (fill_s <= patience) {
                 fresh.clear();
                 rc = rs.wait_blocks(want_end + kOverlapBlocks, F.f.blocks().size(), fresh, complete);

@@ -426,6 +426,35 @@ def test_large_files_are_streamed_into_hbm_and_decoded_round_by_round(ctx, tmp_p
         Reads.from_bam(ctx, BamFile(str(cutoff)))
 
 
+@pytest.mark.timeout(300)
+def test_a_300_mb_file_takes_the_streamed_route_by_itself(ctx, tmp_path, monkeypatch, capfd):
+    """No knobs: 5e7 bare reads are a 300-MB BAM of 33,000 blocks -- beyond the 256 MB at which whole-file decodes are
+    streamed, and many enough blocks for the GPU to inflate them.  Same resident reads, same results as the CPU decode."""
+    from bamsignals_amd import write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    for k in ("BAMSIGNALS_STREAM", "BAMSIGNALS_STREAM_MIN_MB", "BAMSIGNALS_INFLATE", "BAMSIGNALS_INFLATE_ROUND_BLOCKS", "BAMSIGNALS_STREAM_CHUNK_KB"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("BSIG_DIAG_DECODE", "1")
+    ref_len = [120_000_000, 80_000_000, 0, 50_000_000]
+    cols = synth_reads(50_000_000, ref_len, seed=21, paired=True)
+    path = str(tmp_path / "mid.bam")
+    write_columns_as_bam(path, ["a", "b", "empty", "c"], cols, level=1)
+    del cols
+    assert os.path.getsize(path) > 256 << 20
+    capfd.readouterr()
+    _, dev = _both_ways(ctx, path, monkeypatch)
+    assert dev.n_reads == 50_000_000
+    dev.close()
+    err = capfd.readouterr().err
+    assert "streamed: all shares" in err and "the ordinary route" not in err, err[-600:]
+    # switched off, the same file takes the ordinary route to the same reads
+    monkeypatch.setenv("BAMSIGNALS_STREAM", "0")
+    _, dev = _both_ways(ctx, path, monkeypatch)
+    assert dev.n_reads == 50_000_000
+    dev.close()
+    assert "streamed:" not in capfd.readouterr().err
+
+
 def test_inflate_kernel_keeps_its_state_in_registers(ctx):
     """k_inflate's per-lane state -- bit buffer, code counts, construction slots, deferred match words -- lives in
     registers and LDS.  Twice in round 3 a harmless-looking change (a select chain over eight words, a local array
