@@ -100,6 +100,9 @@ struct BsigKParams {
     int32_t resolved;       // 1: `windows` holds one BsigResolved per tile, written by k_resolve_tiles in
                             // front of this launch (large launches: the tile's item and its windows then
                             // arrive in ONE memory round trip instead of two dependent ones)
+    int32_t pad_;
+    const uint8_t *ptab;    // the packed class's filter table for THESE parameters (BSIG_PACK_CODES bytes on the
+                            // device: bit 0 rejected, bit 1 reverse strand), made once per plan by k_make_ptab
 };
 
 #endif

@@ -23,6 +23,8 @@ hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, c
                          void *windows /* n_items * BSIG_MAX_CLASSES * 8 bytes (fixed read ranges: slices of heavy tiles), or NULL */,
                          bool resolve_first /* fill `windows` with k_resolve before the pileup launch */,
                          int32_t *out, hipStream_t st);
+// the packed class's filter table for P (BSIG_PACK_CODES bytes at `out`): once per plan
+hipError_t launch_make_ptab(const BsigReadsDev &R, const BsigKParams &P, uint8_t *out, hipStream_t st);
 hipError_t launch_resolve(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,
                           int64_t n_items, void *windows, hipStream_t st);
 hipError_t launch_count_heavy(const void *windows, int64_t n_items, int64_t heavy_reads,

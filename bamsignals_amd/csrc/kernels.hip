@@ -12,6 +12,7 @@
 //   k_span_hist / k_scatter / k_build_idx       one-time layout of the reads in HBM (bsig_types.h)
 //   k_visits    counts read visits for the roofline figure
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -57,6 +58,68 @@ __device__ __forceinline__ bool fm_rejected(const BsigKParams &P, uint32_t fm)
     return (mapq < P.mapqual) | ((P.requiredF & nf) != 0u) | ((P.filteredF & nf) == 0u);
 }
 // ... and what reads the template length (:332-333)
+// bamCount's whole per-read work without a branch (ref: src/bamsignals.cpp:326-363 with binsize = the range): `acc`
+// counts the read in its low half if it is one, passes the filters and has its 5' end in [glo, glo + gn), and in its
+// high half too if it lies on the reverse strand (a lane sees at most 32,768 reads of a tile, the heavy-tile ceiling)
+__device__ __forceinline__ void count_one(const BsigKParams &P, int glo, int gn, int p, int e, bool neg, bool rej, int tl,
+                                          bool valid, uint32_t &acc)
+{
+    bool ok = valid & !rej;
+    int offset = P.shift;
+    if (P.has_tlen_filter | P.midpoint) {                  // (uniform)
+        const int a = tl < 0 ? -tl : tl;
+        if (P.has_tlen_filter) ok = ok & (a >= P.tf0) & (a <= P.tf1);
+        if (P.midpoint) offset += a >> 1;
+    }
+    const int p5 = neg ? e - offset : p + offset;
+    ok = ok & ((unsigned)(p5 - glo) < (unsigned)gn);
+    acc += ok ? (neg ? 0x10001u : 1u) : 0u;
+}
+
+struct CountOne {
+    const BsigKParams &P;
+    int glo, gn;
+    uint32_t &acc;
+    __device__ __forceinline__ void operator()(int p, int e, bool neg, bool rej, int tl, bool valid) const
+    {
+        count_one(P, glo, gn, p, e, neg, rej, tl, valid, acc);
+    }
+    // four reads of the packed class (words w, table bytes from ptab; read k is one of the window's iff dj + k < nj,
+    // unsigned).  Without a template-length rule the 5' end relative to the interval comes straight out of the word:
+    // pos - glo + shift = d + cp and end - glo - shift = d + span + cm with d = (word - base) & mask.
+    __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
+                                         const uint8_t *__restrict__ ptab) const
+    {
+        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
+        if (P.has_tlen_filter | P.midpoint) {                  // (uniform)
+            auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
+                const int pos = base + (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
+                count_one(P, glo, gn, pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid, acc);
+            };
+            dec(w.x, b0, t.x, dj < nj);
+            dec(w.y, b1, t.y, dj + 1u < nj);
+            dec(w.z, b2, t.z, dj + 2u < nj);
+            dec(w.w, b3, t.w, dj + 3u < nj);
+            return;
+        }
+        // (plain arithmetic, no select: the compiler turns `neg ? a : b` into a diamond of exec masks here.  nm = all
+        // ones for a reverse-strand read, rj = all ones for a rejected one -- which pushes rel out of every interval)
+        const uint32_t cp = (uint32_t)(base - glo + P.shift), cd = (uint32_t)(-2 * P.shift);
+        auto rd = [&](uint32_t x, uint32_t b, uint32_t k) {
+            const uint32_t d = (x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u);
+            const uint32_t sp = (x >> BSIG_PACK_POS_BITS) & 0xFFu;
+            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31), rj = (uint32_t)((int32_t)(b << 31) >> 31);
+            const uint32_t rel = (d + cp + (nm & (sp + cd))) | rj;
+            const bool ok = (dj + k < nj) & (rel < (uint32_t)gn);
+            acc += ok ? ((nm & 0x10000u) | 1u) : 0u;
+        };
+        rd(w.x, b0, 0u);
+        rd(w.y, b1, 1u);
+        rd(w.z, b2, 2u);
+        rd(w.w, b3, 3u);
+    }
+};
+
 __device__ __forceinline__ bool tlen_rejected(const BsigKParams &P, int32_t tl)
 {
     if (!P.has_tlen_filter) return false;
@@ -69,17 +132,31 @@ constexpr uint32_t kPackPosMask = (uint32_t)kPackChunk - 1u;
 
 // Per launch and workgroup: what the flag/mapq filter says about every code of the packed class, one byte per
 // code in LDS (bit 0: rejected, bit 1: reverse strand).  The pair table is 2 KB and stays in L2.
+// The packed class's filter table (per code: bit 0 rejected by mapq / flag masks, bit 1 reverse strand) depends on
+// the file's pair table and the call's parameters only: it is made ONCE PER PLAN (k_make_ptab, 512 bytes on the
+// device, BsigKParams::ptab) and every workgroup copies it into its LDS -- one 16-byte load for half the lanes.
+// Every workgroup used to build it for itself: 90 vector instructions per wave, 13 % of what a north-star tile
+// issues, in launches that are bound by exactly those (NOTES_r04.md, section 9).
 template <int NT>
 __device__ __forceinline__ void build_ptab(uint8_t *ptab, const BsigReadsDev &R, const BsigKParams &P, int tid)
 {
-    const uint4 *src = reinterpret_cast<const uint4 *>(R.fmtab);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(ptab);
-    for (int v = tid; 4 * v < R.n_codes; v += NT) {
-        const uint4 f = src[v];
-        auto b = [&](uint32_t fm) { return (uint32_t)fm_rejected(P, fm) | ((fm >> 3) & 2u); };     // 0x10 >> 3
-        dst[v] = b(f.x) | b(f.y) << 8 | b(f.z) << 16 | b(f.w) << 24;
-    }
+    (void)R;
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.ptab);
+    uint4 *dst = reinterpret_cast<uint4 *>(ptab);
+    for (int v = tid; v < BSIG_PACK_CODES / 16; v += NT) dst[v] = src[v];
 }
+__global__ __launch_bounds__(128) void k_make_ptab(const BsigReadsDev R, const BsigKParams P, uint8_t *__restrict__ out)
+{
+    const int v = threadIdx.x;                              // four codes each: BSIG_PACK_CODES = 4 x 128
+    uint32_t word = 0;
+    if (4 * v < R.n_codes) {
+        const uint4 f = reinterpret_cast<const uint4 *>(R.fmtab)[v];
+        auto b = [&](uint32_t fm) { return (uint32_t)fm_rejected(P, fm) | ((fm >> 3) & 2u); };     // 0x10 >> 3
+        word = b(f.x) | b(f.y) << 8 | b(f.z) << 16 | b(f.w) << 24;
+    }
+    reinterpret_cast<uint32_t *>(out)[v] = word;
+}
+static_assert(BSIG_PACK_CODES == 4 * 128, "k_make_ptab: four codes per thread of one 128-thread workgroup");
 
 // The packed class's window of a tile: the reads whose pos lies in the bucket-rounded window [rlo, rhi) of the
 // reference, walked in chunks of kPackChunk bases (nearly always one): inside a chunk that starts at `base`,
@@ -226,10 +303,20 @@ __global__ void k_count_heavy(const uint2 *__restrict__ windows, int64_t n_items
 __device__ __forceinline__ uint32_t fm_of_class1(uint32_t w) { return (w & 0xFFFu) | ((w >> 12) & 0xFFu) << 16; }
 
 // four consecutive packed words (one lane's 16-B load) of a chunk that starts at `base`
+// a per-read functor may bring its own treatment of four packed reads at once (`quad`): bamCount does
+template <typename F, typename = void>
+struct has_quad : std::false_type {};
+template <typename F>
+struct has_quad<F, std::void_t<decltype(&std::remove_reference_t<F>::quad)>> : std::true_type {};
+
 template <typename F>
 __device__ __forceinline__ void four_packed(const uint4 &w, const int4 &t, uint32_t j, uint32_t j_lo, uint32_t nj, int base,
                                             const uint8_t *__restrict__ ptab, F &&one)
 {
+    if constexpr (has_quad<F>::value) {
+        one.quad(w, t, j - j_lo, nj, base, ptab);
+        return;
+    }
     // the four table bytes are requested before the first one is used
     const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
     const uint32_t dj = j - j_lo;
@@ -269,17 +356,34 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     }
     int4 pa = make_int4(0, 0, 0, 0), ta = make_int4(0, 0, 0, 0), pb = make_int4(0, 0, 0, 0), tb = make_int4(0, 0, 0, 0);
     uint4 fa = make_uint4(0, 0, 0, 0), fb = make_uint4(0, 0, 0, 0);
-    const uint32_t jb0 = (win[0].x & ~3u) + 4u * tid;
+    // The rare classes' windows are short -- the north star's tiles see some 20 reads of class 1 (the 5 % of reads
+    // with a skipped region) -- and the launches are bound by their vector instructions, which a wave issues for all
+    // its lanes or none: four reads per lane made such a window cost a whole pass of four `one`s (160 of a tile's 690
+    // vector instructions).  A window of up to NT reads is taken ONE read per lane.
+    const bool small0 = win[0].y - win[0].x <= (uint32_t)NT, small1 = win[1].y - win[1].x <= (uint32_t)NT;      // (uniform)
+    const uint32_t jb0 = small0 ? win[0].x + (uint32_t)tid : (win[0].x & ~3u) + 4u * tid;
     if (jb0 < win[0].y) {
-        pa = *reinterpret_cast<const int4 *>(R.cls[0].pos + jb0);
-        fa = *reinterpret_cast<const uint4 *>(R.cls[0].fm + jb0);
-        if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(R.cls[0].tlen + jb0);
+        if (small0) {
+            pa.x = R.cls[0].pos[jb0];
+            fa.x = R.cls[0].fm[jb0];
+            if (P.use_tlen) ta.x = R.cls[0].tlen[jb0];
+        } else {
+            pa = *reinterpret_cast<const int4 *>(R.cls[0].pos + jb0);
+            fa = *reinterpret_cast<const uint4 *>(R.cls[0].fm + jb0);
+            if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(R.cls[0].tlen + jb0);
+        }
     }
-    const uint32_t jb1 = (win[1].x & ~3u) + 4u * tid;
+    const uint32_t jb1 = small1 ? win[1].x + (uint32_t)tid : (win[1].x & ~3u) + 4u * tid;
     if (jb1 < win[1].y) {
-        pb = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
-        fb = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
-        if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
+        if (small1) {
+            pb.x = R.cls[1].pos[jb1];
+            fb.x = R.cls[1].fm[jb1];
+            if (P.use_tlen) tb.x = R.cls[1].tlen[jb1];
+        } else {
+            pb = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
+            fb = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
+            if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
+        }
     }
     // The 16-B aligned loads may start before j_lo (possibly on the previous reference) and end
     // after j_hi: only reads in [j_lo, j_hi) count -> `dj < nj` with unsigned wrap-around.
@@ -308,6 +412,9 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     {   // ---- class 0 (span <= 256, a rare pair): no end column, end = pos + (fm >> 24) ------------------
         const BsigClassCols &C = R.cls[0];
         const uint32_t j_lo = win[0].x, j_hi = win[0].y, nj = j_hi - j_lo;
+        if (small0) {
+            if (nj) one(pa.x, pa.x + (int)(fa.x >> 24), (fa.x & 0x10u) != 0u, fm_rejected(P, fa.x), ta.x, jb0 < j_hi);
+        } else
         for (uint32_t j = jb0; j < j_hi;) {
             const uint32_t dj = j - j_lo;
             one(pa.x, pa.x + (int)(fa.x >> 24), (fa.x & 0x10u) != 0u, fm_rejected(P, fa.x), ta.x, dj < nj);
@@ -325,6 +432,10 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     {   // ---- class 1 (span <= 4096, 12-bit flags): no end column either, end = pos + (word >> 20) -----------
         const BsigClassCols &C = R.cls[1];
         const uint32_t j_lo = win[1].x, j_hi = win[1].y, nj = j_hi - j_lo;
+        if (small1) {
+            const uint32_t gx = fm_of_class1(fb.x);
+            if (nj) one(pb.x, pb.x + (int)(fb.x >> 20), (gx & 0x10u) != 0u, fm_rejected(P, gx), tb.x, jb1 < j_hi);
+        } else
         for (uint32_t j = jb1; j < j_hi;) {
             const uint32_t dj = j - j_lo;
             const uint32_t gx = fm_of_class1(fb.x), gy = fm_of_class1(fb.y), gz = fm_of_class1(fb.z), gw = fm_of_class1(fb.w);
@@ -344,6 +455,18 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     for (int c = 2; c < BSIG_SPAN_CLASSES; ++c) {   // ---- classes 2-3: pos, end, fm columns ---------
         const BsigClassCols &C = R.cls[c];
         const uint32_t j_lo = win[c].x, j_hi = win[c].y, nj = j_hi - j_lo;
+        if (nj <= (uint32_t)NT) {                          // (one read per lane, as above)
+            const uint32_t j = j_lo + (uint32_t)tid;
+            if (nj) {
+                int p = 0, e = 0, t = 0;
+                uint32_t f = 0;
+                if (j < j_hi) {
+                    p = C.pos[j]; f = C.fm[j]; e = C.end[j];
+                    if (P.use_tlen) t = C.tlen[j];
+                }
+                one(p, e, (f & 0x10u) != 0u, fm_rejected(P, f), t, j < j_hi);
+            }
+        } else
         for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
             const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
             const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
@@ -755,18 +878,16 @@ __global__ __launch_bounds__(NT) void k_count(const BsigWorkItem *__restrict__ i
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
     const int gn = w.nc;
-    int c_sense = 0, c_anti = 0;
-
-    auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
-        if (!valid || rej || tlen_rejected(P, tl)) return;
-        const int a = tl < 0 ? -tl : tl;
-        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
-        const int p5 = neg ? e - offset : p + offset;
-        if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
-        if (neg != neg_range) ++c_anti; else ++c_sense;
-    };
+    // Counting is all this launch does per read, and the launch is bound by its vector instructions (PMC, config 3's
+    // tiling: 95e6 VALU instructions x 4 cycles over 1,024 SIMDs = the whole 155 us): no branch per read -- a read
+    // that is no read, rejected or outside adds 0 -- and two counters (all, reverse strand) that become sense and
+    // antisense once, behind the loop.
+    uint32_t acc = 0;
+    const CountOne one{P, glo, gn, acc};
     for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
     if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_COUNT, w, pk.n_chunks, clip, ptab, tid, one);
+    const int c_all = (int)(acc & 0xFFFFu), c_neg = (int)(acc >> 16);
+    int c_anti = neg_range ? c_all - c_neg : c_neg, c_sense = c_all - c_anti;
 
     // wave reduction, then across the waves of the workgroup
 #pragma unroll
@@ -845,20 +966,15 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
         const bool neg_range = ((uint32_t)__builtin_amdgcn_readfirstlane((int)stage[t][12]) & BSIG_ITEM_NEG) != 0u;
         const int pbase = __builtin_amdgcn_readfirstlane((int)stage[t][13]);
         const int pchunks = __builtin_amdgcn_readfirstlane((int)stage[t][14]);
-        int c_sense = 0, c_anti = 0;
-        auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
-            if (!valid || rej || tlen_rejected(P, tl)) return;
-            const int a = tl < 0 ? -tl : tl;
-            const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
-            const int p5 = neg ? e - offset : p + offset;
-            if ((unsigned)(p5 - glo) >= (unsigned)gn) return;
-            if (neg != neg_range) ++c_anti; else ++c_sense;
-        };
+        uint32_t acc = 0;                          // (see k_count: nothing branches per read)
+        const CountOne one{P, glo, gn, acc};
         for_each_read<kWave, PRE>(R, P, wn, pbase, ptab, lane, one);
         if (pchunks > 1) {
             const BsigWorkItem w2 = items[first + t];
             packed_later_chunks<kWave>(R, P, BSIG_MODE_COUNT, w2, pchunks, make_uint2(0u, 0xFFFFFFFFu), ptab, lane, one);
         }
+        const int c_all = (int)(acc & 0xFFFFu), c_neg = (int)(acc >> 16);
+        int c_anti = neg_range ? c_all - c_neg : c_neg, c_sense = c_all - c_anti;
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) {
             c_sense += __shfl_xor(c_sense, d);
@@ -1442,6 +1558,12 @@ hipError_t launch_pileup(int mode, int ss, int threads, const BsigReadsDev &R, c
     case 256: return launch_mode<256>(mode, ss, R, P, items, n_items, tile_cells, (uint2 *)windows, resolve_first, out, st);
     default:  return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_make_ptab(const BsigReadsDev &R, const BsigKParams &P, uint8_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_make_ptab, dim3(1), dim3(128), 0, st, R, P, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem *items,

@@ -268,6 +268,7 @@ struct bsig_plan {
     bool needs_zero = false;
     bool have_stats = false;
     bsig_plan_stats stats{};
+    uint8_t *ptab = nullptr;            // the packed class's filter table for kp (BsigKParams::ptab)
     BsigResolved *resolved = nullptr;   // large launches: the windows of every tile, written by k_resolve_tiles in every run
 };
 static int64_t g_resolve_min_override = -1;     // bsig_debug_set_knob(4, n): two launches from n tiles on (sweeps)
@@ -1395,6 +1396,10 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     if (P->n_items >= (1ll << 31)) { delete P; return fail(BSIG_ERR_ARG, "too many tiles for one launch"); }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = P->pool.alloc(&P->items, std::max<size_t>(items.size(), 1));
+    // the packed class's filter table for these parameters (kernels.hip: k_make_ptab)
+    if (e == hipSuccess) e = P->pool.alloc(&P->ptab, (size_t)BSIG_PACK_CODES);
+    if (e == hipSuccess) e = bsig::launch_make_ptab(reads->dev, K, P->ptab, ctx->stream);
+    K.ptab = P->ptab;
     if (e == hipSuccess && !items.empty())
         e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(BsigWorkItem), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
