@@ -76,6 +76,91 @@ __device__ __forceinline__ void count_one(const BsigKParams &P, int glo, int gn,
     acc += ok ? (neg ? 0x10001u : 1u) : 0u;
 }
 
+__device__ __forceinline__ bool tlen_rejected(const BsigKParams &P, int32_t tl)
+{
+    if (!P.has_tlen_filter) return false;
+    const int a = tl < 0 ? -tl : tl;
+    return (a < P.tf0) | (a > P.tf1);
+}
+
+// bamCoverage's per-read work (ref: src/bamsignals.cpp:392-438): +1 where the read begins to cover the tile, -1 behind
+// its last covered cell, in the tile's difference array of signed 16-bit cells (two per LDS dword: see k_coverage).
+struct CoverOne {
+    const BsigKParams &P;
+    int32_t *lds;
+    int loc, c0, nc, sh;
+    bool neg_range;
+    int rend1;                              // last base of the range
+    __device__ __forceinline__ void operator()(int p, int e, bool neg, bool rej, int tl, bool valid) const
+    {
+        if (!valid || rej || tlen_rejected(P, tl)) return;            // :394-399
+        int start = p, end = e;                                       // :401-403
+        if (P.tspan) {                                                // :404-413
+            if (neg && tl < 0) start = end + tl + 1;
+            else if (!neg && tl > 0) end = start + tl - 1;
+        }
+        // covered cells [ra, rb] in range orientation (:423-436), then relative to the tile
+        const int ra = neg_range ? rend1 - end : start - loc;
+        const int rb = neg_range ? rend1 - start : end - loc;
+        const int la = ra - c0, lb = rb - c0;
+        if (la >= nc || lb < 0) return;                               // :420
+        const int ka = sh + (la > 0 ? la : 0);
+        atomicAdd(&lds[ka >> 1], (ka & 1) ? 65536 : 1);
+        if (lb + 1 < nc) {
+            const int kb = sh + lb + 1;
+            atomicAdd(&lds[kb >> 1], (kb & 1) ? -65536 : -1);
+        }
+    }
+    // Four reads of the packed class at once, when no template-length rule applies (the launch is bound by its
+    // vector instructions: PMC, config 3).  Straight arithmetic on the packed word -- first covered cell
+    // la = d + A (or B - d - span on a reverse-strand range), last lb = la + span, d = (word - base) & mask -- and no
+    // branch: a read that is none, is rejected or misses the tile adds 0 to cell 0.
+    __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
+                                         const uint8_t *__restrict__ ptab) const
+    {
+        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
+        if (P.has_tlen_filter | P.tspan) {                     // (uniform)
+            auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
+                const int pos = base + (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
+                (*this)(pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid);
+            };
+            dec(w.x, b0, t.x, dj < nj);
+            dec(w.y, b1, t.y, dj + 1u < nj);
+            dec(w.z, b2, t.z, dj + 2u < nj);
+            dec(w.w, b3, t.w, dj + 3u < nj);
+            return;
+        }
+        // (sh rides in K: k = cell index in the image, first covered cell max(ka, sh), one past the last kb + 1)
+        if (neg_range) four<true>(w, b0, b1, b2, b3, dj, nj, base, rend1 - c0 - base + sh);
+        else four<false>(w, b0, b1, b2, b3, dj, nj, base, base - loc - c0 + sh);
+    }
+    template <bool REV>
+    __device__ __forceinline__ void four(const uint4 &w, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj, uint32_t nj,
+                                         int base, int K) const
+    {
+        const int hi = sh + nc;
+        auto rd = [&](uint32_t x, uint32_t b, uint32_t k) {
+            const int d = (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
+            const int sp = (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu);
+            const int rj = (int32_t)(b << 31) >> 31;                       // all ones: rejected
+            const int ka = REV ? K - d - sp : K + d;
+            const int kb = ((ka + sp) | rj) + 1;                           // (a rejected read ends before the tile)
+            const bool ok = (dj + k < nj) & (ka < hi) & (kb > sh);
+            const bool ok2 = ok & (kb < hi);
+            const int ca = ok ? (ka > sh ? ka : sh) : 0, cb = ok2 ? kb : 0;
+            // an odd cell is the high half of its dword: the shifter takes (k << 4) & 31 = 16 for odd k
+            // (and -1 is all ones: shifted by 16 it is -65536 in the dword's arithmetic mod 2^32)
+            uint32_t *img = reinterpret_cast<uint32_t *>(lds);
+            atomicAdd(&img[ca >> 1], (ok ? 1u : 0u) << (((uint32_t)ca << 4) & 31u));
+            atomicAdd(&img[cb >> 1], (ok2 ? 0xFFFFFFFFu : 0u) << (((uint32_t)cb << 4) & 31u));
+        };
+        rd(w.x, b0, 0u);
+        rd(w.y, b1, 1u);
+        rd(w.z, b2, 2u);
+        rd(w.w, b3, 3u);
+    }
+};
+
 struct CountOne {
     const BsigKParams &P;
     int glo, gn;
@@ -120,12 +205,6 @@ struct CountOne {
     }
 };
 
-__device__ __forceinline__ bool tlen_rejected(const BsigKParams &P, int32_t tl)
-{
-    if (!P.has_tlen_filter) return false;
-    const int a = tl < 0 ? -tl : tl;
-    return (a < P.tf0) | (a > P.tf1);
-}
 
 constexpr int kPackChunk = 1 << BSIG_PACK_POS_BITS;        // bases a packed word's position bits span
 constexpr uint32_t kPackPosMask = (uint32_t)kPackChunk - 1u;
@@ -1035,25 +1114,7 @@ __global__ __launch_bounds__(NT) void k_coverage(const BsigWorkItem *__restrict_
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int rend1 = w.loc + w.len - 1;     // last base of the range
 
-    auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
-        if (!valid || rej || tlen_rejected(P, tl)) return;            // :394-399
-        int start = p, end = e;                                       // :401-403
-        if (P.tspan) {                                                // :404-413
-            if (neg && tl < 0) start = end + tl + 1;
-            else if (!neg && tl > 0) end = start + tl - 1;
-        }
-        // covered cells [ra, rb] in range orientation (:423-436), then relative to the tile
-        const int ra = neg_range ? rend1 - end : start - w.loc;
-        const int rb = neg_range ? rend1 - start : end - w.loc;
-        const int la = ra - w.c0, lb = rb - w.c0;
-        if (la >= w.nc || lb < 0) return;                             // :420
-        const int ka = sh + (la > 0 ? la : 0);
-        atomicAdd(&lds[ka >> 1], (ka & 1) ? 65536 : 1);
-        if (lb + 1 < w.nc) {
-            const int kb = sh + lb + 1;
-            atomicAdd(&lds[kb >> 1], (kb & 1) ? -65536 : -1);
-        }
-    };
+    const CoverOne one{P, lds, w.loc, w.c0, w.nc, sh, neg_range, rend1};
     for_each_read<NT, PRE>(R, P, win, pk.base, ptab, tid, one);
     if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_COVERAGE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();
