@@ -83,6 +83,84 @@ __device__ __forceinline__ bool tlen_rejected(const BsigKParams &P, int32_t tl)
     return (a < P.tf0) | (a > P.tf1);
 }
 
+// bamProfile's per-read work (ref: src/bamsignals.cpp:326-363) on a tile image of 16-bit cells, two per LDS dword.
+template <bool SS>
+struct ProfileOne {
+    const BsigKParams &P;
+    uint32_t *cnt;
+    int loc, len, c0, nc, sh;
+    bool neg_range;
+    __device__ __forceinline__ void operator()(int p, int e, bool neg /* isNegStrand, :11-13 */, bool rej, int tl, bool valid) const
+    {
+        constexpr int S = SS ? 2 : 1;
+        if (!valid || rej || tlen_rejected(P, tl)) return;             // :328-333
+        const int a = tl < 0 ? -tl : tl;
+        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;  // :339
+        const int p5 = neg ? e - offset : p + offset;                  // :340-344
+        int rel = p5 - loc;                                            // :351
+        if ((unsigned)rel >= (unsigned)len) return;                    // :353
+        int anti = neg ? 1 : 0;
+        if (neg_range) { rel = len - rel - 1; anti ^= 1; }             // :356-359
+        const int cell = P.binsize == 1 ? rel
+                                        : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
+        const int lc = cell - c0;
+        if ((unsigned)lc < (unsigned)nc) {
+            const int k = sh + lc * S + (SS ? anti : 0);               // :361-362
+            atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
+        }
+    }
+    // Four reads of the packed class at once when the call has no template-length rule and bins of one base (the
+    // reference's defaults): straight arithmetic on the packed word, one masked LDS add at the end.  With d = (word - base) & mask the 5' end relative to the range is
+    // d + cp on the forward strand and d + span + cp - 2 shift on the reverse one; the tile's cell is that minus c0,
+    // or counted from the range's other end on a reverse-strand range (a tile lies inside its range, so the cell
+    // test is the range test, :351-353).
+    __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
+                                         const uint8_t *__restrict__ ptab) const
+    {
+        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
+        if (P.has_tlen_filter | P.midpoint | (P.binsize != 1)) {       // (uniform)
+            auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
+                const int pos = base + (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
+                (*this)(pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid);
+            };
+            dec(w.x, b0, t.x, dj < nj);
+            dec(w.y, b1, t.y, dj + 1u < nj);
+            dec(w.z, b2, t.z, dj + 2u < nj);
+            dec(w.w, b3, t.w, dj + 3u < nj);
+            return;
+        }
+        if (neg_range) four<true>(w, b0, b1, b2, b3, dj, nj, base, len - 1 - c0 - (base - loc + P.shift));
+        else four<false>(w, b0, b1, b2, b3, dj, nj, base, base - loc + P.shift - c0);
+    }
+    template <bool REV>
+    __device__ __forceinline__ void four(const uint4 &w, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj, uint32_t nj,
+                                         int base, int K) const
+    {
+        const uint32_t cd = (uint32_t)(-2 * P.shift);
+        auto rd = [&](uint32_t x, uint32_t b, uint32_t k) {
+            const uint32_t d = (x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u);
+            const uint32_t sp = (x >> BSIG_PACK_POS_BITS) & 0xFFu;
+            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31), rj = (uint32_t)((int32_t)(b << 31) >> 31);
+            const uint32_t fwd = d + (nm & (sp + cd));                 // 5' end, from base + shift
+            const uint32_t lc = (REV ? (uint32_t)K - fwd : (uint32_t)K + fwd) | rj;       // (rejected: beyond every tile)
+            const bool ok = (dj + k < nj) & (lc < (uint32_t)nc);
+            // antisense: reverse-strand read on a forward range, forward read on a reverse one
+            const uint32_t cell = SS ? (uint32_t)sh + 2u * lc + ((REV ? ~nm : nm) & 1u) : (uint32_t)sh + lc;
+            // (masked, not redirected: the many reads of a window that miss the tile would all meet in one dummy
+            // cell, and LDS atomics on one address take their turns -- config 5's 1-kb tiles: 0.16 -> 0.30 ms)
+            if (ok) atomicAdd(&cnt[cell >> 1], 1u << ((cell << 4) & 31u));     // (odd cell: the dword's high half)
+        };
+        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
+        rd(w.x, b0, 0u);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(w.y, b1, 1u);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(w.z, b2, 2u);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(w.w, b3, 3u);
+    }
+};
+
 // bamCoverage's per-read work (ref: src/bamsignals.cpp:392-438): +1 where the read begins to cover the tile, -1 behind
 // its last covered cell, in the tile's difference array of signed 16-bit cells (two per LDS dword: see k_coverage).
 struct CoverOne {
@@ -113,8 +191,8 @@ struct CoverOne {
     }
     // Four reads of the packed class at once, when no template-length rule applies (the launch is bound by its
     // vector instructions: PMC, config 3).  Straight arithmetic on the packed word -- first covered cell
-    // la = d + A (or B - d - span on a reverse-strand range), last lb = la + span, d = (word - base) & mask -- and no
-    // branch: a read that is none, is rejected or misses the tile adds 0 to cell 0.
+    // la = d + A (or B - d - span on a reverse-strand range), last lb = la + span, d = (word - base) & mask -- and two
+    // masked LDS adds at the end.
     __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
                                          const uint8_t *__restrict__ ptab) const
     {
@@ -147,16 +225,21 @@ struct CoverOne {
             const int kb = ((ka + sp) | rj) + 1;                           // (a rejected read ends before the tile)
             const bool ok = (dj + k < nj) & (ka < hi) & (kb > sh);
             const bool ok2 = ok & (kb < hi);
-            const int ca = ok ? (ka > sh ? ka : sh) : 0, cb = ok2 ? kb : 0;
+            const int ca = ka > sh ? ka : sh;
             // an odd cell is the high half of its dword: the shifter takes (k << 4) & 31 = 16 for odd k
-            // (and -1 is all ones: shifted by 16 it is -65536 in the dword's arithmetic mod 2^32)
+            // (and -1 is all ones: shifted by 16 it is -65536 in the dword's arithmetic mod 2^32).  The adds are
+            // masked, not redirected to a dummy cell: see ProfileOne.
             uint32_t *img = reinterpret_cast<uint32_t *>(lds);
-            atomicAdd(&img[ca >> 1], (ok ? 1u : 0u) << (((uint32_t)ca << 4) & 31u));
-            atomicAdd(&img[cb >> 1], (ok2 ? 0xFFFFFFFFu : 0u) << (((uint32_t)cb << 4) & 31u));
+            if (ok) atomicAdd(&img[ca >> 1], 1u << (((uint32_t)ca << 4) & 31u));
+            if (ok2) atomicAdd(&img[kb >> 1], 0xFFFFFFFFu << (((uint32_t)kb << 4) & 31u));
         };
+        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
         rd(w.x, b0, 0u);
+        __builtin_amdgcn_sched_barrier(0);
         rd(w.y, b1, 1u);
+        __builtin_amdgcn_sched_barrier(0);
         rd(w.z, b2, 2u);
+        __builtin_amdgcn_sched_barrier(0);
         rd(w.w, b3, 3u);
     }
 };
@@ -198,9 +281,13 @@ struct CountOne {
             const bool ok = (dj + k < nj) & (rel < (uint32_t)gn);
             acc += ok ? ((nm & 0x10000u) | 1u) : 0u;
         };
+        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
         rd(w.x, b0, 0u);
+        __builtin_amdgcn_sched_barrier(0);
         rd(w.y, b1, 1u);
+        __builtin_amdgcn_sched_barrier(0);
         rd(w.z, b2, 2u);
+        __builtin_amdgcn_sched_barrier(0);
         rd(w.w, b3, 3u);
     }
 };
@@ -433,36 +520,25 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
             if (P.use_tlen) t0[k] = *reinterpret_cast<const int4 *>(CP.tlen + j);
         }
     }
-    int4 pa = make_int4(0, 0, 0, 0), ta = make_int4(0, 0, 0, 0), pb = make_int4(0, 0, 0, 0), tb = make_int4(0, 0, 0, 0);
-    uint4 fa = make_uint4(0, 0, 0, 0), fb = make_uint4(0, 0, 0, 0);
     // The rare classes' windows are short -- the north star's tiles see some 20 reads of class 1 (the 5 % of reads
     // with a skipped region) -- and the launches are bound by their vector instructions, which a wave issues for all
     // its lanes or none: four reads per lane made such a window cost a whole pass of four `one`s (160 of a tile's 690
-    // vector instructions).  A window of up to NT reads is taken ONE read per lane.
+    // vector instructions).  A window of up to NT reads is taken ONE read per lane, requested here, ahead of the
+    // packed class's work; a longer one is loaded where it is walked (the registers of a four-read prefetch held
+    // across the packed class cost a wave per SIMD).
     const bool small0 = win[0].y - win[0].x <= (uint32_t)NT, small1 = win[1].y - win[1].x <= (uint32_t)NT;      // (uniform)
-    const uint32_t jb0 = small0 ? win[0].x + (uint32_t)tid : (win[0].x & ~3u) + 4u * tid;
-    if (jb0 < win[0].y) {
-        if (small0) {
-            pa.x = R.cls[0].pos[jb0];
-            fa.x = R.cls[0].fm[jb0];
-            if (P.use_tlen) ta.x = R.cls[0].tlen[jb0];
-        } else {
-            pa = *reinterpret_cast<const int4 *>(R.cls[0].pos + jb0);
-            fa = *reinterpret_cast<const uint4 *>(R.cls[0].fm + jb0);
-            if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(R.cls[0].tlen + jb0);
-        }
+    int pa = 0, ta = 0, pb = 0, tb = 0;
+    uint32_t fa = 0, fb = 0;
+    const uint32_t jb0 = win[0].x + (uint32_t)tid, jb1 = win[1].x + (uint32_t)tid;
+    if (small0 && jb0 < win[0].y) {
+        pa = R.cls[0].pos[jb0];
+        fa = R.cls[0].fm[jb0];
+        if (P.use_tlen) ta = R.cls[0].tlen[jb0];
     }
-    const uint32_t jb1 = small1 ? win[1].x + (uint32_t)tid : (win[1].x & ~3u) + 4u * tid;
-    if (jb1 < win[1].y) {
-        if (small1) {
-            pb.x = R.cls[1].pos[jb1];
-            fb.x = R.cls[1].fm[jb1];
-            if (P.use_tlen) tb.x = R.cls[1].tlen[jb1];
-        } else {
-            pb = *reinterpret_cast<const int4 *>(R.cls[1].pos + jb1);
-            fb = *reinterpret_cast<const uint4 *>(R.cls[1].fm + jb1);
-            if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(R.cls[1].tlen + jb1);
-        }
+    if (small1 && jb1 < win[1].y) {
+        pb = R.cls[1].pos[jb1];
+        fb = R.cls[1].fm[jb1];
+        if (P.use_tlen) tb = R.cls[1].tlen[jb1];
     }
     // The 16-B aligned loads may start before j_lo (possibly on the previous reference) and end
     // after j_hi: only reads in [j_lo, j_hi) count -> `dj < nj` with unsigned wrap-around.
@@ -492,42 +568,38 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
         const BsigClassCols &C = R.cls[0];
         const uint32_t j_lo = win[0].x, j_hi = win[0].y, nj = j_hi - j_lo;
         if (small0) {
-            if (nj) one(pa.x, pa.x + (int)(fa.x >> 24), (fa.x & 0x10u) != 0u, fm_rejected(P, fa.x), ta.x, jb0 < j_hi);
+            if (nj) one(pa, pa + (int)(fa >> 24), (fa & 0x10u) != 0u, fm_rejected(P, fa), ta, jb0 < j_hi);
         } else
-        for (uint32_t j = jb0; j < j_hi;) {
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
+            const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
+            const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
             const uint32_t dj = j - j_lo;
-            one(pa.x, pa.x + (int)(fa.x >> 24), (fa.x & 0x10u) != 0u, fm_rejected(P, fa.x), ta.x, dj < nj);
-            one(pa.y, pa.y + (int)(fa.y >> 24), (fa.y & 0x10u) != 0u, fm_rejected(P, fa.y), ta.y, dj + 1u < nj);
-            one(pa.z, pa.z + (int)(fa.z >> 24), (fa.z & 0x10u) != 0u, fm_rejected(P, fa.z), ta.z, dj + 2u < nj);
-            one(pa.w, pa.w + (int)(fa.w >> 24), (fa.w & 0x10u) != 0u, fm_rejected(P, fa.w), ta.w, dj + 3u < nj);
-            j += 4u * NT;
-            if (j < j_hi) {
-                pa = *reinterpret_cast<const int4 *>(C.pos + j);
-                fa = *reinterpret_cast<const uint4 *>(C.fm + j);
-                if (P.use_tlen) ta = *reinterpret_cast<const int4 *>(C.tlen + j);
-            }
+            one(p.x, p.x + (int)(f.x >> 24), (f.x & 0x10u) != 0u, fm_rejected(P, f.x), t.x, dj < nj);
+            one(p.y, p.y + (int)(f.y >> 24), (f.y & 0x10u) != 0u, fm_rejected(P, f.y), t.y, dj + 1u < nj);
+            one(p.z, p.z + (int)(f.z >> 24), (f.z & 0x10u) != 0u, fm_rejected(P, f.z), t.z, dj + 2u < nj);
+            one(p.w, p.w + (int)(f.w >> 24), (f.w & 0x10u) != 0u, fm_rejected(P, f.w), t.w, dj + 3u < nj);
         }
     }
     {   // ---- class 1 (span <= 4096, 12-bit flags): no end column either, end = pos + (word >> 20) -----------
         const BsigClassCols &C = R.cls[1];
         const uint32_t j_lo = win[1].x, j_hi = win[1].y, nj = j_hi - j_lo;
         if (small1) {
-            const uint32_t gx = fm_of_class1(fb.x);
-            if (nj) one(pb.x, pb.x + (int)(fb.x >> 20), (gx & 0x10u) != 0u, fm_rejected(P, gx), tb.x, jb1 < j_hi);
+            const uint32_t gx = fm_of_class1(fb);
+            if (nj) one(pb, pb + (int)(fb >> 20), (gx & 0x10u) != 0u, fm_rejected(P, gx), tb, jb1 < j_hi);
         } else
-        for (uint32_t j = jb1; j < j_hi;) {
+        for (uint32_t j = (j_lo & ~3u) + 4u * tid; j < j_hi; j += 4u * NT) {
+            const int4 p = *reinterpret_cast<const int4 *>(C.pos + j);
+            const uint4 f = *reinterpret_cast<const uint4 *>(C.fm + j);
+            int4 t = make_int4(0, 0, 0, 0);
+            if (P.use_tlen) t = *reinterpret_cast<const int4 *>(C.tlen + j);
             const uint32_t dj = j - j_lo;
-            const uint32_t gx = fm_of_class1(fb.x), gy = fm_of_class1(fb.y), gz = fm_of_class1(fb.z), gw = fm_of_class1(fb.w);
-            one(pb.x, pb.x + (int)(fb.x >> 20), (gx & 0x10u) != 0u, fm_rejected(P, gx), tb.x, dj < nj);
-            one(pb.y, pb.y + (int)(fb.y >> 20), (gy & 0x10u) != 0u, fm_rejected(P, gy), tb.y, dj + 1u < nj);
-            one(pb.z, pb.z + (int)(fb.z >> 20), (gz & 0x10u) != 0u, fm_rejected(P, gz), tb.z, dj + 2u < nj);
-            one(pb.w, pb.w + (int)(fb.w >> 20), (gw & 0x10u) != 0u, fm_rejected(P, gw), tb.w, dj + 3u < nj);
-            j += 4u * NT;
-            if (j < j_hi) {
-                pb = *reinterpret_cast<const int4 *>(C.pos + j);
-                fb = *reinterpret_cast<const uint4 *>(C.fm + j);
-                if (P.use_tlen) tb = *reinterpret_cast<const int4 *>(C.tlen + j);
-            }
+            const uint32_t gx = fm_of_class1(f.x), gy = fm_of_class1(f.y), gz = fm_of_class1(f.z), gw = fm_of_class1(f.w);
+            one(p.x, p.x + (int)(f.x >> 20), (gx & 0x10u) != 0u, fm_rejected(P, gx), t.x, dj < nj);
+            one(p.y, p.y + (int)(f.y >> 20), (gy & 0x10u) != 0u, fm_rejected(P, gy), t.y, dj + 1u < nj);
+            one(p.z, p.z + (int)(f.z >> 20), (gz & 0x10u) != 0u, fm_rejected(P, gz), t.z, dj + 2u < nj);
+            one(p.w, p.w + (int)(f.w >> 20), (gw & 0x10u) != 0u, fm_rejected(P, gw), t.w, dj + 3u < nj);
         }
     }
 #pragma unroll
@@ -748,23 +820,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
 
-    auto one = [&](int p, int e, bool neg /* isNegStrand, :11-13 */, bool rej, int tl, bool valid) {
-        if (!valid || rej || tlen_rejected(P, tl)) return;             // :328-333
-        const int a = tl < 0 ? -tl : tl;
-        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;  // :339
-        const int p5 = neg ? e - offset : p + offset;                  // :340-344
-        int rel = p5 - w.loc;                                          // :351
-        if ((unsigned)rel >= (unsigned)w.len) return;                  // :353
-        int anti = neg ? 1 : 0;
-        if (neg_range) { rel = w.len - rel - 1; anti ^= 1; }           // :356-359
-        const int cell = P.binsize == 1 ? rel
-                                        : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
-        const int lc = cell - w.c0;
-        if ((unsigned)lc < (unsigned)w.nc) {
-            const int k = sh + lc * S + (SS ? anti : 0);               // :361-362
-            atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
-        }
-    };
+    const ProfileOne<SS> one{P, cnt, w.loc, w.len, w.c0, w.nc, sh, neg_range};
     if (!BSIG_ABLATE(1)) {
         for_each_read<NT, PRE>(R, P, win, pk.base, ptab, tid, one);
         if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_PROFILE, w, pk.n_chunks, clip, ptab, tid, one);
@@ -844,22 +900,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, 8)
         const int sh = (int)(w.out_off & 3);
         const int nvec = (sh + nv + 3) >> 2;
         const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
-        auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
-            if (!valid || rej || tlen_rejected(P, tl)) return;
-            const int a = tl < 0 ? -tl : tl;
-            const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
-            const int p5 = neg ? e - offset : p + offset;
-            int rel = p5 - w.loc;
-            if ((unsigned)rel >= (unsigned)w.len) return;
-            int anti = neg ? 1 : 0;
-            if (neg_range) { rel = w.len - rel - 1; anti ^= 1; }
-            const int cell = P.binsize == 1 ? rel : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
-            const int lc = cell - w.c0;
-            if ((unsigned)lc < (unsigned)w.nc) {
-                const int k = sh + lc * S + (SS ? anti : 0);
-                atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
-            }
-        };
+        const ProfileOne<SS> one{P, cnt, w.loc, w.len, w.c0, w.nc, sh, neg_range};
         for_each_read<kWave, PRE>(R, P, win, pbase, ptab, tid, one);
         if (pchunks > 1) packed_later_chunks<kWave>(R, P, BSIG_MODE_PROFILE, w, pchunks, make_uint2(0u, 0xFFFFFFFFu), ptab, tid, one);
         block_sync<kWave>();
