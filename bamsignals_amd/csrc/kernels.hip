@@ -109,8 +109,7 @@ struct ProfileOne {
             atomicAdd(&cnt[k >> 1], 1u << ((k & 1) << 4));
         }
     }
-    // Four reads of the packed class at once when the call has no template-length rule and bins of one base (the
-    // reference's defaults): straight arithmetic on the packed word, one masked LDS add at the end.  With d = (word - base) & mask the 5' end relative to the range is
+    // Four reads of the packed class at once for bins of one base: straight arithmetic on the packed word, one masked LDS add at the end.  With d = (word - base) & mask the 5' end relative to the range is
     // d + cp on the forward strand and d + span + cp - 2 shift on the reverse one; the tile's cell is that minus c0,
     // or counted from the range's other end on a reverse-strand range (a tile lies inside its range, so the cell
     // test is the range test, :351-353).
@@ -118,7 +117,7 @@ struct ProfileOne {
                                          const uint8_t *__restrict__ ptab) const
     {
         const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
-        if (P.has_tlen_filter | P.midpoint | (P.binsize != 1)) {       // (uniform)
+        if (P.binsize != 1) {                                          // (uniform)
             auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
                 const int pos = base + (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
                 (*this)(pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid);
@@ -129,19 +128,35 @@ struct ProfileOne {
             dec(w.w, b3, t.w, dj + 3u < nj);
             return;
         }
-        if (neg_range) four<true>(w, b0, b1, b2, b3, dj, nj, base, len - 1 - c0 - (base - loc + P.shift));
-        else four<false>(w, b0, b1, b2, b3, dj, nj, base, base - loc + P.shift - c0);
+        const bool tl_rule = (P.has_tlen_filter | P.midpoint) != 0;    // (uniform)
+        if (neg_range) {
+            const int K = len - 1 - c0 - (base - loc + P.shift);
+            if (tl_rule) four<true, true>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+            else four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+        } else {
+            const int K = base - loc + P.shift - c0;
+            if (tl_rule) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+            else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+        }
     }
-    template <bool REV>
-    __device__ __forceinline__ void four(const uint4 &w, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj, uint32_t nj,
-                                         int base, int K) const
+    // TL: a template-length rule applies (:332-333 the filter, :339 the midpoint: the 5' end moves by |tlen| / 2)
+    template <bool REV, bool TL>
+    __device__ __forceinline__ void four(const uint4 &w, const int4 &t, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj,
+                                         uint32_t nj, int base, int K) const
     {
         const uint32_t cd = (uint32_t)(-2 * P.shift);
-        auto rd = [&](uint32_t x, uint32_t b, uint32_t k) {
+        auto rd = [&](uint32_t x, uint32_t b, int tl, uint32_t k) {
             const uint32_t d = (x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u);
             const uint32_t sp = (x >> BSIG_PACK_POS_BITS) & 0xFFu;
-            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31), rj = (uint32_t)((int32_t)(b << 31) >> 31);
-            const uint32_t fwd = d + (nm & (sp + cd));                 // 5' end, from base + shift
+            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31);
+            uint32_t rj = (uint32_t)((int32_t)(b << 31) >> 31), h = 0;
+            if (TL) {
+                const int a = tl < 0 ? -tl : tl;
+                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? 0xFFFFFFFFu : 0u;
+                if (P.midpoint) h = (uint32_t)(a >> 1);
+            }
+            // 5' end from base + shift: pos + h on the forward strand, pos + span - 2 shift - h on the reverse one
+            const uint32_t fwd = d + h + (nm & (sp + cd - 2u * h));
             const uint32_t lc = (REV ? (uint32_t)K - fwd : (uint32_t)K + fwd) | rj;       // (rejected: beyond every tile)
             const bool ok = (dj + k < nj) & (lc < (uint32_t)nc);
             // antisense: reverse-strand read on a forward range, forward read on a reverse one
@@ -151,13 +166,13 @@ struct ProfileOne {
             if (ok) atomicAdd(&cnt[cell >> 1], 1u << ((cell << 4) & 31u));     // (odd cell: the dword's high half)
         };
         // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
-        rd(w.x, b0, 0u);
+        rd(w.x, b0, t.x, 0u);
         __builtin_amdgcn_sched_barrier(0);
-        rd(w.y, b1, 1u);
+        rd(w.y, b1, t.y, 1u);
         __builtin_amdgcn_sched_barrier(0);
-        rd(w.z, b2, 2u);
+        rd(w.z, b2, t.z, 2u);
         __builtin_amdgcn_sched_barrier(0);
-        rd(w.w, b3, 3u);
+        rd(w.w, b3, t.w, 3u);
     }
 };
 

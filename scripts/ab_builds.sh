@@ -5,7 +5,7 @@
 A=$(realpath "$1"); ROUNDS=${2:-2}
 one() {  # label, env...
     local label=$1; shift
-    for c in ns c2 c5 C3 count; do
+    for c in ns c2 c5 C3 C4 count; do
         case $c in
         ns) out=$(env "$@" python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-e2e --no-also 2>/dev/null | tail -1) ;;
         c2) out=$(env "$@" python bench.py --config C2 --steps 64 --warmup 16 --no-cpu-baseline --no-e2e 2>/dev/null | tail -1) ;;
