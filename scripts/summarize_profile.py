@@ -123,7 +123,7 @@ if ns:
     shutil.copyfile(ns, os.path.join(P, f"{tag}_decode_ns_kernel_stats.csv"))
     lines.append("\n## Device-side decode of the NORTH STAR's BAM (`rocprofv3 --kernel-trace --stats -- python3 "
                  "scripts/decode_ns_time.py 500000000 3`: 5e8 bare reads, 3.0 GB file, 21 GB of stream in 327,000 blocks; "
-                 "three decodes, each a head share + three passes)\n")
+                 "three decodes, each streamed: the file into HBM once, six or seven shares of up to one round of inflate lanes)\n")
     lines.append("| kernel | calls | total ms per decode | avg ns | min ns | max ns |\n|---|---|---|---|---|---|")
     for r in csv.DictReader(open(ns)):
         if any(s in r["Name"] for s in ("k_inflate", "k_crc32", "k_bam_walk", "k_bam_extract", "k_scatter", "k_span_hist", "k_build_idx", "k_check_idx")):
