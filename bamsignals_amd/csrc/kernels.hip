@@ -1808,6 +1808,29 @@ extern "C" int bsig_debug_set_knob(int which, int value)
     return 0;
 }
 
+// (debug: what the compiler made of the pileup kernels the BASELINE configurations run -- registers per lane and
+// scratch bytes per lane (spills: there must be none); tests/test_gpu_parity.py.  which: 0 k_profile resolved,
+// 1 its 8-wave build, 2 k_profile fused, 3 k_profile_multi (8 waves, four tiles), 4 k_coverage resolved,
+// 5 k_count_multi<4, 2>, 6 k_profile resolved with strands)
+extern "C" int bsig_debug_pileup_attrs(int which, int *vgprs, int *scratch_bytes)
+{
+    const void *f = nullptr;
+    switch (which) {
+    case 0: f = reinterpret_cast<const void *>(&k_profile<64, false, 2, 1, true>); break;
+    case 1: f = reinterpret_cast<const void *>(&k_profile<64, false, 2, 8, true>); break;
+    case 2: f = reinterpret_cast<const void *>(&k_profile<64, false, 2, 1, false>); break;
+    case 3: f = reinterpret_cast<const void *>(&k_profile_multi<false, 2, 8, 4>); break;
+    case 4: f = reinterpret_cast<const void *>(&k_coverage<64, 2, true>); break;
+    case 5: f = reinterpret_cast<const void *>(&k_count_multi<4, 2>); break;
+    case 6: f = reinterpret_cast<const void *>(&k_profile<64, true, 2, 1, true>); break;
+    default: return 1;
+    }
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, f) != hipSuccess) return 2;
+    if (vgprs) *vgprs = a.numRegs;
+    if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
+    return 0;
+}
 #ifdef BSIG_STAMPS
 extern "C" int bsig_debug_set_stamp_buffer(void *buf)
 {

@@ -713,7 +713,16 @@ def test_fuzz_streams(ctx, tmp_path, monkeypatch):
         bam = BamFile(path)
         monkeypatch.setenv("BAMSIGNALS_DEVICE_DECODE", "require")
         monkeypatch.setenv("BAMSIGNALS_INFLATE", "gpu" if case % 2 else "cpu")      # both inflate engines
+        # ... and, with the GPU inflating, both routes: every other such file is streamed into HBM and decoded
+        # in shares of a few blocks behind the stream (chunks from smaller than a block to larger than the file)
+        streamed = case % 4 == 1
+        if streamed:
+            monkeypatch.setenv("BAMSIGNALS_STREAM_MIN_MB", "0")
+            monkeypatch.setenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS", str(int(rng.integers(6, 40))))
+            monkeypatch.setenv("BAMSIGNALS_STREAM_CHUNK_KB", str(int(rng.choice([2, 7, 64, 4096]))))
         dev = Reads.from_bam(ctx, bam)
+        for k in ("BAMSIGNALS_STREAM_MIN_MB", "BAMSIGNALS_INFLATE_ROUND_BLOCKS", "BAMSIGNALS_STREAM_CHUNK_KB"):
+            monkeypatch.delenv(k, raising=False)
         # the same file decoded in 2-4 shares (the multi-GPU route on one GPU): either the shares are
         # proven to tile the stream, or the call steps back to the single decode -- same reads either way
         monkeypatch.setenv("BAMSIGNALS_SHARD_MIN_BLOCKS", "1")

@@ -526,3 +526,22 @@ def test_heavy_tile_slices(ctx, synth, monkeypatch):
         assert np.array_equal(got, want), (kind, a)
     hot.close()
 
+
+def test_pileup_kernels_keep_their_register_budget(ctx):
+    """The pileup launches are bound by their vector instructions and by how many waves a SIMD holds.  Twice in round 4
+    a harmless-looking change moved that: a four-read prefetch of the rare classes held across the packed class's work
+    cost 19 VGPRs (a wave per SIMD), and with one more path on top the 8-wave builds spilled 22-52 registers to
+    scratch (config 5's share 0.16 -> 0.22 ms).  No scratch, and at most 64 VGPRs -- eight waves per SIMD -- for the
+    kernels the BASELINE configurations run."""
+    import ctypes
+    from bamsignals_amd import _lib
+    fn = _lib.load().bsig_debug_pileup_attrs
+    fn.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    names = ["k_profile resolved", "k_profile resolved, 8 waves", "k_profile fused", "k_profile_multi", "k_coverage resolved",
+             "k_count_multi<4, 2>", "k_profile resolved, strands"]
+    for which, name in enumerate(names):
+        regs, scratch = ctypes.c_int(0), ctypes.c_int(-1)
+        assert fn(which, ctypes.byref(regs), ctypes.byref(scratch)) == 0, name
+        assert scratch.value == 0, (name, scratch.value)
+        assert 0 < regs.value <= 64, (name, regs.value)
+
