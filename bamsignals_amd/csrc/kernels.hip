@@ -1579,7 +1579,7 @@ static int knob(int k)
 {
     static const char *const names[6] = {"BAMSIGNALS_PROFILE_PRE", "BAMSIGNALS_COUNT_TILES", "BAMSIGNALS_COUNT_PRE", "BAMSIGNALS_KNOB3",
                                          "BAMSIGNALS_KNOB4", "BAMSIGNALS_PROFILE_TILES"};
-    static const int dflt[6] = {2, 4, 2, 0, 0, 0};
+    static const int dflt[6] = {2, 0, 0, 0, 0, 0};
     if (g_knobs[k] < 0) {
         const char *e = getenv(names[k]);
         g_knobs[k] = e ? atoi(e) : dflt[k];
@@ -1593,9 +1593,11 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
                               uint2 *windows, bool resolve_first, int32_t *out, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
-    // count family: consecutive tiles per wave and class-0 passes in flight (knobs 1 and 2; 4 x 2 measured best
-    // on config 3's tiling, scripts/count_sweep.py)
-    const int count_tiles = knob(1), count_pre = knob(2);
+    // count family: consecutive tiles per wave and packed passes in flight (knobs 1 and 2, 0 = by the launch's size:
+    // 8 x 4 from 65,536 tiles on -- eight tiles per wave still fill every SIMD eight times over --, 4 x 2 below;
+    // scripts/count_sweep.py on config 3's tiling, final build: 1 x 4 0.139 ms, 2 x 2 0.122, 4 x 2 0.112, 8 x 4 0.107)
+    const bool count_large = n_items >= 65536;
+    const int count_tiles = knob(1) > 0 ? knob(1) : count_large ? 8 : 4, count_pre = knob(2) > 0 ? knob(2) : count_large ? 4 : 2;
     if (windows && resolve_first) {
         // P.resolved is set: the windows of every tile first (one lane per tile), with the lookup form of the parameters
         BsigKParams Q = P;

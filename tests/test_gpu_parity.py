@@ -302,6 +302,19 @@ def test_large_launches_look_their_windows_up_in_a_launch_of_their_own(ctx, synt
     want, _ = oracle_c.pileup_core(orc, rg, binsize=-1, ss=True)
     got, _ = _gpu(ctx, gpu, rg, "pileup", binsize=-1, ss=True)
     assert np.array_equal(got, want), (what, "count")
+    # bamCount's forms: 1, 2, 4 or 8 consecutive tiles per wave, 2-4 packed passes in flight (launches of 65,536 tiles
+    # and more take 8 x 4 by themselves, smaller ones 4 x 2), also under a template-length rule
+    from bamsignals_amd import _lib
+    knob = _lib.load().bsig_debug_set_knob
+    try:
+        for tiles, pre in ((1, 2), (2, 3), (4, 2), (8, 4)):
+            assert knob(1, tiles) == 0 and knob(2, pre) == 0
+            for a in (dict(binsize=-1, ss=True), dict(binsize=-1, shift=40, requiredF=66, tlen_filter=(50, 500), pe_mid=True)):
+                want, _ = oracle_c.pileup_core(orc, rg, **a)
+                got, _ = _gpu(ctx, gpu, rg, "pileup", **dict(a))
+                assert np.array_equal(got, want), (what, "count", tiles, pre, a)
+    finally:
+        knob(1, 0); knob(2, 0)
 
 
 @pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
