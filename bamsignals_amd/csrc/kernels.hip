@@ -204,40 +204,50 @@ struct CoverOne {
             atomicAdd(&lds[kb >> 1], (kb & 1) ? -65536 : -1);
         }
     }
-    // Four reads of the packed class at once, when no template-length rule applies (the launch is bound by its
-    // vector instructions: PMC, config 3).  Straight arithmetic on the packed word -- first covered cell
+    // Four reads of the packed class at once (the launch is bound by its vector instructions: PMC, config 3).
+    // Straight arithmetic on the packed word -- first covered cell
     // la = d + A (or B - d - span on a reverse-strand range), last lb = la + span, d = (word - base) & mask -- and two
     // masked LDS adds at the end.
     __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
                                          const uint8_t *__restrict__ ptab) const
     {
         const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
-        if (P.has_tlen_filter | P.tspan) {                     // (uniform)
-            auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
-                const int pos = base + (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
-                (*this)(pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid);
-            };
-            dec(w.x, b0, t.x, dj < nj);
-            dec(w.y, b1, t.y, dj + 1u < nj);
-            dec(w.z, b2, t.z, dj + 2u < nj);
-            dec(w.w, b3, t.w, dj + 3u < nj);
-            return;
+        // (sh rides in K: k = cell index in the image, first covered cell max(ka, sh), one past the last kb)
+        const bool tl_rule = (P.has_tlen_filter | P.tspan) != 0;       // (uniform)
+        if (neg_range) {
+            const int K = rend1 - c0 - base + sh;
+            if (tl_rule) four<true, true>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+            else four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+        } else {
+            const int K = base - loc - c0 + sh;
+            if (tl_rule) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, K);
+            else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, K);
         }
-        // (sh rides in K: k = cell index in the image, first covered cell max(ka, sh), one past the last kb + 1)
-        if (neg_range) four<true>(w, b0, b1, b2, b3, dj, nj, base, rend1 - c0 - base + sh);
-        else four<false>(w, b0, b1, b2, b3, dj, nj, base, base - loc - c0 + sh);
     }
-    template <bool REV>
-    __device__ __forceinline__ void four(const uint4 &w, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj, uint32_t nj,
-                                         int base, int K) const
+    // TL: a template-length rule applies (:398-399 the filter; :404-413 paired.end = "extend": a forward read with
+    // tlen > 0 covers tlen bases from its start, a reverse one with tlen < 0 covers -tlen bases up to its end)
+    template <bool REV, bool TL>
+    __device__ __forceinline__ void four(const uint4 &w, const int4 &t, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj,
+                                         uint32_t nj, int base, int K) const
     {
         const int hi = sh + nc;
-        auto rd = [&](uint32_t x, uint32_t b, uint32_t k) {
+        auto rd = [&](uint32_t x, uint32_t b, int tl, uint32_t k) {
             const int d = (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
             const int sp = (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu);
-            const int rj = (int32_t)(b << 31) >> 31;                       // all ones: rejected
-            const int ka = REV ? K - d - sp : K + d;
-            const int kb = ((ka + sp) | rj) + 1;                           // (a rejected read ends before the tile)
+            int rj = (int32_t)(b << 31) >> 31;                             // all ones: rejected
+            int s0 = d, e0 = d + sp;                                       // first and last covered base, from `base`
+            if (TL) {
+                const int a = tl < 0 ? -tl : tl;
+                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? -1 : 0;
+                if (P.tspan) {
+                    const int nm = (int32_t)(b << 30) >> 31;               // all ones: reverse strand
+                    const int s1 = e0 + tl + 1, e1 = d + tl - 1;
+                    s0 = (nm & (tl < 0 ? -1 : 0)) ? s1 : s0;
+                    e0 = (~nm & (tl > 0 ? -1 : 0)) ? e1 : e0;
+                }
+            }
+            const int ka = REV ? K - e0 : K + s0;
+            const int kb = ((REV ? K - s0 : K + e0) | rj) + 1;             // (a rejected read ends before the tile)
             const bool ok = (dj + k < nj) & (ka < hi) & (kb > sh);
             const bool ok2 = ok & (kb < hi);
             const int ca = ka > sh ? ka : sh;
@@ -249,13 +259,13 @@ struct CoverOne {
             if (ok2) atomicAdd(&img[kb >> 1], 0xFFFFFFFFu << (((uint32_t)kb << 4) & 31u));
         };
         // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
-        rd(w.x, b0, 0u);
+        rd(w.x, b0, t.x, 0u);
         __builtin_amdgcn_sched_barrier(0);
-        rd(w.y, b1, 1u);
+        rd(w.y, b1, t.y, 1u);
         __builtin_amdgcn_sched_barrier(0);
-        rd(w.z, b2, 2u);
+        rd(w.z, b2, t.z, 2u);
         __builtin_amdgcn_sched_barrier(0);
-        rd(w.w, b3, 3u);
+        rd(w.w, b3, t.w, 3u);
     }
 };
 
