@@ -569,6 +569,9 @@ class Workload:
         achieved = st["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                # what the launch really moves per second (PMC bytes / this run's time), beside what the guide calls
+                # achievable on this part (MI355X_MICROARCH.md: 8 TB/s peak, about 6.3 TB/s achievable); informational
+                "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None, "achievable_GBps": 6300.0,
                 "kernel": "k_profile", "kernel_ms": kernel_ms,
                 "algorithmic_bytes": st["algorithmic_bytes"],
                 # SURVEY 8(d)'s layout-agnostic figure 15*V + 16*I + 4*S*C for the same launch
