@@ -1118,13 +1118,11 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
             const BsigWorkItem w2 = items[first + t];
             packed_later_chunks<kWave>(R, P, BSIG_MODE_COUNT, w2, pchunks, make_uint2(0u, 0xFFFFFFFFu), ptab, lane, one);
         }
-        const int c_all = (int)(acc & 0xFFFFu), c_neg = (int)(acc >> 16);
-        int c_anti = neg_range ? c_all - c_neg : c_neg, c_sense = c_all - c_anti;
+        // (the wave's sum stays packed: a tile that is not sliced has at most 32,768 reads in its windows)
 #pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) {
-            c_sense += __shfl_xor(c_sense, d);
-            c_anti += __shfl_xor(c_anti, d);
-        }
+        for (int d = kWave / 2; d > 0; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d);
+        const int c_all = (int)(acc & 0xFFFFu), c_neg = (int)(acc >> 16);
+        const int c_anti = neg_range ? c_all - c_neg : c_neg, c_sense = c_all - c_anti;
         if (lane == t) { my_sense = c_sense; my_anti = c_anti; }
     }
     if (have) {
