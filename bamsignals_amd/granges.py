@@ -28,6 +28,13 @@ class GRanges:
         bad = set(self.strand) - {"+", "-", "*"}
         if bad:
             raise ValueError(f"invalid strand values {sorted(bad)}")
+        # seqnames and strand as GenomicRanges holds them -- factor codes + levels (ref: src/bamsignals.cpp:97-104 reads
+        # exactly those): encoded once here, not on every call that flattens the ranges for the C ABI
+        self._levels = list(dict.fromkeys(self.seqnames))
+        lut = {s: k for k, s in enumerate(self._levels)}
+        self._codes = np.fromiter((lut[s] for s in self.seqnames), dtype=np.int32, count=n)
+        smap = {"+": 1, "-": -1, "*": 0}
+        self._strand_int = np.fromiter((smap[s] for s in self.strand), dtype=np.int32, count=n)
 
     def __len__(self):
         return len(self.start)
@@ -44,11 +51,7 @@ class GRanges:
 
     def flatten(self):
         """(levels, codes, start, width, strand_int) as the C ABI's file-level entry points take them."""
-        levels = list(dict.fromkeys(self.seqnames))
-        lut = {s: k for k, s in enumerate(levels)}
-        codes = np.asarray([lut[s] for s in self.seqnames], dtype=np.int32)
-        strand = np.asarray([1 if s == "+" else -1 if s == "-" else 0 for s in self.strand], dtype=np.int32)
-        return levels, codes, self.start, self.width, strand
+        return self._levels, self._codes, self.start, self.width, self._strand_int
 
     def __repr__(self):
         head = ", ".join(f"{s}:{a}-{b}:{t}" for s, a, b, t in

@@ -46,6 +46,8 @@ for r in range(rounds):
         res[i] += [c["call_s"] for c in warm]
         print(v, "round", r, "warm calls", [round(c["call_s"], 4) for c in warm], "download", [round(c["stages_s"].get("download", 0), 4) for c in warm],
               "cold", round(child["calls"][0]["call_s"], 3), flush=True)
+        if r == 0:
+            print("   stages of the last warm call:", {k: (round(x, 4) if isinstance(x, float) else x) for k, x in warm[-1]["stages_s"].items()}, flush=True)
 for i, v in enumerate(variants):
     print(v, "median warm call %.4f s" % float(np.median(res[i])))
 shutil.rmtree(d, ignore_errors=True)
