@@ -176,6 +176,79 @@ struct ProfileOne {
     }
 };
 
+// bamProfile's per-read work on the wide-bin image of k_profile_small: 32-bit cells in the lane's own replica.
+template <bool SS>
+struct SmallOne {
+    const BsigKParams &P;
+    int32_t *mine;
+    int loc, len, c0, nc;
+    bool neg_range;
+    __device__ __forceinline__ void operator()(int p, int e, bool neg, bool rej, int tl, bool valid) const
+    {
+        constexpr int S = SS ? 2 : 1;
+        if (!valid || rej || tlen_rejected(P, tl)) return;
+        const int a = tl < 0 ? -tl : tl;
+        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
+        const int p5 = neg ? e - offset : p + offset;
+        int rel = p5 - loc;
+        if ((unsigned)rel >= (unsigned)len) return;
+        int anti = neg ? 1 : 0;
+        if (neg_range) { rel = len - rel - 1; anti ^= 1; }
+        const int cell = P.binsize == 1 ? rel : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
+        const int lc = cell - c0;
+        if ((unsigned)lc < (unsigned)nc) atomicAdd(&mine[lc * S + (SS ? anti : 0)], 1);
+    }
+    // four packed reads at once, as ProfileOne::quad, with the bin of the range-oriented position by the exact magic
+    // multiply (the position must lie inside the range for it: that test cannot ride on the cell test here)
+    __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
+                                         const uint8_t *__restrict__ ptab) const
+    {
+        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
+        const bool tl_rule = (P.has_tlen_filter | P.midpoint) != 0;    // (uniform)
+        const int A = base - loc + P.shift;
+        if (neg_range) {
+            if (tl_rule) four<true, true>(w, t, b0, b1, b2, b3, dj, nj, base, len - 1 - A);
+            else four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, len - 1 - A);
+        } else {
+            if (tl_rule) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, A);
+            else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, A);
+        }
+    }
+    template <bool REV, bool TL>
+    __device__ __forceinline__ void four(const uint4 &w, const int4 &t, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj,
+                                         uint32_t nj, int base, int K) const
+    {
+        const uint32_t cd = (uint32_t)(-2 * P.shift);
+        const bool binned = P.binsize != 1;                            // (uniform)
+        auto rd = [&](uint32_t x, uint32_t b, int tl, uint32_t k) {
+            const uint32_t d = (x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u);
+            const uint32_t sp = (x >> BSIG_PACK_POS_BITS) & 0xFFu;
+            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31);
+            uint32_t rj = (uint32_t)((int32_t)(b << 31) >> 31), h = 0;
+            if (TL) {
+                const int a = tl < 0 ? -tl : tl;
+                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? 0xFFFFFFFFu : 0u;
+                if (P.midpoint) h = (uint32_t)(a >> 1);
+            }
+            const uint32_t fwd = d + h + (nm & (sp + cd - 2u * h));
+            const uint32_t rel = (REV ? (uint32_t)K - fwd : (uint32_t)K + fwd) | rj;      // position in range orientation
+            const uint32_t cell = binned ? __umulhi(rel, P.div_magic) >> P.div_shift : rel;
+            const uint32_t lc = cell - (uint32_t)c0;
+            const bool ok = (dj + k < nj) & (rel < (uint32_t)len) & (lc < (uint32_t)nc);
+            const uint32_t idx = SS ? 2u * lc + ((REV ? ~nm : nm) & 1u) : lc;
+            if (ok) atomicAdd(&mine[idx], 1);
+        };
+        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
+        rd(w.x, b0, t.x, 0u);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(w.y, b1, t.y, 1u);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(w.z, b2, t.z, 2u);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(w.w, b3, t.w, 3u);
+    }
+};
+
 // bamCoverage's per-read work (ref: src/bamsignals.cpp:392-438): +1 where the read begins to cover the tile, -1 behind
 // its last covered cell, in the tile's difference array of signed 16-bit cells (two per LDS dword: see k_coverage).
 struct CoverOne {
@@ -974,20 +1047,7 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     int32_t *mine = lds + (tid & (n_rep - 1)) * stride;
 
-    auto one = [&](int p, int e, bool neg, bool rej, int tl, bool valid) {
-        if (!valid || rej || tlen_rejected(P, tl)) return;
-        const int a = tl < 0 ? -tl : tl;
-        const int offset = P.midpoint ? (a >> 1) + P.shift : P.shift;
-        const int p5 = neg ? e - offset : p + offset;
-        int rel = p5 - w.loc;
-        if ((unsigned)rel >= (unsigned)w.len) return;
-        int anti = neg ? 1 : 0;
-        if (neg_range) { rel = w.len - rel - 1; anti ^= 1; }
-        const int cell = P.binsize == 1 ? rel
-                                        : (int)(__umulhi((uint32_t)rel, P.div_magic) >> P.div_shift);
-        const int lc = cell - w.c0;
-        if ((unsigned)lc < (unsigned)w.nc) atomicAdd(&mine[lc * S + (SS ? anti : 0)], 1);
-    };
+    const SmallOne<SS> one{P, mine, w.loc, w.len, w.c0, w.nc, neg_range};
     for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
     if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_PROFILE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();

@@ -4,7 +4,8 @@ JSON line with the HIP-event time per launch and the plan's algorithmic bytes.
    C3     bamCoverage, chr1 (248,956,422 bp) in 2-kb tiles, 1e8 SE reads      -> k_coverage<64>
    C4     bamProfile PE filter tlenFilter=c(50,500) shift=75 ss=TRUE, 100k x 2 kb, 1e8 PE reads on 250 Mbp -> k_profile<64, true>
    C4mid  the same with paired.end="midpoint"
-   count  bamCount on C3's tiling                                             -> k_count<64>"""
+   count  bamCount on C3's tiling                                             -> k_count_multi
+   bins   bamProfile binsize=200 ss=TRUE, 100k x 2 kb on the C3 reads (the wide-bin form a ChIP-seq caller uses) -> k_profile_small"""
 import json
 import os
 import sys
@@ -30,6 +31,12 @@ def main():
             rgs = [tile_ranges([L], 2000)]
             prm = make_params(_lib.MODE_COVERAGE) if case == "C3" else make_params(_lib.MODE_COUNT, binsize=-1)
             name = ("C3: bamCoverage, chr1 2-kb tiling, 1e8 SE reads" if case == "C3" else "bamCount on C3's tiling, 1e8 SE reads")
+        elif case == "bins":
+            L = 248_956_422
+            cols = synth_reads(100_000_000, [L], seed=3, with_cigar=False)
+            rgs = [synth_ranges(100_000, 2000, [L], seed=20 + b) for b in range(2)]
+            prm = make_params(_lib.MODE_PROFILE, binsize=200, ss=True)
+            name = "bamProfile binsize=200 ss=TRUE, 100k x 2kb, 1e8 SE reads on 249 Mbp"
         elif case in ("C4", "C4mid"):
             cols = synth_reads(100_000_000, [250_000_000], seed=9, paired=True, with_cigar=False)
             rgs = [synth_ranges(100_000, 2000, [250_000_000], seed=10 + b) for b in range(2)]
