@@ -572,26 +572,17 @@ struct Staging {
         cap = bytes;
         return BSIG_OK;
     }
-    // the raw file stream of a streamed decode (RawStream below): a page-locked pair, events and a stream of its
-    // own, held (raw_mu) by one streamed decode at a time -- beside whoever holds `mu` for a share
+    // the raw file stream of a streamed decode (RawStream below): events and a stream of its own, held (raw_mu) by
+    // one streamed decode at a time -- beside whoever holds `mu` for a share; the page-locked halves it streams
+    // through are the device's PinnedPair (runtime_internal.h), which the result download uses after it
     std::mutex raw_mu;
-    uint8_t *raw_buf[2] = {nullptr, nullptr};
-    size_t raw_cap = 0;
     hipEvent_t raw_ev[2] = {nullptr, nullptr};
     hipStream_t s_raw = nullptr;
-    int ensure_raw(size_t bytes)
+    int ensure_raw()
     {
         if (!s_raw) HIP_TRY(hipStreamCreateWithFlags(&s_raw, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k)
             if (!raw_ev[k]) HIP_TRY(hipEventCreateWithFlags(&raw_ev[k], hipEventDisableTiming));
-        if (raw_cap >= bytes) return BSIG_OK;
-        for (int k = 0; k < 2; ++k) {
-            if (raw_buf[k]) (void)bsig::metered_host_free(raw_buf[k]);
-            raw_buf[k] = nullptr;
-        }
-        raw_cap = 0;
-        for (int k = 0; k < 2; ++k) HIP_TRY(bsig::metered_host_malloc((void **)&raw_buf[k], bytes));
-        raw_cap = bytes;
         return BSIG_OK;
     }
 };
@@ -829,6 +820,7 @@ struct RawStream {
     const BgzfFile &f;
     const int device, threads;
     Staging &S;
+    uint8_t *const *const halves;       // the device's page-locked pair (the caller holds it)
     const size_t chunk;
     uint8_t *const d_file;
     std::mutex mu;
@@ -841,8 +833,8 @@ struct RawStream {
     std::thread th;
     double t_read = 0, t_half = 0;      // the stream's own time: reading chunks, waiting for a free half
 
-    RawStream(const BgzfFile &file, int dev, int thr, Staging &st, size_t chunk_bytes, uint8_t *dst)
-        : f(file), device(dev), threads(thr), S(st), chunk(chunk_bytes), d_file(dst) {}
+    RawStream(const BgzfFile &file, int dev, int thr, Staging &st, uint8_t *const *pair, size_t chunk_bytes, uint8_t *dst)
+        : f(file), device(dev), threads(thr), S(st), halves(pair), chunk(chunk_bytes), d_file(dst) {}
     ~RawStream() { halt(); }
     void start()
     {
@@ -887,14 +879,14 @@ struct RawStream {
             int walk_rc = 0;
             const double t0 = now_s();
             bsig::pool_for(n_runs + walk_prev, threads, [&](int64_t q) {
-                if (walk_prev && q == 0) { walk_rc = w.chunk(S.raw_buf[h ^ 1], p0, plen, size, fresh); return; }
+                if (walk_prev && q == 0) { walk_rc = w.chunk(halves[h ^ 1], p0, plen, size, fresh); return; }
                 const uint64_t at = (uint64_t)(q - walk_prev) * per_run;
-                if (!f.read_span(c0 + at, (size_t)std::min<uint64_t>(per_run, len - at), S.raw_buf[h] + at)) bad.store(1);
+                if (!f.read_span(c0 + at, (size_t)std::min<uint64_t>(per_run, len - at), halves[h] + at)) bad.store(1);
             });
             t_read += now_s() - t0;
             if (bad.load() || walk_rc) { bad_rc = kNeedsCpuPath; break; }        // (the ordinary path reports what is wrong)
             if (len) {
-                hipError_t e = hipMemcpyAsync(d_file + c0, S.raw_buf[h], len, hipMemcpyHostToDevice, S.s_raw);
+                hipError_t e = hipMemcpyAsync(d_file + c0, halves[h], len, hipMemcpyHostToDevice, S.s_raw);
                 if (e == hipSuccess) e = hipEventRecord(S.raw_ev[h], S.s_raw);
                 if (e != hipSuccess) { bad_rc = fail(BSIG_ERR_DEVICE, "streaming the file to the device failed: %s", hipGetErrorString(e)); break; }
                 used[h] = true;
@@ -1762,13 +1754,17 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
         };
         try { side.th = std::thread(body); } catch (const std::system_error &) {}
     }
-    int rc = S.ensure_raw(chunk);
+    int rc = S.ensure_raw();
+    if (rc) return rc;
+    bsig::PinnedPair &pair = bsig::pinned_pair_for(ctx->device);
+    std::unique_lock<std::mutex> pair_lock(pair.mu);       // (until the stream has ended)
+    rc = pair.ensure(chunk);
     if (rc) return rc;
     ScratchPool file_pool(ctx->device, ctx->stream);
     uint8_t *d_file = nullptr;
     HIP_TRY(file_pool.alloc(&d_file, (size_t)size + 64 + ScratchPool::kSmall));      // (a block of its own: it goes back before the layout)
     diag_mark("streamed: page-locked pair + the file's device buffer");
-    RawStream rs(F.f, ctx->device, threads, S, chunk, d_file);
+    RawStream rs(F.f, ctx->device, threads, S, pair.buf, chunk, d_file);
     const double t_stream = now_s();
     rs.start();
     double fill_env = -1;
@@ -1864,6 +1860,7 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
         B = Bend;
     }
     rs.halt();
+    pair_lock.unlock();
     if (getenv("BSIG_DIAG_DECODE"))
         fprintf(stderr, "streamed: the stream read for %.1f ms and waited %.1f ms for a free half\n", rs.t_read * 1e3, rs.t_half * 1e3);
     if (rc) return rc;

@@ -748,15 +748,12 @@ namespace {
 // threads move each half on into the destination while the next one is in flight.
 struct DownloadStage {
     std::mutex mu;
-    uint8_t *buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
-    static constexpr size_t kHalf = 32u << 20;
+    static constexpr size_t kHalf = 32u << 20;          // (the halves are the device's PinnedPair)
     int ensure()
     {
-        for (int k = 0; k < 2; ++k) {
-            if (!buf[k]) HIP_TRY(bsig::metered_host_malloc((void **)&buf[k], kHalf));
+        for (int k = 0; k < 2; ++k)
             if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-        }
         return BSIG_OK;
     }
 };
@@ -772,6 +769,30 @@ DownloadStage &download_for(int device)
     return *all.back().second;
 }
 
+}  // namespace
+int bsig::PinnedPair::ensure(size_t bytes)
+{
+    if (cap >= bytes) return BSIG_OK;
+    for (int k = 0; k < 2; ++k) {
+        if (buf[k]) (void)bsig::metered_host_free(buf[k]);
+        buf[k] = nullptr;
+    }
+    cap = 0;
+    for (int k = 0; k < 2; ++k) HIP_TRY(bsig::metered_host_malloc((void **)&buf[k], bytes));
+    cap = bytes;
+    return BSIG_OK;
+}
+bsig::PinnedPair &bsig::pinned_pair_for(int device)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, PinnedPair *>> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : all)
+        if (kv.first == device) return *kv.second;
+    all.emplace_back(device, new PinnedPair);
+    return *all.back().second;
+}
+namespace {
 bool is_pinned_host(const void *p)
 {
     hipPointerAttribute_t a;
@@ -790,7 +811,11 @@ int download_staged(int device, hipStream_t st, const std::vector<DlSlice> &slic
     DownloadStage &g_download = download_for(device);
     std::lock_guard<std::mutex> lock(g_download.mu);
     HIP_TRY(hipSetDevice(device));
-    const int rc = g_download.ensure();
+    int rc = g_download.ensure();
+    if (rc) return rc;
+    bsig::PinnedPair &pair = bsig::pinned_pair_for(device);
+    std::lock_guard<std::mutex> pair_lock(pair.mu);
+    rc = pair.ensure(DownloadStage::kHalf);
     if (rc) return rc;
     const size_t half = DownloadStage::kHalf;
     struct Part { size_t at; const uint8_t *src; size_t len; int64_t dst_c0; };      // `at`: offset in the half
@@ -825,7 +850,7 @@ int download_staged(int device, hipStream_t st, const std::vector<DlSlice> &slic
         const Chunk &C = chunks[c];
         const size_t a = (C.len * (size_t)t / (size_t)n_thr) & ~(size_t)3;
         const size_t b = t + 1 == n_thr ? C.len : (C.len * (size_t)(t + 1) / (size_t)n_thr) & ~(size_t)3;
-        const uint8_t *buf = g_download.buf[c & 1];
+        const uint8_t *buf = pair.buf[c & 1];
         for (size_t p = C.p0; p < C.p1 && a < b; ++p) {
             const Part &P = parts[p];
             const size_t lo = std::max(a, P.at), hi = std::min(b, P.at + P.len);
@@ -848,7 +873,7 @@ int download_staged(int device, hipStream_t st, const std::vector<DlSlice> &slic
     auto issue = [&](size_t c) {
         const Chunk &C = chunks[c];
         for (size_t p = C.p0; p < C.p1 && e == hipSuccess; ++p)
-            e = hipMemcpyAsync(g_download.buf[c & 1] + parts[p].at, parts[p].src, parts[p].len, hipMemcpyDeviceToHost, st);
+            e = hipMemcpyAsync(pair.buf[c & 1] + parts[p].at, parts[p].src, parts[p].len, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipEventRecord(g_download.ev[c & 1], st);
     };
     for (size_t c = 0; c < std::min<size_t>(2, n_chunks) && e == hipSuccess; ++c) issue(c);
@@ -1083,7 +1108,11 @@ int upload_staged(int device, hipStream_t st, const uint8_t *src, uint8_t *dst_d
     DownloadStage &D = download_for(device);
     std::lock_guard<std::mutex> lock(D.mu);
     HIP_TRY(hipSetDevice(device));
-    const int rc = D.ensure();
+    int rc = D.ensure();
+    if (rc) return rc;
+    bsig::PinnedPair &pair = bsig::pinned_pair_for(device);
+    std::lock_guard<std::mutex> pair_lock(pair.mu);
+    rc = pair.ensure(DownloadStage::kHalf);
     if (rc) return rc;
     const size_t half = DownloadStage::kHalf;
     int n_thr = 8;
@@ -1097,12 +1126,12 @@ int upload_staged(int device, hipStream_t st, const uint8_t *src, uint8_t *dst_d
         std::vector<std::thread> th;
         auto part = [&](int t) {
             const size_t a = len * (size_t)t / (size_t)n_thr, b = len * (size_t)(t + 1) / (size_t)n_thr;
-            if (b > a) memcpy(D.buf[h] + a, src + at + a, b - a);
+            if (b > a) memcpy(pair.buf[h] + a, src + at + a, b - a);
         };
         for (int t = 1; t < n_thr; ++t) th.emplace_back(part, t);
         part(0);
         for (auto &x : th) x.join();
-        HIP_TRY(hipMemcpyAsync(dst_dev + at, D.buf[h], len, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dst_dev + at, pair.buf[h], len, hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(D.ev[h], st));
         used[h] = true;
     }

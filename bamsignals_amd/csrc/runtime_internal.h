@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cstdint>
 #include <string>
@@ -53,6 +54,16 @@ inline hipError_t metered_malloc(void **p, size_t bytes) { AllocTimer t; return 
 inline hipError_t metered_free(void *p) { AllocTimer t; return hipFree(p); }
 inline hipError_t metered_host_malloc(void **p, size_t bytes) { AllocTimer t; return hipHostMalloc(p, bytes, hipHostMallocDefault); }
 inline hipError_t metered_host_free(void *p) { AllocTimer t; return hipHostFree(p); }
+// Two page-locked halves of at least `bytes` each, one pair per GPU, for whoever moves bulk data through the host on
+// that GPU: the streamed decode on the way in, the result download on the way out.  Pinning 2 x 32 MB costs 10 ms, and
+// a session's first call used to pay it once for each.  The holder keeps `mu` for as long as it uses the halves.
+struct PinnedPair {
+    std::mutex mu;
+    uint8_t *buf[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    int ensure(size_t bytes);          // (holding mu; the device current)
+};
+PinnedPair &pinned_pair_for(int device);
 // *got receives the block's real size (>= bytes), which block_free wants back
 hipError_t block_alloc(int device, size_t bytes, double max_waste, void **p, size_t *got);
 void block_free(int device, void *p, size_t bytes);
