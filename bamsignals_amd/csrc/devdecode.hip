@@ -979,6 +979,40 @@ struct Piece {
     }
 };
 
+// One set of columns for ALL the shares of a streamed decode: every share's extraction writes behind the share
+// before it, and the layout reads the columns where they are -- no piece per share, no join (15 bytes per read in and
+// out again: 4.7 ms and a second 7.5 GB for the north star's 5e8 reads).  Sized by the first share's reads per byte
+// of stream with some head-room; a share it cannot hold takes a piece of its own and the pieces are joined as before.
+struct ColumnArena {
+    int32_t *pos = nullptr, *end = nullptr, *tlen = nullptr;
+    uint16_t *flag = nullptr;
+    uint8_t *mapq = nullptr;
+    int64_t cap = 0, used = 0;
+    hipError_t make(ScratchPool &pool, int64_t cap_reads)
+    {
+        const size_t c4 = ((size_t)cap_reads * 4 + 255) & ~(size_t)255, c2 = ((size_t)cap_reads * 2 + 255) & ~(size_t)255,
+                     c1 = ((size_t)cap_reads + 255) & ~(size_t)255;
+        uint8_t *base = nullptr;
+        const hipError_t e = pool.alloc(&base, 3 * c4 + c2 + c1 + ScratchPool::kSmall);
+        if (e != hipSuccess) return e;
+        pos = (int32_t *)base;
+        end = (int32_t *)(base + c4);
+        tlen = (int32_t *)(base + 2 * c4);
+        flag = (uint16_t *)(base + 3 * c4);
+        mapq = base + 3 * c4 + c2;
+        cap = cap_reads;
+        return hipSuccess;
+    }
+    bool take(Piece &pc, int64_t n)
+    {
+        if (!pos || used + n > cap) return false;
+        pc.pos = pos + used; pc.end = end + used; pc.tlen = tlen + used; pc.flag = flag + used; pc.mapq = mapq + used;
+        pc.n = n;
+        used += n;
+        return true;
+    }
+};
+
 // env BSIG_DIAG_DECODE: wall time since the previous mark, per call site (where do 2-3 s stalls come from?)
 void diag_mark(const char *what)
 {
@@ -1060,9 +1094,20 @@ int finish_reads(bsig_ctx *ctx, hipStream_t st, ScratchPool &tmp, std::vector<st
         return BSIG_OK;
     }
     Piece whole;
+    // (pieces that lie back to back -- the shares of a streamed decode in their ColumnArena -- are the columns already)
+    bool back_to_back = pieces.size() > 1;
+    for (size_t k = 0; back_to_back && k + 1 < pieces.size(); ++k) {
+        const Piece &a = *pieces[k], &b = *pieces[k + 1];
+        back_to_back = b.pos == a.pos + a.n && b.end == a.end + a.n && b.tlen == a.tlen + a.n && b.flag == a.flag + a.n && b.mapq == a.mapq + a.n;
+    }
+    if (back_to_back) {
+        whole = *pieces[0];
+        whole.n = n_reads;
+        if (getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "columns: %zu pieces lie back to back, nothing to join\n", pieces.size());
+    }
     Piece *cols = pieces.size() == 1 ? pieces[0].get() : &whole;
     hipError_t e = hipSuccess;
-    if (pieces.size() > 1) {
+    if (pieces.size() > 1 && !back_to_back) {
         e = whole.alloc(tmp, n_reads);
         int64_t at = 0;
         for (auto &pp : pieces) {
@@ -1133,7 +1178,8 @@ constexpr size_t kOverlapBlocks = 4;
 // (the whole-file decode sizes its reservation of the resident columns by it).
 int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const std::vector<uint64_t> &uoff, size_t Bbeg,
                  size_t Bend, int threads, bool gpu_inflate, ShareOut &R, bool more_follow = false, bool no_ramp = false,
-                 const std::function<void(int64_t, uint64_t)> *after_first_pass = nullptr, RawStream *raw = nullptr)
+                 const std::function<void(int64_t, uint64_t)> *after_first_pass = nullptr, RawStream *raw = nullptr,
+                 ColumnArena *arena = nullptr)
 {
     // raw: the compressed file is (being) streamed into raw->d_file at its file offsets (GPU inflate only): nothing
     // is packed or copied here, a pass waits until the stream has passed its last block
@@ -1580,7 +1626,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         if (n_chunk > 0) {
             R.pieces.emplace_back(new Piece);
             Piece &pc = *R.pieces.back();
-            DD_TRY(pc.alloc(tmp, n_chunk));
+            if (!(arena && arena->take(pc, n_chunk))) DD_TRY(pc.alloc(tmp, n_chunk));
             DD_TRY(hipMemcpyAsync(d_seg_n, seg_n.data(), (size_t)n_seg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             DD_TRY(hipMemcpyAsync(d_seg_base, seg_base.data(), (size_t)n_seg * sizeof(int64_t), hipMemcpyHostToDevice, st));
             DD_TRY(hipMemcpyAsync(d_seg_prev, seg_prev.data(), (size_t)n_seg * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1771,6 +1817,7 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
     if (const char *e = getenv("BAMSIGNALS_STREAM_FILL_MS")) fill_env = atof(e) * 1e-3;
 
     Reservation reserved;
+    ColumnArena arena;
     g_reserved_bytes = 0;
     g_reserve_wait = 0;
     const std::function<void(int64_t, uint64_t)> reserve = [&](int64_t n_first, uint64_t bytes_first) {
@@ -1778,6 +1825,12 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
         const BgzfBlock &lb = F.f.blocks().back();
         const double stream_bytes = (double)F.uoff.back() * (double)size / (double)std::max<uint64_t>(lb.coff + lb.csize, 1);
         const double est_reads = (double)n_first * stream_bytes / (double)bytes_first;
+        // one set of columns for all the shares (synthetic and real files hold their reads per byte within a percent
+        // or two along the file; a share that does not fit takes a piece of its own).  env BAMSIGNALS_COLUMN_ARENA:
+        // 0 = none, a number = the head-room factor (tests: 1.05 on small files, 0.5 for shares that do not fit)
+        const char *ae = getenv("BAMSIGNALS_COLUMN_ARENA");
+        const double room = ae ? atof(ae) : est_reads >= 1e7 ? 1.05 : 0.0;
+        if (room > 0 && arena.make(file_pool, (int64_t)(est_reads * room) + (ae ? 16 : 1 << 20)) != hipSuccess) (void)hipGetLastError();
         if (est_reads < 1e7) return;
         const size_t want = (size_t)(est_reads * 8.6 * 1.10) + ((size_t)32 << 20);
         reserved.start(ctx->device, want);
@@ -1854,7 +1907,7 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
         const size_t Bend = complete ? (nb <= want_end + kOverlapBlocks ? nb : want_end) : std::min(want_end, nb - kOverlapBlocks);
         last = complete && Bend == nb;
         sh.emplace_back();
-        rc = decode_share(ctx, F.f, F.hdr, F.uoff, B, Bend, threads, true, sh.back(), !complete, true, B == 0 ? &reserve : nullptr, &rs);
+        rc = decode_share(ctx, F.f, F.hdr, F.uoff, B, Bend, threads, true, sh.back(), !complete, true, B == 0 ? &reserve : nullptr, &rs, &arena);
         if (getenv("BSIG_DIAG_DECODE")) fprintf(stderr, "streamed: share of blocks [%zu, %zu) done (rc %d)\n", B, Bend, rc);
         if (rc) break;
         B = Bend;

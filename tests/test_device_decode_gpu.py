@@ -376,7 +376,14 @@ def test_large_files_are_streamed_into_hbm_and_decoded_round_by_round(ctx, tmp_p
     write_columns_as_bam(path, ["a", "b", "empty", "c"], cols)                # ~1,200 blocks
     files.append((path, 1_500_000))
     for f, n_reads in files:
-        for rnd, chunk_kb in ((7, "3"), (40, "100"), (64, "5000"), (100000, None)):
+        # ... and the shares' extractions write into ONE set of columns sized by the first share's reads per byte
+        # (large files by themselves; here by request): with head-room, and too small -- the shares that do not fit
+        # take pieces of their own and everything is joined as before
+        for rnd, chunk_kb, arena in ((7, "3", "1.05"), (40, "100", "0.5"), (64, "5000", None), (100000, None, "1.05")):
+            if arena:
+                monkeypatch.setenv("BAMSIGNALS_COLUMN_ARENA", arena)
+            else:
+                monkeypatch.delenv("BAMSIGNALS_COLUMN_ARENA", raising=False)
             monkeypatch.setenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS", str(rnd))
             if chunk_kb:
                 monkeypatch.setenv("BAMSIGNALS_STREAM_CHUNK_KB", chunk_kb)
@@ -390,11 +397,14 @@ def test_large_files_are_streamed_into_hbm_and_decoded_round_by_round(ctx, tmp_p
             dev.close()
             err = capfd.readouterr().err
             assert "streamed: all shares" in err and "the ordinary route" not in err, (f, rnd, chunk_kb, err[-600:])
+            if rnd < 100:
+                assert ("nothing to join" in err) == (arena == "1.05"), (f, rnd, arena)
             shares = [(int(a), int(b)) for a, b in re.findall(r"streamed: share of blocks \[(\d+), (\d+)\) done", err)]
             assert shares[0][0] == 0 and all(x[1] == y[0] for x, y in zip(shares, shares[1:])), shares
             own = rnd - 4 if rnd > 8 else rnd                                 # (a share sees four blocks beyond its own: one round in all)
             assert all(0 < b - a <= own for a, b in shares[:-1]) and 0 < shares[-1][1] - shares[-1][0] <= own + 4, (rnd, shares)
     # the engine choice still holds: a few badly compressible blocks are the CPU pool's, whatever the route
+    monkeypatch.delenv("BAMSIGNALS_COLUMN_ARENA", raising=False)
     monkeypatch.delenv("BAMSIGNALS_INFLATE_ROUND_BLOCKS")
     monkeypatch.delenv("BAMSIGNALS_INFLATE")
     capfd.readouterr()
