@@ -1404,12 +1404,17 @@ __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n
     int32_t my_max[BSIG_MAX_CLASSES];
 #pragma unroll
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c) { my_cnt[c] = 0; my_max[c] = 0; }
+    // (a chunk of 2,048 reads nearly always lies inside one reference: the search over the references' first reads,
+    // four dependent loads per read, is made for the chunk's two ends -- uniform, scalar loads -- and per read only
+    // where they differ)
+    const int64_t last = (base + kPrepChunk < n ? base + kPrepChunk : n) - 1;
+    const int rf_lo = ref_of_read(ref_off, n_ref, base < n ? base : n - 1), rf_hi = ref_of_read(ref_off, n_ref, last);
     for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
         const int64_t i = base + r * kPrepThreads + tid;
         if (i < n) {
             const int p = pos[i];
             const int span = end[i] - p + 1;
-            const int rf = ref_of_read(ref_off, n_ref, i);
+            const int rf = rf_lo == rf_hi ? rf_lo : ref_of_read(ref_off, n_ref, i);
             uint32_t code;
             const int c = read_class(span, flag[i], mapq[i], p, (int64_t)ref_units[rf] << BSIG_REF_UNIT_SHIFT, codemap, code);
 #pragma unroll
@@ -1471,6 +1476,9 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
     if (tid < BSIG_MAX_CLASSES) run[tid] = chunk_base[(int64_t)blockIdx.x * BSIG_MAX_CLASSES + tid];
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kPrepChunk;
+    // (the chunk's reference from its two ends, per read only where they differ: see k_span_hist)
+    const int64_t last = (base + kPrepChunk < n ? base + kPrepChunk : n) - 1;
+    const int rf_lo = ref_of_read(ref_off, n_ref, base < n ? base : n - 1), rf_hi = ref_of_read(ref_off, n_ref, last);
     for (int r = 0; r < kPrepChunk / kPrepThreads; ++r) {
         const int64_t i = base + r * kPrepThreads + tid;
         const bool valid = i < n;
@@ -1478,7 +1486,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_scatter(int64_t n, int32_t n_r
         uint32_t code = 0;
         if (valid) {
             p = pos[i]; e = end[i];
-            rf = ref_of_read(ref_off, n_ref, i);
+            rf = rf_lo == rf_hi ? rf_lo : ref_of_read(ref_off, n_ref, i);
             cls = read_class(e - p + 1, flag[i], mapq[i], p, (int64_t)ref_units[rf] << BSIG_REF_UNIT_SHIFT, codemap, code);
         }
         uint32_t rank = 0;
