@@ -2840,6 +2840,35 @@ int bsig_reads_from_bam_regions(bsig_ctx *ctx, bsig_bam *bam, int64_t n_regions,
     return bsig_reads_upload(ctx, &cols, reads);
 }
 
+// (debug, host only -- no GPU is touched: the block table as RawStream's header walk builds it, the file fed in chunks
+// of chunk_bytes; tests compare it with the mapped walk for chunks from a few bytes to more than the file.  Returns
+// BSIG_OK, or BSIG_ERR_FORMAT where the walk declines (the streamed decode then takes the ordinary route))
+int bsig_debug_stream_walk(const char *path, int64_t chunk_bytes, int64_t *n_blocks, uint64_t *checksum)
+{
+    if (!path || !n_blocks || !checksum || chunk_bytes <= 0) return fail(BSIG_ERR_ARG, "bad argument");
+    bsig::BgzfFile f;
+    if (f.map(path)) return BSIG_ERR_IO;
+    const uint64_t size = f.size();
+    std::vector<uint8_t> buf((size_t)std::min<uint64_t>((uint64_t)chunk_bytes, std::max<uint64_t>(size, 1)));
+    RawStream::Walk w;
+    std::vector<bsig::BgzfBlock> blocks;
+    for (uint64_t c0 = 0; c0 < size; c0 += (uint64_t)chunk_bytes) {
+        const uint64_t len = std::min<uint64_t>((uint64_t)chunk_bytes, size - c0);
+        if (!f.read_span(c0, (size_t)len, buf.data())) return fail(BSIG_ERR_IO, "cannot read %s", path);
+        if (w.chunk(buf.data(), c0, len, size, blocks)) return fail(BSIG_ERR_FORMAT, "the stream's header walk declines this file");
+    }
+    if (w.next != size) return fail(BSIG_ERR_FORMAT, "the stream's header walk declines this file");
+    uint64_t h = 1469598103934665603ull;
+    for (const bsig::BgzfBlock &b : blocks)
+        for (uint64_t v : {(uint64_t)b.coff, (uint64_t)b.csize, (uint64_t)b.doff, (uint64_t)b.dlen, (uint64_t)b.isize, (uint64_t)b.crc}) {
+            h ^= v;
+            h *= 1099511628211ull;
+        }
+    *n_blocks = (int64_t)blocks.size();
+    *checksum = h;
+    return BSIG_OK;
+}
+
 void bsig_device_decode_timing(double *t6)
 {
     for (int k = 0; k < 6; ++k) t6[k] = g_dev_decode_timing[k];

@@ -572,3 +572,53 @@ def test_csi_index_of_a_multibin_bam(tmp_path):
         b.close()
         os.remove(q + ".csi")
     ref.close()
+
+
+def test_the_streams_header_walk_gives_the_same_block_table(tmp_path, monkeypatch):
+    """Large files are streamed into HBM in chunks and the BGZF block table is read off the chunks on their way
+    (devdecode.hip: RawStream::Walk): a block's header or trailer may straddle a chunk border, a chunk may be smaller
+    than a block, larger than the file, or end exactly at a block's end.  Host only: the walk over the fixture and a
+    synthetic file under chunk sizes from 1 byte up must give the table of the mapped walk; files it cannot take
+    (cut inside a block, odd extra fields) are declined, never mis-tabulated."""
+    import ctypes as C
+    from bamsignals_amd import _lib
+    from bamsignals_amd.bamio import write_columns_as_bam
+    lib = _lib.load()
+    lib.bsig_debug_stream_walk.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+
+    def mapped(path):
+        monkeypatch.setenv("BAMSIGNALS_SCAN", "mmap")
+        n, h = C.c_int64(), C.c_uint64()
+        _lib.check(lib.bsig_debug_block_table(path.encode(), C.byref(n), C.byref(h)))
+        return n.value, h.value
+
+    def streamed(path, chunk):
+        n, h = C.c_int64(), C.c_uint64()
+        _lib.check(lib.bsig_debug_stream_walk(path.encode(), chunk, C.byref(n), C.byref(h)))
+        return n.value, h.value
+
+    want = mapped(BAM)
+    size = os.path.getsize(BAM)
+    first = struct.unpack_from("<H", open(BAM, "rb").read(18), 16)[0] + 1          # the first block's size
+    for chunk in (1, 2, 3, 7, 17, 18, 19, 25, 26, 27, 64, 1000, 4096, first - 1, first, first + 1, 2 * first, 65536, 65537,
+                  100_000, size - 1, size, size + 1, 1 << 30):
+        assert streamed(BAM, chunk) == want, chunk
+    cols = _synth(600_000, seed=11)
+    p = str(tmp_path / "syn.bam")
+    write_columns_as_bam(p, ["a", "b", "c"], cols)
+    want = mapped(p)
+    assert want[0] > 300
+    rng = np.random.default_rng(5)
+    for chunk in [5, 333, 8192, 65536, 1 << 20, 32 << 20] + [int(x) for x in rng.integers(20, 200_000, 25)]:
+        assert streamed(p, chunk) == want, chunk
+    raw = open(p, "rb").read()
+    q = str(tmp_path / "cut.bam")
+    open(q, "wb").write(raw[: len(raw) // 2 + 1234])                                # the file ends inside a block
+    for chunk in (100, 65536, 1 << 30):
+        with pytest.raises(_lib.BsigError, match="declines"):
+            streamed(q, chunk)
+    bad = bytearray(raw)
+    bad[3] &= ~4 & 0xFF                                                             # no extra field: not a BGZF block
+    open(q, "wb").write(bytes(bad))
+    with pytest.raises(_lib.BsigError, match="declines"):
+        streamed(q, 4096)
