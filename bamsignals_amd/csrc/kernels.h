@@ -42,6 +42,8 @@ hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, co
                             const int32_t *end, const uint16_t *flag, const uint8_t *mapq, const uint16_t *codemap /* or NULL */,
                             uint32_t *chunk_counts,
                             int32_t *maxspan /* BSIG_MAX_CLASSES + 1: the last = "not sorted" flag */, hipStream_t st);
+// exclusive scan of the chunks' class counts (BSIG_MAX_CLASSES per chunk) and the class totals, on the device
+hipError_t launch_chunk_scan(int64_t n_chunks, const uint32_t *counts, uint64_t *chunk_base, uint64_t *totals, hipStream_t st);
 hipError_t launch_scatter(int64_t n, int32_t n_ref, const int64_t *ref_off, const uint32_t *ref_unit0,
                           const uint32_t *ref_units, const int32_t *pos, const int32_t *end,
                           const uint16_t *flag, const uint8_t *mapq, const int32_t *tlen, const uint16_t *codemap,

@@ -1446,6 +1446,51 @@ __global__ __launch_bounds__(kPrepThreads) void k_span_hist(int64_t n, int32_t n
     }
 }
 
+// The exclusive scan of the chunks' class counts (chunk_base[k][c] = reads of class c in the chunks before k) and the
+// class totals, on the device: the counts used to travel to the host (4.9 MB for 5e8 reads), be summed there and come
+// back as 9.8 MB of bases, 3 ms of every layout.  One workgroup: every thread sums a slab of consecutive chunks, the
+// slab sums are scanned in LDS, every thread writes its slab's bases.
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_chunk_scan(int64_t n_chunks, const uint32_t *__restrict__ counts,
+                                                             uint64_t *__restrict__ chunk_base, uint64_t *__restrict__ totals)
+{
+    __shared__ uint64_t slab[kScanThreads][BSIG_MAX_CLASSES];
+    const int tid = threadIdx.x;
+    const int64_t per = (n_chunks + kScanThreads - 1) / kScanThreads;
+    const int64_t k0 = (int64_t)tid * per, k1 = k0 + per < n_chunks ? k0 + per : n_chunks;
+    uint64_t sum[BSIG_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) sum[c] = 0;
+    for (int64_t k = k0; k < k1; ++k)
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) sum[c] += counts[k * BSIG_MAX_CLASSES + c];
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) slab[tid][c] = sum[c];
+    __syncthreads();
+    // inclusive scan over the slabs, in place (Hillis-Steele: ten steps)
+    for (int d = 1; d < kScanThreads; d <<= 1) {
+        uint64_t add[BSIG_MAX_CLASSES];
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) add[c] = tid >= d ? slab[tid - d][c] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) slab[tid][c] += add[c];
+        __syncthreads();
+    }
+    uint64_t run[BSIG_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < BSIG_MAX_CLASSES; ++c) run[c] = slab[tid][c] - sum[c];
+    for (int64_t k = k0; k < k1; ++k)
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
+            chunk_base[k * BSIG_MAX_CLASSES + c] = run[c];
+            run[c] += counts[k * BSIG_MAX_CLASSES + c];
+        }
+    if (tid == kScanThreads - 1)
+#pragma unroll
+        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) totals[c] = slab[tid][c];
+}
+
 struct ScatterOut {
     int32_t *pos[BSIG_MAX_CLASSES];
     int32_t *end[BSIG_MAX_CLASSES];
@@ -1817,6 +1862,12 @@ hipError_t launch_span_hist(int64_t n, int32_t n_ref, const int64_t *ref_off, co
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_span_hist, dim3((unsigned)prep_chunks(n)), dim3(kPrepThreads), 0, st,
                        n, n_ref, ref_off, ref_units, pos, end, flag, mapq, codemap, chunk_counts, maxspan);
+    return hipGetLastError();
+}
+
+hipError_t launch_chunk_scan(int64_t n_chunks, const uint32_t *counts, uint64_t *chunk_base, uint64_t *totals, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(kScanThreads), 0, st, n_chunks, counts, chunk_base, totals);
     return hipGetLastError();
 }
 

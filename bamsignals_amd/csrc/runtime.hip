@@ -516,20 +516,18 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
     HIP_TRY(tmp.alloc(&d_maxspan, BSIG_MAX_CLASSES + 1));
     HIP_TRY(hipMemsetAsync(d_maxspan, 0, (BSIG_MAX_CLASSES + 1) * sizeof(int32_t), st));
     HIP_TRY(bsig::launch_span_hist(n, n_ref, d_ref_off, d_units, d_pos, d_end, d_flag, d_mapq, d_codemap, d_counts, d_maxspan, st));
-    std::vector<uint32_t> counts(n_chunks * BSIG_MAX_CLASSES);
+    // (the scan of the chunk counts stays on the device: only the class totals and the longest spans come back)
+    uint64_t *d_base, *d_totals;
+    HIP_TRY(tmp.alloc(&d_base, (size_t)n_chunks * BSIG_MAX_CLASSES));
+    HIP_TRY(tmp.alloc(&d_totals, BSIG_MAX_CLASSES));
+    HIP_TRY(bsig::launch_chunk_scan(n_chunks, d_counts, d_base, d_totals, st));
     int32_t maxspan[BSIG_MAX_CLASSES + 1];
-    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    uint64_t class_n[BSIG_MAX_CLASSES] = {};
+    HIP_TRY(hipMemcpyAsync(class_n, d_totals, sizeof class_n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(maxspan, d_maxspan, sizeof maxspan, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (maxspan[BSIG_MAX_CLASSES])
         return fail(BSIG_ERR_ARG, "reads must be sorted by position inside every reference (coordinate-sorted BAM order)");
-    std::vector<uint64_t> base(n_chunks * BSIG_MAX_CLASSES);
-    uint64_t class_n[BSIG_MAX_CLASSES] = {};
-    for (int64_t k = 0; k < n_chunks; ++k)
-        for (int c = 0; c < BSIG_MAX_CLASSES; ++c) {
-            base[k * BSIG_MAX_CLASSES + c] = class_n[c];
-            class_n[c] += counts[k * BSIG_MAX_CLASSES + c];
-        }
     if (diag) fprintf(stderr, "  [layout] class counts %.1f ms\n", diag_ms());
 
     // bucket width per class: about 16 reads per bucket, 16 bp .. 64 kbp (the packed class: at most one
@@ -580,9 +578,6 @@ int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_
     R->info.n_codes = R->dev.n_codes;
 
     if (diag) fprintf(stderr, "  [layout] column + index allocations %.1f ms\n", diag_ms());
-    uint64_t *d_base;
-    HIP_TRY(tmp.alloc(&d_base, base.size()));
-    HIP_TRY(hipMemcpyAsync(d_base, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     HIP_TRY(bsig::launch_scatter(n, n_ref, d_ref_off, d_unit0, d_units, d_pos, d_end, d_flag, d_mapq, d_tlen, d_codemap,
                                  d_base, S, st));
     for (int c = 0; c < BSIG_MAX_CLASSES; ++c)
