@@ -545,9 +545,11 @@ struct Staging {
         d_crc_tables = p;
         return BSIG_OK;
     }
-    int ensure_streams()
+    // (copy: the stream the ordinary route's helper thread sends a pass's packed bytes on; a streamed decode has no
+    // use for it, and a stream costs 4 ms to make in a session's first call)
+    int ensure_streams(bool copy = true)
     {
-        if (!s_copy) HIP_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+        if (copy && !s_copy) HIP_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
         if (!s_inflate) HIP_TRY(hipStreamCreateWithFlags(&s_inflate, hipStreamNonBlocking));
         if (!s_crc) HIP_TRY(hipStreamCreateWithFlags(&s_crc, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {
@@ -1321,7 +1323,7 @@ int decode_share(bsig_ctx *ctx, const BgzfFile &f, const BamHeader &hdr, const s
         }
     } pf;
     if (gpu_inflate) {
-        rc = S.ensure_streams();
+        rc = S.ensure_streams(!raw);
         if (rc) return rc;
         pf.cs = S.s_copy;
     }
@@ -1781,7 +1783,7 @@ int reads_from_bam_streamed(bsig_ctx *ctx, const std::string &path, int threads,
         auto body = [&S, dev] {
             (void)hipSetDevice(dev);
             std::lock_guard<std::mutex> lk(S.mu);
-            if (S.ensure(0) != BSIG_OK || S.ensure_streams() != BSIG_OK) return;
+            if (S.ensure(0) != BSIG_OK || S.ensure_streams(false) != BSIG_OK) return;
             const bool crc = crc_check_enabled() && S.ensure_crc_tables(S.s_crc) == BSIG_OK;
             warm_inflate(S.s_inflate, crc ? S.s_crc : nullptr, S.d_crc_tables);
             // ... and the first copy between pageable memory and the device on that stream (the shares' job lists):
