@@ -165,13 +165,9 @@ struct ProfileOne {
             // cell, and LDS atomics on one address take their turns -- config 5's 1-kb tiles: 0.16 -> 0.30 ms)
             if (ok) atomicAdd(&cnt[cell >> 1], 1u << ((cell << 4) & 31u));     // (odd cell: the dword's high half)
         };
-        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
         rd(w.x, b0, t.x, 0u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.y, b1, t.y, 1u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.z, b2, t.z, 2u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.w, b3, t.w, 3u);
     }
 };
@@ -238,13 +234,9 @@ struct SmallOne {
             const uint32_t idx = SS ? 2u * lc + ((REV ? ~nm : nm) & 1u) : lc;
             if (ok) atomicAdd(&mine[idx], 1);
         };
-        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
         rd(w.x, b0, t.x, 0u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.y, b1, t.y, 1u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.z, b2, t.z, 2u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.w, b3, t.w, 3u);
     }
 };
@@ -331,13 +323,9 @@ struct CoverOne {
             if (ok) atomicAdd(&img[ca >> 1], 1u << (((uint32_t)ca << 4) & 31u));
             if (ok2) atomicAdd(&img[kb >> 1], 0xFFFFFFFFu << (((uint32_t)kb << 4) & 31u));
         };
-        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
         rd(w.x, b0, t.x, 0u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.y, b1, t.y, 1u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.z, b2, t.z, 2u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.w, b3, t.w, 3u);
     }
 };
@@ -379,13 +367,9 @@ struct CountOne {
             const bool ok = (dj + k < nj) & (rel < (uint32_t)gn);
             acc += ok ? ((nm & 0x10000u) | 1u) : 0u;
         };
-        // (one read after the other: interleaved, the four reads' temporaries cost ten registers and a wave per SIMD)
         rd(w.x, b0, 0u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.y, b1, 1u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.z, b2, 2u);
-        __builtin_amdgcn_sched_barrier(0);
         rd(w.w, b3, 3u);
     }
 };
