@@ -1069,8 +1069,8 @@ __global__ __launch_bounds__(NT) void k_count(const BsigWorkItem *__restrict__ i
     const int gn = w.nc;
     // Counting is all this launch does per read, and the launch is bound by its vector instructions (PMC, config 3's
     // tiling: 95e6 VALU instructions x 4 cycles over 1,024 SIMDs = the whole 155 us): no branch per read -- a read
-    // that is no read, rejected or outside adds 0 -- and two counters (all, reverse strand) that become sense and
-    // antisense once, behind the loop.
+    // that is no read, rejected or outside adds 0 -- and ONE packed counter (all reads in its low half, reverse-strand
+    // ones in its high half) that becomes sense and antisense once, behind the loop.
     uint32_t acc = 0;
     const CountOne one{P, glo, gn, acc};
     for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
