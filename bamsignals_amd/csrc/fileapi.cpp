@@ -975,41 +975,32 @@ std::vector<std::pair<std::string, bool>> index_candidates(const std::string &ba
     return c;
 }
 
-// parses the index of b (whichever candidate exists first); 0, or an error with its message in b->idx_err
+// parses the index of b: the FIRST candidate that exists is the index, as in htslib's search (a file of a .csi name
+// that is not a CSI index fails the open there -- bam_index_load returns NULL, ref: src/bamsignals.cpp:207-210 --
+// and is not passed over for an older .bai beside it); 0, or an error with its message in b->idx_err
 int load_index(bsig_bam *b)
 {
-    int rc = BSIG_ERR_NOINDEX;
     for (const auto &cand : index_candidates(b->path)) {
         struct stat sb;
         if (stat(cand.first.c_str(), &sb) != 0) continue;
         const int r = cand.second ? bsig::csi_load(cand.first, b->idx) : bsig::bai_load(cand.first, b->idx);
         if (r == 0) { b->from_csi = cand.second; return 0; }
-        // a .csi that is not a CSI index is no index at all (a stale or foreign file of that name must not hide
-        // the reference's "not available"); a damaged BAI is reported as such
+        // a damaged BAI is reported as such; a .csi that is no CSI index gets the reference's own text
         if (!cand.second && r != BSIG_ERR_NOINDEX) { b->idx_err = bsig_last_error(); return r; }
-        rc = cand.second ? rc : r;
+        break;
     }
     b->idx_err = "BAM indexing file is not available for file " + b->path;
     return BSIG_ERR_NOINDEX;
 }
 
-// does some index file with the right magic exist?  (cheap: the file-level calls parse the index in the
-// background and only need to know now whether the reference's "not available" error is due)
+// does some index file exist?  (cheap: the file-level calls parse the index in the background and only need to
+// know now whether the reference's "not available" error is due; what the first existing candidate holds is the
+// parse's business, see load_index)
 bool index_present(const std::string &bam)
 {
     for (const auto &cand : index_candidates(bam)) {
-        unsigned char magic[4] = {0, 0, 0, 0};
-        if (!cand.second) {
-            FILE *f = fopen(cand.first.c_str(), "rb");
-            if (!f) continue;
-            fclose(f);
-            return true;      // (a BAI of that name that is damaged: the parse reports it)
-        }
-        gzFile g = gzopen(cand.first.c_str(), "rb");
-        if (!g) continue;
-        const bool ok = gzread(g, magic, 4) == 4 && !memcmp(magic, "CSI\1", 4);
-        gzclose(g);
-        if (ok) return true;
+        struct stat sb;
+        if (stat(cand.first.c_str(), &sb) == 0) return true;
     }
     return false;
 }

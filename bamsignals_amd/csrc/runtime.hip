@@ -1174,7 +1174,9 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
     R->ref_units.assign((const uint32_t *)p_un, (const uint32_t *)p_un + H.n_ref);
     R->info = bsig_reads_info{};
     R->info.n_reads = H.n_reads;
-    if (H.n_codes > BSIG_PACK_CODES || (H.n_codes == 0) != (H.cls[BSIG_CLASS_PACKED].n == 0))
+    // no table, no packed reads; the converse does not hold: the pair sample may have seen short reads of which
+    // none qualified for the packed class (all beyond their reference's end), and such a layout is saved as it is
+    if (H.n_codes > BSIG_PACK_CODES || (H.n_codes == 0 && H.cls[BSIG_CLASS_PACKED].n != 0))
         return fail(BSIG_ERR_FORMAT, "%s is damaged (pair table)", path);
     if (H.n_codes) {
         const uint8_t *p_tab = take(BSIG_PACK_CODES * 4);

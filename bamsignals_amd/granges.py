@@ -1,6 +1,10 @@
 """A minimal GRanges: exactly the slots the reference's native code reads
 (``seqnames``, ``ranges@start``, ``ranges@width``, ``strand``; ref: parseRegions,
-src/bamsignals.cpp:92-135).  Coordinates are 1-based and closed, as in GenomicRanges."""
+src/bamsignals.cpp:92-135).  Coordinates are 1-based and closed, as in GenomicRanges.
+
+A GRanges is immutable: ``seqnames`` and ``strand`` are tuples behind read-only properties and ``start`` /
+``width`` are read-only arrays, because the factor encodings the C ABI takes are made once at construction
+(an edit afterwards would silently be computed on the old values).  Subset with ``gr[i]`` or build a new one."""
 from __future__ import annotations
 
 import numpy as np
@@ -8,21 +12,23 @@ import numpy as np
 
 class GRanges:
     def __init__(self, seqnames, start, width=None, end=None, strand="*"):
-        self.start = np.atleast_1d(np.asarray(start, dtype=np.int64)).astype(np.int32)
-        n = len(self.start)
+        self._start = np.atleast_1d(np.asarray(start, dtype=np.int64)).astype(np.int32)
+        n = len(self._start)
         if width is None:
             if end is None:
                 raise ValueError("give width or end")
-            width = np.atleast_1d(np.asarray(end, dtype=np.int64)) - self.start + 1
-        self.width = np.broadcast_to(np.asarray(width, dtype=np.int64), (n,)).astype(np.int32)
-        if np.any(self.width < 0):
+            width = np.atleast_1d(np.asarray(end, dtype=np.int64)) - self._start + 1
+        self._width = np.broadcast_to(np.asarray(width, dtype=np.int64), (n,)).astype(np.int32)
+        self._start.setflags(write=False)
+        self._width.setflags(write=False)
+        if np.any(self._width < 0):
             raise ValueError("negative widths are not allowed")
         if isinstance(seqnames, str):
             seqnames = [seqnames] * n
-        self.seqnames = [str(s) for s in seqnames]
+        self._seqnames = tuple(str(s) for s in seqnames)
         if isinstance(strand, str):
             strand = [strand] * n
-        self.strand = [str(s) for s in strand]
+        self._strand = tuple(str(s) for s in strand)
         if len(self.seqnames) != n or len(self.strand) != n:
             raise ValueError("seqnames, start, width and strand differ in length")
         bad = set(self.strand) - {"+", "-", "*"}
@@ -33,8 +39,15 @@ class GRanges:
         self._levels = list(dict.fromkeys(self.seqnames))
         lut = {s: k for k, s in enumerate(self._levels)}
         self._codes = np.fromiter((lut[s] for s in self.seqnames), dtype=np.int32, count=n)
+        self._codes.setflags(write=False)
         smap = {"+": 1, "-": -1, "*": 0}
         self._strand_int = np.fromiter((smap[s] for s in self.strand), dtype=np.int32, count=n)
+        self._strand_int.setflags(write=False)
+
+    seqnames = property(lambda self: self._seqnames)
+    strand = property(lambda self: self._strand)
+    start = property(lambda self: self._start)
+    width = property(lambda self: self._width)
 
     def __len__(self):
         return len(self.start)

@@ -177,12 +177,14 @@ def driver_reclaim_probe(gb=96):
         "h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; h.hipFree.argtypes = [C.c_void_p]\n"
         "ps, ts = [], []\n"
         "p = C.c_void_p(); h.hipMalloc(C.byref(p), 256); h.hipFree(p)\n"
-        f"for _ in range({int(gb) // 8}):\n"
+        "fr, to = C.c_size_t(), C.c_size_t(); h.hipMemGetInfo(C.byref(fr), C.byref(to))\n"
+        # never more than what is free now less 16 GB: other users of this GPU (the parent's resident workload) keep theirs
+        f"for _ in range(min({int(gb) // 8}, max(0, (fr.value - (16 << 30)) >> 33))):\n"
         "    p = C.c_void_p(); t = time.perf_counter(); rc = h.hipMalloc(C.byref(p), 8 << 30); ts.append(time.perf_counter() - t)\n"
         "    if rc != 0: break\n"
         "    ps.append(p)\n"
         "for p in ps: h.hipFree(p)\n"
-        "print(json.dumps(dict(calls=len(ts), bytes_per_call=8 << 30, slowest_s=max(ts), total_s=sum(ts))))\n")
+        "print(json.dumps(dict(calls=len(ts), bytes_per_call=8 << 30, slowest_s=max(ts + [0.0]), total_s=sum(ts), free_bytes_before=fr.value)))\n")
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
         out = json.loads(r.stdout.strip().splitlines()[-1])
@@ -239,8 +241,14 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
         arena_gb = 0
         # whatever ran on this GPU before the bench (the GPU tests, a profiler) left freed memory for the driver to reclaim:
         # shown, and settled, by plain hipMalloc calls in a process of their own
+        # ... and one session IN FRONT of that probe: what a session's first call costs behind whatever tenant came
+        # before (it is listed by itself, `cold_call_before_the_probe_s`, and is not among the three below)
+        first, flat0 = cold_call_in_fresh_process(d, "ns_unsettled", bam, names, rg, call, device, arena_gb=arena_gb)
+        if not np.array_equal(flat0, want_flat):
+            raise SystemExit("file-level result differs from the resident-column result")
+        del flat0
         reclaim = driver_reclaim_probe()
-        log(f"end_to_end: driver reclaim probe {reclaim}")
+        log(f"end_to_end: first session {first['calls'][0]['call_s']:.3f} s; driver reclaim probe {reclaim}")
         # three sessions, the median one reported: a session's first call now and then catches an allocation stall
         # of the driver (r03: one run in three to five, 0.5 s instead of 0.28 s; profiles/NOTES_r01_r03.md) -- all three are listed
         child, flat = cold_call_in_fresh_process(d, "ns", bam, names, rg, call, device, arena_gb=arena_gb)
@@ -287,6 +295,8 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
                    cold_call_sessions_stages_s=[{k: c["calls"][0]["stages_s"].get(k) for k in stage_keys + ("alloc_calls", "reserved_bytes", "reservation_wait")}
                                                 for c in sessions],
                    stages_well_above_the_fastest_session=outliers, driver_reclaim_probe=reclaim,
+                   cold_call_before_the_probe_s=first["calls"][0]["call_s"],
+                   cold_call_before_the_probe_stages_s={k: first["calls"][0]["stages_s"].get(k) for k in stage_keys + ("alloc_calls",)},
                    cold_call_stages_s=stages, warm_call_s=t_warm,
                    # the compressed file's trip into HBM: what the call waited for it, and the file size over the
                    # whole decode (block scan + copies + inflate + parse), i.e. the ingest rate the cold call sees
@@ -294,7 +304,9 @@ def end_to_end(cfg, cols, rg, want_flat, device, oracle_c):
                    host_cpus_used=child["host_cpus_used"], hip_context_s=child["hip_context_s"], route=child["calls"][0]["route"],
                    measured_in="fresh child processes with their HIP context up (a new session's first BAM; see cold_call_in_fresh_process), "
                                "run while the parent still holds its resident workload (nothing has been freed on the GPU since the "
-                               "timed steps): three sessions, the median one's call and stages reported, all three listed with their stages",
+                               "timed steps): three sessions behind the driver_reclaim_probe, the median one's call and stages reported, all "
+                               "three listed with their stages; cold_call_before_the_probe_s is one more session run IN FRONT of the probe "
+                               "(what a first call costs behind whatever this GPU's previous tenant left for the driver to reclaim)",
                    arena_gb=arena_gb,
                    cold_Mbases_s=bases / t_cold / 1e6, warm_Mbases_s=bases / t_warm / 1e6,
                    vs_cpu_path_cold=(t_dec1 + t_orc) / t_cold, vs_cpu_path_warm=(t_dec1 + t_orc) / t_warm,

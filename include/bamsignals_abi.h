@@ -210,7 +210,7 @@ int bsig_pileup_columns(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges
 typedef struct bsig_bam bsig_bam;
 /* opens <path> and loads <path>.csi, <stem>.csi, <path>.bai or <stem>.bai (the first that exists, in the order
  * of htslib's bam_index_load, ref: src/bamsignals.cpp:207; a CSI index may have any min_shift / depth --
- * references beyond 2^29 bp need one; a file of a .csi name that is not a CSI index counts as absent); errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the reference's messages
+ * references beyond 2^29 bp need one; the first file that exists IS the index: one of a .csi name that is not a CSI index fails the open as it does in htslib, an older .bai beside it is not consulted); errors BSIG_ERR_IO / BSIG_ERR_NOINDEX with the reference's messages
  * (ref: src/bamsignals.cpp:204,209).                                                             */
 int bsig_bam_open(const char *path, bsig_bam **bam);
 void bsig_bam_close(bsig_bam *bam);

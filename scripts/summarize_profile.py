@@ -40,7 +40,10 @@ def pmc(case, kind, counter, kernel):
 lines = [f"# {tag}: rocprofv3 summaries (MI355X, one GPU)\n",
          "Per case: the un-profiled run (HIP events around the K-launch train / K), `rocprofv3 --kernel-trace --stats` of the same "
          "command, and two PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs; FETCH_SIZE doubled as "
-         "MI355X_MICROARCH.md prescribes for gfx950: 128-B requests are tallied at 64 B; both in units of 1,024 B).\n"]
+         "MI355X_MICROARCH.md prescribes for gfx950: 128-B requests are tallied at 64 B; both in units of 1,024 B).  "
+         "**The read side is an UPPER bound**: the guide establishes the factor of two for wide coalesced reads (16 B per lane) only, and "
+         "these launches also issue scalar loads and narrow index loads whose requests may be tallied at their true size; ALL of "
+         "FETCH_SIZE is doubled here, so traffic / B can only be overstated (reads are about a quarter of a launch's traffic).\n"]
 for case, (kernel, cmd) in CASES.items():
     stats = newest(f"{tag}_{case}_trace/*/*_kernel_stats.csv")
     plain = os.path.join(G, f"{tag}_{case}_plain.json")

@@ -20,7 +20,7 @@ def pytest_configure(config):
     orc = os.path.join(ROOT, "oracle", "liboracle.so")
     if not (os.path.exists(so) and os.path.exists(orc)):
         import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bamsignals_amd", "csrc")])
+        subprocess.check_call(["make", "-j4", "-C", os.path.join(ROOT, "bamsignals_amd", "csrc")])
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
 
 

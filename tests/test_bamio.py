@@ -538,6 +538,13 @@ def test_a_csi_index_is_preferred_to_a_bai(tmp_path, fixture_reads):
     (tmp_path / "both.bam.bai").write_bytes(b"BAI\x01" + b"\xff" * 40)
     with pytest.raises(_lib.BsigError):
         BamFile(str(p))
+    # the first index file that exists IS the index (htslib: a .csi that does not load fails bam_index_load, the
+    # reference then reports "not available", ref: src/bamsignals.cpp:207-210): a good .bai behind it is not consulted
+    shutil.copy(BAM + ".bai", tmp_path / "both.bam.bai")
+    (tmp_path / "both.csi").write_bytes(b"CSI\x01 truncated")
+    with pytest.raises(_lib.BsigError, match="BAM indexing file is not available"):
+        BamFile(str(p))
+    (tmp_path / "both.bam.bai").write_bytes(b"BAI\x01" + b"\xff" * 40)
     (tmp_path / "both.csi").write_bytes(_bai_to_csi(open(BAM + ".bai", "rb").read(), 5))      # <stem>.csi
     b = BamFile(str(p))
     got = b.decode(rid=np.asarray([1], np.int32), beg=np.asarray([100], np.int64), end=np.asarray([4000], np.int64))

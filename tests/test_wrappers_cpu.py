@@ -48,7 +48,16 @@ def test_granges():
     assert list(gr.width) == [6, 4, 1] and list(gr.end) == [10, 4, 9] and len(gr) == 3
     levels, codes, start, width, strand = gr.flatten()
     assert levels == ["chr2", "chr1"] and list(codes) == [0, 1, 0] and list(strand) == [1, -1, 0]
-    assert len(gr[1:]) == 2 and gr[1:].seqnames == ["chr1", "chr2"]
+    assert len(gr[1:]) == 2 and gr[1:].seqnames == ("chr1", "chr2")
+    # immutable: the factor encodings are made once, so an edit must fail instead of being ignored
+    with pytest.raises(AttributeError):
+        gr.strand = ["+", "+", "+"]
+    with pytest.raises(AttributeError):
+        gr.seqnames = ["chr1"] * 3
+    with pytest.raises(ValueError):
+        gr.start[0] = 7
+    with pytest.raises(ValueError):
+        gr.width[0] = 7
     with pytest.raises(ValueError):
         GRanges("chr1", [1], width=[-2])
     with pytest.raises(ValueError):
