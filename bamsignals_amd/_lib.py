@@ -53,7 +53,7 @@ class PlanStats(C.Structure):
                 ("visits", C.c_int64), ("visits_short", C.c_int64), ("streamed", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("bytes_per_visit_short", C.c_int32),
                 ("bytes_per_visit_long", C.c_int32), ("visits_packed", C.c_int64),
-                ("bytes_per_visit_packed", C.c_int32), ("reserved", C.c_int32)]
+                ("bytes_per_visit_packed", C.c_int32), ("heavy_tiles", C.c_int32)]
 
 
 _lib = None

@@ -1618,6 +1618,7 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         t.visits_short = (int64_t)(acc[0] + acc[1]);         // classes 0 and 1: no end column
         t.visits = (int64_t)(acc[0] + acc[1] + acc[2] + acc[3] + acc[BSIG_CLASS_PACKED]);
         t.streamed = (int64_t)acc[BSIG_MAX_CLASSES];
+        t.heavy_tiles = (int32_t)std::min<int64_t>(p->n_heavy_tiles, INT32_MAX);
         t.bytes_per_visit_packed = p->kp.use_tlen ? 8 : 4;     // the packed word [+ tlen]
         t.bytes_per_visit_short = p->kp.use_tlen ? 12 : 8;     // span <= 4096: pos + flag/mapq/span in one word [+ tlen]
         t.bytes_per_visit_long = p->kp.use_tlen ? 16 : 12;     // pos + end + flag/mapq [+ tlen]

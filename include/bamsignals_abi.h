@@ -177,7 +177,9 @@ typedef struct {
     int32_t bytes_per_visit_long;    /* 12 (pos + end + flag|mapq), 16 with the tlen column     */
     int64_t visits_packed;     /* ... of V in the packed class (not part of visits_short)       */
     int32_t bytes_per_visit_packed;  /* 4  (one word), 8 with the tlen column                   */
-    int32_t reserved;
+    int32_t heavy_tiles;       /* tiles whose read windows hold more reads than a tile image's 16-bit counters may
+                                * see (32,768; 32,767 for coverage; BAMSIGNALS_HEAVY_READS lowers it): their reads are
+                                * cut into slices that a second launch adds with integer atomics; 0: one launch     */
 } bsig_plan_stats;
 
 int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n_ranges,

@@ -1,7 +1,10 @@
 """GPU: bench.py launched as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), at a
-small size and over gloo with two ranks sharing the box's one GPU: the line must carry the strong-scaling block
-(config 5's shape at fixed total size: kernel + gather + reassembly timed, checked against the 1-GPU result
-and the oracle) and the in-process block (one process, two GPU slots, every gather route)."""
+small size and over gloo with two ranks sharing the box's one GPU.  The headline must be the workload at FIXED
+total size with the whole north-star step in the timed region -- kernels on the rank's shard, the gather of the
+shards to rank 0, the reassembly in rank 0's HBM (ref: src/bamsignals.cpp:164,181,186 is why the shard is legal;
+the reassembled result is the product) -- checked against the oracle on the ASSEMBLED result; beside it the
+informational blocks: the replicas without a collective, config 5's shape at fixed total size, and the in-process
+route (one process, two GPU slots, every gather route)."""
 import json
 import os
 import socket
@@ -34,7 +37,22 @@ def test_two_ranks_emit_strong_and_in_process_blocks():
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    # the headline: fixed total size, and `value` = the whole job's bases x steps / the region that holds the gather
+    cfg = res["config"]
+    assert cfg["workload"].startswith("C5:") and cfg["ranges_total"] == 3000 and cfg["ranges_per_gpu"] == 1500
+    assert "gather to rank 0" in cfg["parallelism"] and "inside the timed region" in cfg["parallelism"]
+    bases = cfg["ranges_total"] * cfg["range_width"]
+    assert abs(res["value"] - bases * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"]) / 1e6) <= 1e-6 * res["value"]
+    par = res["parity_checked"]
+    assert par["ranges_per_batch"] == 3000 and "assembled on rank 0" in par["how"] and par["cells"] == par["batches"] * bases
+    ph = res["step_phases"]
+    assert ph["gather_bytes_into_rank0"] == 1500 * cfg["range_width"] * 4 and len(ph["kernel_ms_by_rank"]) == 2
+    # a step cannot be shorter than rank 0's kernel + what it waits for the shards + their placement
+    assert res["ms_per_step"] > 0.5 * sum(ph["rank0_ms"].values())
+    # the replicas (no collective) are informational and are NOT the headline
+    rep = res["no_collective"]
+    assert rep["value"] > 0 and "replicas" in rep["what"] and rep["value"] != res["value"]
     st = res["strong"]
     assert st["n_gpus"] == 2 and st["ranges_total"] == 6000 and st["ranges_per_gpu"] == 3000
     assert "identical to the 1-GPU result" in st["checked"] and "identical to the oracle" in st["checked"]
