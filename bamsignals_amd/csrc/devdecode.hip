@@ -296,14 +296,20 @@ struct alignas(4) LaneSlot {
 };
 static_assert(sizeof(LaneSlot) % 8 == 4, "LaneSlot must be an odd number of dwords");
 
-// LANES blocks per wave: a file of 40,000 blocks is only 625 full waves for 1,024 SIMDs, and what
-// a lane does is a chain of dependent steps (bits -> table -> bits ...): fewer blocks per wave put
-// more waves on the chip, which hides that latency and wastes less on lanes that wait for the
-// longest code or match of their wave.
-// (three waves per SIMD: 168 VGPRs instead of the 172 the compiler would take, which would stop at two)
+// LANES blocks per workgroup, worked on by TWO waves (inflate_lane.h: produce / consume): lane l of wave 0 decodes
+// block l's symbols into tokens, lane l of wave 1 turns them into bytes; the mailboxes lie behind the tables in LDS.
+// (LANES < 64 leaves the upper lanes of both waves idle: a file of 40,000 blocks is only 625 full waves for 1,024
+// SIMDs, and what a lane does is a chain of dependent steps -- fewer blocks per wave put more waves on the chip and
+// waste less on lanes that wait for the longest code or match of their wave.)
+// Seven 32-block workgroups per CU by LDS = 14 waves = up to four per SIMD: at most 128 VGPRs.
 #ifndef BSIG_INFLATE_WAVES
-#define BSIG_INFLATE_WAVES 3
+#define BSIG_INFLATE_WAVES 4
 #endif
+#ifndef BSIG_PRODUCER_PRIO
+#define BSIG_PRODUCER_PRIO 2
+#endif
+constexpr int kInflateThreads = 128;
+constexpr size_t kMailboxBytes = 12;      // per block: Token::a + Token::b
 #ifdef BSIG_INFLATE_PROF
 // diagnostic build: per-lane counters of the first launches' lanes (scripts/inflate_prof.py)
 constexpr int kProfLanes = 1 << 17;
@@ -311,24 +317,36 @@ struct ProfRow { bsig_inflate::LaneProf p; uint64_t cycles; uint32_t isize, in_l
 __device__ ProfRow g_prof_rows[kProfLanes];
 #endif
 template <int LANES>
-__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(BSIG_INFLATE_WAVES, 8))) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
+__global__ __launch_bounds__(kInflateThreads) __attribute__((amdgpu_waves_per_eu(BSIG_INFLATE_WAVES, 8))) void k_inflate(const uint8_t *__restrict__ comp, const InflateJob *__restrict__ jobs,
                                                    int64_t n, uint8_t *__restrict__ out, uint8_t *__restrict__ lens,
-                                                   int *__restrict__ status)
+                                                   int *__restrict__ status, uint32_t lds_pad)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     LaneSlot *slots = reinterpret_cast<LaneSlot *>(lds_raw);
-    const int64_t i = (int64_t)blockIdx.x * LANES + threadIdx.x;
-    if (i >= n) return;
+    // (behind the tables and whatever the occupancy knob pads them with: 8-byte words, then 4-byte words)
+    uint8_t *mail = lds_raw + (((size_t)LANES * (sizeof(LaneSlot) + lds_pad) + 7) & ~(size_t)7);
+    uint64_t *tok_a = reinterpret_cast<uint64_t *>(mail);
+    uint32_t *tok_b = reinterpret_cast<uint32_t *>(mail + (size_t)LANES * 8);
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    if (threadIdx.x < LANES) tok_b[threadIdx.x] = 0;          // every mailbox starts empty
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * LANES + lane;
+    if (lane >= LANES || i >= n) return;
     const InflateJob j = jobs[i];
+    bsig_inflate::ChanLds ch(tok_a + lane, tok_b + lane);
+    if (role == 1) {
+        bsig_inflate::consume(out + j.out_off, j.isize, ch);
+        return;
+    }
+    // the decode chain is the longer one: its wave goes first wherever the two meet on a SIMD
+    __builtin_amdgcn_s_setprio(BSIG_PRODUCER_PRIO);
 #ifdef BSIG_INFLATE_PROF
     bsig_inflate::LaneProf pf{};
     const uint64_t t0 = clock64();
-    const int rc = bsig_inflate::inflate_block(comp + j.in_off, j.in_len, out + j.out_off, j.isize, slots[threadIdx.x].t,
-                                               lens + i * bsig_inflate::kLensBytes, &pf);
+    const int rc = bsig_inflate::produce(comp + j.in_off, j.in_len, j.isize, slots[lane].t, lens + i * bsig_inflate::kLensBytes, ch, &pf);
     if (i < kProfLanes) g_prof_rows[i] = ProfRow{pf, (uint64_t)clock64() - t0, j.isize, j.in_len};
 #else
-    const int rc = bsig_inflate::inflate_block(comp + j.in_off, j.in_len, out + j.out_off, j.isize, slots[threadIdx.x].t,
-                                               lens + i * bsig_inflate::kLensBytes);
+    const int rc = bsig_inflate::produce(comp + j.in_off, j.in_len, j.isize, slots[lane].t, lens + i * bsig_inflate::kLensBytes, ch);
 #endif
     if (rc) atomicMax(status, rc);
 }
@@ -400,6 +418,12 @@ int inflate_lanes_per_wave()
     if (const char *e = getenv("BAMSIGNALS_INFLATE_LANES")) lanes = atoi(e);
     return lanes == 64 || lanes == 32 || lanes == 16 || lanes == 4 ? lanes : 8;
 }
+size_t inflate_lds_pad();
+// LDS of one workgroup of k_inflate: the blocks' tables (+ the occupancy knob's padding), then their mailboxes
+size_t inflate_lds_bytes(int lanes, size_t pad)
+{
+    return (((size_t)lanes * (sizeof(LaneSlot) + pad) + 7) & ~(size_t)7) + (size_t)lanes * kMailboxBytes;
+}
 size_t inflate_lds_pad()
 {
     // (extra LDS bytes per lane that nobody uses, to run the kernel at a lower occupancy -- 340 gives the 160
@@ -425,16 +449,16 @@ size_t inflate_round_blocks(int device)
     auto it = known.find(key);
     if (it != known.end()) return it->second;
     int cus = 0, wgs = 0;
-    const size_t lds = (size_t)lanes * (sizeof(LaneSlot) + pad);
+    const size_t lds = inflate_lds_bytes(lanes, pad);
     hipError_t e = hipSetDevice(device);                    // (the occupancy query speaks of the current device)
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) {
         switch (lanes) {
-        case 64: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<64>, 64, lds); break;
-        case 32: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<32>, 32, lds); break;
-        case 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<16>, 16, lds); break;
-        case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<4>, 4, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<8>, 8, lds); break;
+        case 64: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<64>, kInflateThreads, lds); break;
+        case 32: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<32>, kInflateThreads, lds); break;
+        case 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<16>, kInflateThreads, lds); break;
+        case 4:  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<4>, kInflateThreads, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, k_inflate<8>, kInflateThreads, lds); break;
         }
     }
     const size_t c = e == hipSuccess && cus > 0 && wgs > 0 ? (size_t)cus * (size_t)wgs * (size_t)lanes : 0;
@@ -472,11 +496,11 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
     const int lanes = inflate_lanes_per_wave();
     const size_t lds_pad = inflate_lds_pad();
     switch (lanes) {
-    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
-    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3((unsigned)((n + 31) / 32)), dim3(32), 32 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
-    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3((unsigned)((n + 15) / 16)), dim3(16), 16 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
-    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(4), 4 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
-    default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(8), 8 * (sizeof(LaneSlot) + lds_pad), st, comp, jobs, n, out, lens, status); break;
+    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3((unsigned)((n + 63) / 64)), dim3(kInflateThreads), inflate_lds_bytes(64, lds_pad), st, comp, jobs, n, out, lens, status, (uint32_t)lds_pad); break;
+    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3((unsigned)((n + 31) / 32)), dim3(kInflateThreads), inflate_lds_bytes(32, lds_pad), st, comp, jobs, n, out, lens, status, (uint32_t)lds_pad); break;
+    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3((unsigned)((n + 15) / 16)), dim3(kInflateThreads), inflate_lds_bytes(16, lds_pad), st, comp, jobs, n, out, lens, status, (uint32_t)lds_pad); break;
+    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3((unsigned)((n + 3) / 4)), dim3(kInflateThreads), inflate_lds_bytes(4, lds_pad), st, comp, jobs, n, out, lens, status, (uint32_t)lds_pad); break;
+    default: hipLaunchKernelGGL(k_inflate<8>, dim3((unsigned)((n + 7) / 8)), dim3(kInflateThreads), inflate_lds_bytes(8, lds_pad), st, comp, jobs, n, out, lens, status, (uint32_t)lds_pad); break;
     }
     if (crc_tables && crc_st) {
         hipError_t e = hipEventRecord(inflated, st);
@@ -493,6 +517,83 @@ hipError_t launch_inflate(const uint8_t *comp, const InflateJob *jobs, int64_t n
     return hipGetLastError();
 }
 
+}  // namespace
+// (diagnostic: k_inflate ALONE on blocks [first, first + n) of a BGZF file -- the compressed bytes resident, `reps`
+// launches between HIP events, then the CRC32 of every block against its trailer; scripts/inflate_bench.py.  ms[0] =
+// fastest launch, ms[1] = mean; bytes[0] = compressed, bytes[1] = inflated.)
+extern "C" int bsig_debug_inflate_bench(int device, const char *path, int64_t first, int64_t n, int reps, double *ms, int64_t *bytes,
+                                        int *status_out)
+{
+    using namespace bsig;
+    BgzfFile f;
+    if (f.open(path) != 0) return 1;
+    const std::vector<BgzfBlock> &B = f.blocks();
+    if (first < 0 || first >= (int64_t)B.size()) return 2;
+    n = std::min<int64_t>(n, (int64_t)B.size() - first);
+    while (n > 0 && B[first + n - 1].isize == 0) --n;                       // (the EOF block)
+    if (n <= 0 || reps <= 0) return 2;
+    const uint64_t c0 = B[first].coff, c1 = B[first + n - 1].coff + B[first + n - 1].csize;
+    std::vector<uint8_t> host((size_t)(c1 - c0) + 64, 0);
+    if (!f.read_span(c0, (size_t)(c1 - c0), host.data())) return 3;
+    std::vector<InflateJob> jobs((size_t)n);
+    uint64_t at = 0;
+    // (BSIG_BENCH_OUT_STRIDE: every block's output at a multiple of that many bytes instead of back to back -- does the
+    // spacing of the lanes' output areas matter to the caches?)
+    const uint64_t stride = getenv("BSIG_BENCH_OUT_STRIDE") ? (uint64_t)atoll(getenv("BSIG_BENCH_OUT_STRIDE")) : 0;
+    uint64_t total_isize = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const BgzfBlock &b = B[first + k];
+        jobs[k] = InflateJob{b.coff - c0 + b.doff, at, b.dlen, b.isize, b.crc, 0};
+        at += stride ? std::max<uint64_t>(stride, (b.isize + 15u) & ~15u) : b.isize;
+        total_isize += b.isize;
+    }
+    if (hipSetDevice(device) != hipSuccess) return 4;
+    uint8_t *d_comp = nullptr, *d_out = nullptr, *d_lens = nullptr;
+    InflateJob *d_jobs = nullptr;
+    int *d_status = nullptr;
+    uint32_t *d_tab = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipStreamCreate(&st);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_comp, host.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)at + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_lens, (size_t)n * bsig_inflate::kLensBytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_jobs, (size_t)n * sizeof(InflateJob));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_status, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tab, 8 * 256 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_comp, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(InflateJob), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_tab, crc32_slice8_tables(), 8 * 256 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_status, 0, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 1e30, sum = 0;
+    for (int r = -1; r < reps && e == hipSuccess; ++r) {                    // (one launch first, untimed)
+        e = hipMemsetAsync(d_out, 0, (size_t)at + 64, st);
+        if (e == hipSuccess) e = hipEventRecord(e0, st);
+        if (e == hipSuccess) e = launch_inflate(d_comp, d_jobs, n, d_out, d_lens, d_status, nullptr, st);
+        if (e == hipSuccess) e = hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        float t = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (r >= 0) { best = std::min(best, (double)t); sum += t; }
+    }
+    int status[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = launch_inflate(d_comp, d_jobs, n, d_out, d_lens, d_status, d_tab, st);     // ... and the CRCs
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(status, d_status, sizeof status, hipMemcpyDeviceToHost);
+    (void)hipFree(d_comp); (void)hipFree(d_out); (void)hipFree(d_lens); (void)hipFree(d_jobs); (void)hipFree(d_status); (void)hipFree(d_tab);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return 5;
+    if (ms) { ms[0] = best; ms[1] = sum / reps; }
+    if (bytes) { bytes[0] = (int64_t)(c1 - c0); bytes[1] = (int64_t)total_isize; bytes[2] = n; }
+    if (status_out) *status_out = status[0];
+    return 0;
+}
+namespace {
+
 // a launch of nothing (n = 0: every lane leaves at once) on the streams a decode is about to use: a session's first
 // launch of k_inflate costs 9 ms beyond the kernel (the queue's first use, the kernel's first dispatch) -- time a
 // streamed decode has anyway while the head of the file travels
@@ -502,11 +603,11 @@ void warm_inflate(hipStream_t st, hipStream_t crc_st, const uint32_t *crc_tables
     const size_t lds_pad = inflate_lds_pad();
     const int64_t n = 0;
     switch (lanes) {
-    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3(1), dim3(64), 64 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
-    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3(1), dim3(32), 32 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
-    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3(1), dim3(16), 16 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
-    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3(1), dim3(4), 4 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
-    default: hipLaunchKernelGGL(k_inflate<8>, dim3(1), dim3(8), 8 * (sizeof(LaneSlot) + lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr); break;
+    case 64: hipLaunchKernelGGL(k_inflate<64>, dim3(1), dim3(kInflateThreads), inflate_lds_bytes(64, lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr, (uint32_t)lds_pad); break;
+    case 32: hipLaunchKernelGGL(k_inflate<32>, dim3(1), dim3(kInflateThreads), inflate_lds_bytes(32, lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr, (uint32_t)lds_pad); break;
+    case 16: hipLaunchKernelGGL(k_inflate<16>, dim3(1), dim3(kInflateThreads), inflate_lds_bytes(16, lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr, (uint32_t)lds_pad); break;
+    case 4:  hipLaunchKernelGGL(k_inflate<4>, dim3(1), dim3(kInflateThreads), inflate_lds_bytes(4, lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr, (uint32_t)lds_pad); break;
+    default: hipLaunchKernelGGL(k_inflate<8>, dim3(1), dim3(kInflateThreads), inflate_lds_bytes(8, lds_pad), st, nullptr, nullptr, n, nullptr, nullptr, nullptr, (uint32_t)lds_pad); break;
     }
     // (k_crc32 stages its tables before its lanes look at n: they must be there)
     if (crc_st && crc_tables) hipLaunchKernelGGL(k_crc32, dim3(1), dim3(64), 0, crc_st, nullptr, nullptr, n, crc_tables, nullptr);

@@ -9,12 +9,13 @@
 //     cover, as a chain of compares WITHOUT branches, then one lookup.  704 bytes of LDS per lane on
 //     the device (6 bits of distance table cost no resident lane and save 2 % on literal-heavy blocks),
 //     where zlib-style two-level tables need 5.7 KB;
-//   * memory is waited for ONCE per turn of the main loop (see BSIG_VM_DRAIN in inflate_block): the
-//     compiler's waits are all-or-nothing (s_waitcnt vmcnt(0)), so every load whose value is needed
-//     at once stalls the wave for a whole trip and drains what else is in flight;
-//   * per turn of the main loop one symbol (up to six if they are literals the first-level table
-//     knows) OR a slice of a pending match: a lane that copies a 258-byte match does not hold the
-//     other lanes of its wave for 258 turns;
+//   * a block's work is split over TWO lanes in two waves (round 5, see produce / consume below): one decodes
+//     symbols into tokens, the other turns tokens into bytes; a 12-byte mailbox in LDS lies between them;
+//   * the consumer waits for memory ONCE per turn (see BSIG_VM_DRAIN in consume): the compiler's waits are
+//     all-or-nothing (s_waitcnt vmcnt(0)), so every load whose value is needed at once stalls the wave for a whole
+//     trip and drains what else is in flight;
+//   * per turn one token (up to six literals the first-level table knows and/or the match behind them) OR a slice
+//     of a pending match: a lane that copies a 258-byte match does not hold the other lanes of its wave for 258 turns;
 //   * the LZ77 window is the output itself (global memory): matches read back what the lane wrote.
 //
 // The same source compiles for the host (tests/test_inflate_lane.py runs it against zlib) and for
@@ -23,6 +24,9 @@
 #define BSIG_INFLATE_LANE_H
 #include <stdint.h>
 #include <string.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <vector>
+#endif
 
 #if defined(__HIPCC__)
 #define BSIG_HD __host__ __device__ __forceinline__
@@ -44,6 +48,16 @@ constexpr int kLFast = BSIG_LFAST, kDFast = BSIG_DFAST;   // first-level table b
 #endif
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
+// (diagnostic builds only, scripts/inflate_bench.py: what a turn costs WITHOUT part of its memory traffic -- the
+// control flow of the decode does not depend on the output, so the kernel runs the same turns and writes garbage:
+// 1 = no match loads, 2 = neither match loads nor match stores, 3 = no output traffic at all, 4 = everything but the
+// literals' store, 5 = the literals' store alone, 6 / 7 = see consume)
+#ifndef BSIG_ABLATE
+#define BSIG_ABLATE 0
+#endif
+#define BSIG_ABL_NO_MLOAD (BSIG_ABLATE == 1 || BSIG_ABLATE == 2 || BSIG_ABLATE == 3 || BSIG_ABLATE == 5)
+#define BSIG_ABL_NO_MSTORE (BSIG_ABLATE == 2 || BSIG_ABLATE == 3 || BSIG_ABLATE == 5)
+#define BSIG_ABL_NO_LSTORE (BSIG_ABLATE == 3 || BSIG_ABLATE == 4)
 
 // per-lane working storage that nearly every symbol touches (LDS on the device): 704 bytes = 224 lanes per CU
 // (160 with the cold tables in LDS as well).  More would not help a big file: a lane's turn takes 6,000-7,000
@@ -185,7 +199,7 @@ BSIG_HD uint64_t peek64(const uint8_t *p, const uint8_t *end)
 // requests the 8 bytes at in.p for the NEXT refill.
 // On the device this is ONE unconditional load whose result nobody touches before that refill: the address is
 // clamped to `end` (the 8 bytes there are readable -- a BGZF block's trailer follows its deflate data, see
-// inflate_block) and the bytes behind the input are masked off when they are taken.  With peek64's two paths
+// produce) and the bytes behind the input are masked off when they are taken.  With peek64's two paths
 // (a whole word, or the last bytes one by one) the value went through a register copy where the paths join,
 // and the compiler waits for a load before it copies it: every refill waited for the load it had just issued
 // (r03: 9,500 cycles per turn of a wave, profiles/r03_inflate_prof.txt).
@@ -486,7 +500,7 @@ BSIG_HD int cl_order(int k)
     return (int)((k < 12 ? lo >> (5 * k) : hi >> (5 * (k - 12))) & 31);
 }
 
-constexpr int kLensCodes = 352;   // scratch of inflate_block: 32 for the code-length code + 316 lengths
+constexpr int kLensCodes = 352;   // scratch of produce: 32 for the code-length code + 316 lengths
 constexpr int kLensBytes = 784;   // ... + ColdTables (324 bytes) behind it; the scratch must be 8-byte aligned
 static_assert(kLensCodes % 4 == 0 && kLensCodes + (int)sizeof(ColdTables) <= kLensBytes, "scratch layout");
 
@@ -508,9 +522,7 @@ BSIG_HD int dist_extra(int s) { return s < 4 ? 0 : (s >> 1) - 1; }
 struct LaneProf {
     uint32_t turns, hdrs, walks, match_turns, lit_turns, lits;
     uint64_t hdr_cycles;
-    // sections of a turn: 0 refill + first symbol, 1 further literals (+ the symbol behind them), 2 length/distance
-    // of a match, 3 the deferred stores, 4 the literals' store, 5 the match's loads (or its direct copy), 6 the turn
-    uint64_t sec_cycles[8];     // (7: the wait in the middle of the turn)
+    uint64_t sec_cycles[8];     // (rounds 3-4: shader-clock cycles per section of the one-lane turn; unused since the split)
     uint32_t sec_n[8];
     uint32_t short_period;      // matches with a distance below 8
     uint32_t long_dist;         // distance codes longer than the first-level table
@@ -534,19 +546,94 @@ struct LaneProf {
 #define BSIG_PROF_CLOCK() 0ull
 #endif
 
-// Inflates one raw DEFLATE stream of in_len bytes into exactly out_len bytes (nothing behind
-// out + out_len is touched).  lens: kLensBytes of scratch, 4-byte aligned (global memory on the device).
-// On the device the 8 bytes behind in_p + in_len must be readable (never used: see request()); the host build
-// reads nothing behind the input (tests/asan checks that).
-// Returns OK or an ERR_ code.
-BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, uint32_t out_len, LaneTables &T,
-                          uint8_t *lens, LaneProf *prof = nullptr)
+// ---- the two halves of a block's work and the channel between them ------------------------------------------------
+// Huffman decoding and LZ77 copying are two dependent chains of their own -- bits -> table -> bits ..., and
+// load -> wait -> store ... -- and one lane that runs both pays their SUM per turn (r05 ablation, one round of 57,344
+// blocks: bare records 16.6 ms of which 8.2 decode with all output traffic removed; real-shaped 24.5 of which 18.0).
+// So a block is worked on by TWO lanes, one in each of two waves of a workgroup: the PRODUCER decodes symbols into
+// tokens -- up to six literal bytes and/or one match (length, distance) -- and the CONSUMER turns tokens into bytes
+// (what used to be the second half of a turn: the deferred match stores, the literals' store, the match loads).  The
+// two waves issue side by side and neither waits for the other's memory; between them a one-token mailbox in LDS
+// (12 bytes per block: the tables leave no more at seven workgroups per CU).
+//
+// token: a = literal bytes (bits 0..47) | number of literals << 48 (0..6) | match length << 51 (0 = none, 3..258)
+//        b = valid (bit 0) | distance << 1 (1..32768) | end of stream (bit 17) | error code << 18
+// b == 0: the mailbox is empty.  The producer writes a, then b; the consumer reads b, then a, then clears b; LDS
+// operations of one wave are carried out in order, so no fence is needed, only that the compiler keeps the order
+// (volatile).  The host build pushes the tokens of a whole block into a vector and runs the consumer over it: the
+// same two functions, against zlib in tests/test_inflate_lane.py and under the sanitizers.
+struct Token {
+    uint64_t a;
+    uint32_t b;
+};
+constexpr uint32_t kTokValid = 1u, kTokEnd = 1u << 17;
+constexpr int kTokErrShift = 18;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef BSIG_IDLE_SLEEP
+#define BSIG_IDLE_SLEEP 2
+#endif
+#define BSIG_SLEEP_IF_ALL(c) do { if (__all(c)) __builtin_amdgcn_s_sleep(BSIG_IDLE_SLEEP); } while (0)
+#else
+#define BSIG_SLEEP_IF_ALL(c) do { } while (0)
+#endif
+
+// the device's mailbox: two words of LDS per block.  (Pointers INTO LDS by type: through generic pointers the compiler
+// issues flat_ loads and stores, which wait for LDS and memory alike and may complete out of order.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSIG_LDS __attribute__((address_space(3)))
+#else
+#define BSIG_LDS
+#endif
+struct ChanLds {
+    BSIG_LDS volatile uint64_t *a;
+    BSIG_LDS volatile uint32_t *b;
+    template <typename A, typename B>
+    BSIG_HD ChanLds(A *a_, B *b_) : a((BSIG_LDS volatile uint64_t *)a_), b((BSIG_LDS volatile uint32_t *)b_) {}
+    BSIG_HD bool ready() const { return *b == 0u; }              // (producer) may the next token be sent?
+    BSIG_HD void send(const Token &t) const { *a = t.a; *b = t.b; }
+    BSIG_HD bool take(Token &t) const                             // (consumer)
+    {
+        const uint32_t f = *b;
+        if (f == 0u) return false;
+        t.a = *a;
+        t.b = f;
+        *b = 0u;
+        return true;
+    }
+};
+#if !defined(__HIP_DEVICE_COMPILE__)
+// the host's channel: every token of the block, then the consumer
+struct ChanVec {
+    std::vector<Token> *v;
+    size_t rd;
+    bool ready() const { return true; }
+    void send(const Token &t) const { v->push_back(t); }
+    bool take(Token &t)
+    {
+        if (rd >= v->size()) return false;
+        t = (*v)[rd++];
+        return true;
+    }
+};
+#endif
+
+// PRODUCER: decodes one raw DEFLATE stream of in_len bytes that must inflate to exactly out_len bytes into tokens.
+// lens: kLensBytes of scratch, 8-byte aligned (global memory on the device).  On the device the 8 bytes behind
+// in_p + in_len must be readable (never used: see request()); the host build reads nothing behind the input
+// (tests/asan checks that).  Every token is checked before it is sent (distance within what is out, length within
+// out_len), so the consumer needs no checks of its own.  Ends the stream with an end token that carries the return
+// value: OK or an ERR_ code.
+template <typename Chan>
+BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, LaneTables &T, uint8_t *lens, Chan &ch,
+                    LaneProf *prof = nullptr)
 {
     (void)prof;
     BitIn in;
     in.p = in_p; in.end = in_p + in_len; in.buf = 0; in.cnt = 0;
     request(in);
-    uint32_t op = 0;
+    uint32_t op = 0;                   // bytes the tokens sent so far make
+    int err = OK;
     Counts lc, dc;
     ColdTables &Cd = *reinterpret_cast<ColdTables *>(lens + kLensCodes);
     LSyms ls{Cd.lsym, Cd.lhi, T.lsym_hot, {}, 0};
@@ -562,21 +649,30 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
         const uint32_t last = take(in, 1);
         const uint32_t type = take(in, 2);
         if (type == 0) {
-            // stored: skip to the byte boundary, LEN / NLEN, raw bytes
+            // stored: skip to the byte boundary, LEN / NLEN, raw bytes -- sent as literals, six per token (rare in a
+            // BAM: only data that does not compress)
             take(in, in.cnt & 7);
             refill(in);
             const uint32_t len = take(in, 16), nlen = take(in, 16);
-            if ((len ^ 0xFFFFu) != nlen) return ERR_STORED;
+            if ((len ^ 0xFFFFu) != nlen) { err = ERR_STORED; break; }
             // bytes still in the bit buffer belong to the raw data
             const uint8_t *src = in.p - (in.cnt >> 3);
-            if (src + len > in.end) return ERR_INPUT;
-            if (op + len > out_len) return ERR_OUTPUT;
-            for (uint32_t k = 0; k < len; ++k) out[op + k] = src[k];
+            if (src + len > in.end) { err = ERR_INPUT; break; }
+            if (op + len > out_len) { err = ERR_OUTPUT; break; }
+            for (uint32_t k = 0; k < len;) {
+                if (!ch.ready()) { BSIG_SLEEP_IF_ALL(true); continue; }
+                const uint32_t m = len - k < 6u ? len - k : 6u;
+                uint64_t w = 0;
+                for (uint32_t q = 0; q < m; ++q) w |= (uint64_t)src[k + q] << (8 * q);
+                ch.send(Token{w | (uint64_t)m << 48, kTokValid});
+                k += m;
+            }
             op += len;
             in.p = src + len; in.buf = 0; in.cnt = 0;
             request(in);
         } else if (type == 3) {
-            return ERR_CODE;
+            err = ERR_CODE;
+            break;
         } else {
             if (type == 1) {
                 // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
@@ -586,7 +682,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
             } else {
                 const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
-                if (nlen > 286 || ndist > 30) return ERR_TABLE;
+                if (nlen > 286 || ndist > 30) { err = ERR_TABLE; break; }
                 // the code-length code: its 19 lengths (3 bits each, in the order of RFC 1951, 3.2.7) in one register
                 uint64_t clw = 0;
                 for (int k = 0; k < ncode; ++k) {
@@ -598,8 +694,10 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                 // hot symbols' LDS (128 bytes, rewritten with the literal/length table below).  (The symbols are
                 // sorted into ds as well -- free until the distance code is built -- for builds with fewer hot symbols.)
                 constexpr bool kClTable = kHotSyms >= 128;
-                if (!construct<kClTable ? 7 : 0>(cc, Fast8{kClTable ? T.lsym_hot : nullptr}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); }))
-                    return ERR_TABLE;
+                if (!construct<kClTable ? 7 : 0>(cc, Fast8{kClTable ? T.lsym_hot : nullptr}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); })) {
+                    err = ERR_TABLE;
+                    break;
+                }
                 // literal/length + distance code lengths, run-length coded.  They are collected in the first-level
                 // literal table's LDS (free until that table is rebuilt below) and copied to the scratch in one go:
                 // a store per length to global memory made every wait of this loop -- each refill's -- a wait for
@@ -616,21 +714,21 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                     int s;
                     if (kClTable) {
                         const uint32_t e = T.lsym_hot[in.buf & 127u];
-                        if (!e) return ERR_CODE;
+                        if (!e) { err = ERR_CODE; break; }
                         in.buf >>= (e & 7u);
                         in.cnt -= (int)(e & 7u);
                         s = (int)(e >> 3);
                     } else {
                         s = decode_walk(in, cc, ds);
                     }
-                    if (s < 0) return ERR_CODE;
+                    if (s < 0) { err = ERR_CODE; break; }
                     if (s < 16) {
                         ll_near[idx++] = (uint8_t)s;
                         prev_len = s;
                     } else {
                         int prev = 0, rep;
                         if (s == 16) {
-                            if (idx == 0) return ERR_TABLE;
+                            if (idx == 0) { err = ERR_TABLE; break; }
                             prev = prev_len;
                             rep = 3 + (int)take(in, 2);
                         } else if (s == 17) {
@@ -638,7 +736,7 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         } else {
                             rep = 11 + (int)take(in, 7);
                         }
-                        if (idx + rep > nlen + ndist) return ERR_TABLE;
+                        if (idx + rep > nlen + ndist) { err = ERR_TABLE; break; }
                         if (prev) {
                             while (rep--) ll_near[idx++] = (uint8_t)prev;      // (code 16: at most six)
                         } else {
@@ -646,226 +744,315 @@ BSIG_HD int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, ui
                         }
                         prev_len = prev;
                     }
-                    if (overrun(in)) return ERR_INPUT;
+                    if (overrun(in)) { err = ERR_INPUT; break; }
                 }
+                if (err) break;
                 for (int k = 0; k < nlen + ndist; k += 8) store64(ll + k, load64(ll_near + k));      // (<= 320 bytes either side)
                 {
                     LenReader eob(ll + 256);
-                    if (eob(0) == 0) return ERR_TABLE;            // no end-of-block code
+                    if (eob(0) == 0) { err = ERR_TABLE; break; }  // no end-of-block code
                 }
-                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next)) return ERR_TABLE;
-                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) return ERR_TABLE;
+                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next)) { err = ERR_TABLE; break; }
+                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) { err = ERR_TABLE; break; }
             }
-            // ---- the compressed data of this block: per turn ONE symbol, or a slice of the pending match.
-            // The bytes of a match are LOADED in the turn that meets it and STORED in the next one,
-            // behind that turn's symbol decode: the trip to memory runs beside the decode. ----
+            // ---- the compressed data of this block: per turn ONE token -- a run of up to six literals the first-level
+            // table knows and/or the match behind them.  The only memory a turn touches is the input word requested a
+            // turn ahead (and, rarely, a cold symbol), so a turn is the decode chain and nothing else. ----
             const WalkStart lws = walk_start<kLFast>(lc), dws = walk_start<kDFast>(dc);
             BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
-            uint32_t pend = 0, pdist = 0;
-            uint32_t pper = 0, pdone = 0;      // the match's period (its distance as coded) and how much of it is out
-            uint64_t wpat = 0;                 // short period: the bytes before the match, asked for a turn ahead
-            uint32_t pp = 0;                   // ... and whether they were
-            uint32_t dn = 0, dpos = 0;          // deferred stores: dn bytes (in 8-byte moves) at out + dpos
-            W16 v[kTurn / 16];
-            for (uint32_t k = 0; k < kTurn / 16; ++k) v[k] = W16{0, 0};
-            int err = OK;
-            // The compiler waits for memory with s_waitcnt vmcnt(0) wherever a loaded value is first used -- the
-            // exact counts are beyond it in a loop whose loads and stores sit under lane-dependent branches -- and
-            // that wait drains EVERYTHING in flight.  A turn's first use was the refill at its top, a few
-            // instructions behind the match loads the previous turn ends with: every turn stood still for one trip
-            // to memory (2,800 of its 8,900 cycles, profiles/r03_inflate_prof.txt).  The turn now waits ONCE, in
-            // its middle, where it needs the previous turn's match words: by then those loads have had the symbol
-            // decode to arrive in, and the input word requested at the top is as old.  The refill at the top then
-            // finds its word ready (the compiler sees the drain between the request and the use) and the loads the
-            // turn ends with are not waited for until the middle of the next one.
-            BSIG_VM_DRAIN();
             for (;;) {
+                // Is the mailbox empty?  Asked NOW, needed only when the token is ready: the answer arrives beside the
+                // first table lookup instead of standing in front of the chain, and the token is decoded while the
+                // consumer may still be busy with the previous one.
+                const bool room = ch.ready();
                 uint64_t lit = 0;
-                uint32_t nlit = 0;
-                bool stop = false;
-                BSIG_PROF(prof->turns++; if (pend) prof->match_turns++);
-                BSIG_SEC_BEGIN(6);
-                if (pend == 0) {
-                    BSIG_SEC_BEGIN(0);
-                    refill(in);
-                    BSIG_PROF(if (lfast_at(T, in.buf) == 0) prof->walks++);
-                    int s = decode<kLFast>(in, T, lc, ls, lws);
-                    BSIG_SEC_END(0);
-                    uint32_t opx = op;                 // where the next symbol's bytes will go
-                    if (s < 256) {
-                        if (s < 0) { err = ERR_CODE; stop = true; }
-                        else if (op >= out_len) { err = ERR_OUTPUT; stop = true; }
-                        else {
-                            // a literal; up to five more if the first-level table says the next symbols
-                            // are literals too (<= 8 bits each: the 56 bits of the refill cover 15 + 5 x 8)
-                            lit = (uint64_t)s;
-                            nlit = 1;
-                            s = -2;                    // nothing more this turn, unless a match follows
-                            BSIG_SEC_BEGIN(1);
-                            if (kLFast > 0 && kMultiLit) {
+                uint32_t nlit = 0, mlen = 0, mdist = 0;
+                bool eob = false;
+                BSIG_PROF(prof->turns++);
+                refill(in);
+                BSIG_PROF(if (lfast_at(T, in.buf) == 0) prof->walks++);
+                int s = decode<kLFast>(in, T, lc, ls, lws);
+                uint32_t opx = op;                 // where the next symbol's bytes will go
+                if (s < 256) {
+                    if (s < 0) { err = ERR_CODE; }
+                    else if (op >= out_len) { err = ERR_OUTPUT; }
+                    else {
+                        // a literal; up to five more if the first-level table says the next symbols
+                        // are literals too (<= 8 bits each: the 56 bits of the refill cover 15 + 5 x 8)
+                        lit = (uint64_t)s;
+                        nlit = 1;
+                        s = -2;                    // nothing more this turn, unless a match follows
+                        if (kLFast > 0 && kMultiLit) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-                                for (int q = 1; q < 6; ++q) {
-                                    const uint32_t e = lfast_at(T, in.buf);
-                                    if (e == 0 || (e >> 4) >= 256u || in.cnt < 2 * kLFast || op + (uint32_t)q >= out_len) break;
-                                    const int len = (int)(e & 15u);
-                                    in.buf >>= len;
-                                    in.cnt -= len;
-                                    lit |= (uint64_t)(e >> 4) << (8 * q);
-                                    nlit = (uint32_t)q + 1;
-                                }
-                                // a match right behind the literals rides in the same turn (its bits come
-                                // with a second refill; the words it needs were requested a turn ago)
-                                if (in.cnt >= kLFast) {
-                                    const uint32_t e = lfast_at(T, in.buf);
-                                    if (e && (e >> 4) > 256u) {
-                                        refill(in);
-                                        s = decode<kLFast>(in, T, lc, ls, lws);
-                                    }
+                            for (int q = 1; q < 6; ++q) {
+                                const uint32_t e = lfast_at(T, in.buf);
+                                if (e == 0 || (e >> 4) >= 256u || in.cnt < 2 * kLFast || op + (uint32_t)q >= out_len) break;
+                                const int len = (int)(e & 15u);
+                                in.buf >>= len;
+                                in.cnt -= len;
+                                lit |= (uint64_t)(e >> 4) << (8 * q);
+                                nlit = (uint32_t)q + 1;
+                            }
+                            // a match right behind the literals rides in the same token (its bits come
+                            // with a second refill; the word it needs was requested a turn ago)
+                            if (in.cnt >= kLFast) {
+                                const uint32_t e = lfast_at(T, in.buf);
+                                if (e && (e >> 4) > 256u) {
+                                    refill(in);
+                                    s = decode<kLFast>(in, T, lc, ls, lws);
                                 }
                             }
-                            BSIG_SEC_END(1);
-                            opx = op + nlit;
                         }
+                        opx = op + nlit;
                     }
-                    BSIG_SEC_BEGIN(2);
+                }
+                if (err == OK) {
                     if (s == 256) {
-                        stop = true;
+                        eob = true;
                     } else if (s > 256) {
                         s -= 257;
-                        if (s >= 29) { err = ERR_CODE; stop = true; }
+                        if (s >= 29) { err = ERR_CODE; }
                         else {
                             const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
                             BSIG_PROF(if (T.dfast[in.buf & ((1u << kDFast) - 1)] == 0) prof->long_dist++);
                             const int d = decode_dist(in, T.dfast, dc, ds, dws);             // <= 20 + 28 of the 56 bits
-                            if (d < 0 || d >= 30) { err = ERR_CODE; stop = true; }
+                            if (d < 0 || d >= 30) { err = ERR_CODE; }
                             else {
                                 const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
-                                if (dist > opx) { err = ERR_DIST; stop = true; }
-                                else if (opx + len > out_len) { err = ERR_OUTPUT; stop = true; }
-                                else if (overrun(in)) { err = ERR_INPUT; stop = true; }
-                                else { pend = len; pdist = dist; pper = dist; pdone = 0; }
+                                if (dist > opx) { err = ERR_DIST; }
+                                else if (opx + len > out_len) { err = ERR_OUTPUT; }
+                                else if (overrun(in)) { err = ERR_INPUT; }
+                                else { mlen = len; mdist = dist; }
                             }
                         }
-                        BSIG_SEC_END(2);
                     }
                 }
-                // the previous turn's match bytes
-                BSIG_SEC_BEGIN(7);
-                BSIG_VM_DRAIN();
-                BSIG_SEC_END(7);
-                BSIG_SEC_BEGIN(3);
-                if (dn) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                    for (uint32_t k = 0; k < kTurn / 16; ++k)
-                        if (16 * k < dn) store128(out + dpos + 16 * k, v[k]);
-                    dn = 0;
-                    BSIG_SEC_END(3);
+                if (err) break;
+                BSIG_PROF(if (nlit) { prof->lit_turns++; prof->lits += nlit; } if (mlen) prof->match_turns++);
+                if (nlit | mlen) {
+                    // (the consumer still holds the previous token: a long match, or its memory is slow)
+                    if (!room)
+                        while (!ch.ready()) BSIG_SLEEP_IF_ALL(true);
+                    ch.send(Token{lit | (uint64_t)nlit << 48 | (uint64_t)mlen << 51, kTokValid | mdist << 1});
+                    op = opx + mlen;
                 }
-                if (stop) break;
-                BSIG_PROF(if (nlit) { prof->lit_turns++; prof->lits += nlit; });
-                BSIG_SEC_BEGIN(4);
-                if (nlit) {
-                    if (op + 8 <= out_len) {
-                        store64(out + op, lit);      // (what lies behind the literals is overwritten by what follows)
-                    } else {
-                        for (uint32_t q = 0; q < nlit; ++q) out[op + q] = (uint8_t)(lit >> (8 * q));
-                    }
-                    op += nlit;
-                    BSIG_SEC_END(4);
-                }
-                BSIG_SEC_BEGIN(5);
-                if (pend) {
-                    // up to kTurn bytes of the match per turn, in 16-byte moves (every lane's move is a
-                    // request of its own to the memory system: half as many as with 8 bytes).  A move may
-                    // write up to 15 bytes past the match (inside this block's own area: the next symbols
-                    // overwrite them); only the last bytes of a block are moved one by one.
-                    uint32_t n = pend < kTurn ? pend : kTurn;
-                    if (op + ((n + 15u) & ~15u) <= out_len) {
-                        if (pdist < 8) {
-                            // short period (runs, 2- and 3-byte patterns): the first 8 bytes come from a
-                            // pattern built in registers; behind them the same bytes repeat at a distance
-                            // that is a multiple of the period and >= 8, so the rest is ordinary moves.
-                            // The period's bytes are the literals of this very turn if there are enough of
-                            // them (a run starts as "one literal, then the match at distance 1"); else they
-                            // are ASKED for now and the pattern is built next turn -- waiting for them here
-                            // would drain the stores this turn has just issued (r03: 5 % of the north
-                            // star's matches are of this kind, so some lane of a wave met one in four turns
-                            // out of five, 900 cycles each).
-                            uint64_t w = wpat;                                // its low `pdist` bytes are valid
-                            bool have = pp != 0;
-                            pp = 0;
-                            if (!have && pdist <= nlit) {
-                                w = lit >> (8u * (nlit - pdist));
-                                have = true;
-                            }
-                            // (the pattern first, the request behind it: a request issued BEFORE the other
-                            // lanes read `wpat` would make them wait for it)
-                            const bool ask = !have;
-                            if (have) {
-                                uint64_t pat = 0;
-                                uint32_t j = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                                for (int i = 0; i < 8; ++i) {
-                                    pat |= ((w >> (8 * j)) & 0xFFull) << (8 * i);
-                                    j = j + 1 == pdist ? 0 : j + 1;
-                                }
-                                store64(out + op, pat);
-                                const uint32_t m = n < 8u ? n : 8u;
-                                op += m; pend -= m; n -= m;
-                                // smallest multiple of the period >= 8 (periods 1..7: 8 8 9 8 10 12 14)
-                                pdist = (0xECA8988u >> (4u * (pdist - 1u))) & 15u;
-                                pper = pdist;
-                                pdone = 0;
-                            }
-                            if (ask) {
-                                BSIG_PROF(prof->short_period++);
-                                wpat = load64(out + op - pdist);
-                                pp = 1;
-                                n = 0;
-                            }
-                        }
-                        // a source that overlaps the destination (period < the slice): the bytes repeat with
-                        // that period, so once enough of them are out the SAME bytes lie further back as
-                        // well -- the distance doubles (it stays a multiple of the period) -- and until then
-                        // the slice stops where the source would run into it.  Every slice is then loads
-                        // from bytes that are all there, stored next turn: no load-wait-store chain, which
-                        // for the bare reads of the north star's file (a 36-byte record repeats most of the
-                        // previous one: distances below 64 are the rule) was a quarter of a turn.
-                        if (pdist < kTurn && pdone + pper >= 2u * pdist) pdist *= 2u;
-                        // (what a move reads past the slice may not be written yet: it lands past the slice)
-                        if (pdist < n) n = pdist;                                    // (>= 8: pdist >= 8 here)
-                        const uint8_t *from = out + op - pdist;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                        for (uint32_t k = 0; k < kTurn / 16; ++k)
-                            if (16 * k < n) v[k] = load128(from + 16 * k);
-                        dn = n;
-                        dpos = op;
-                    } else {
-                        const uint8_t *from = out + op - pdist;
-                        for (uint32_t k = 0; k < n; ++k) out[op + k] = from[k];      // byte by byte: overlaps repeat
-                    }
-                    pdone += n;
-                    op += n;
-                    pend -= n;
-                    BSIG_SEC_END(5);
-                }
-                BSIG_SEC_END(6);
+                if (eob) break;
             }
-            if (err) return err;
+            if (err) break;
         }
-        if (overrun(in)) return ERR_INPUT;
+        if (overrun(in)) { err = ERR_INPUT; break; }
         if (last) break;
     }
-    return op == out_len ? OK : ERR_OUTPUT;
+    if (err == OK && op != out_len) err = ERR_OUTPUT;
+    while (!ch.ready()) BSIG_SLEEP_IF_ALL(true);
+    ch.send(Token{0, kTokValid | kTokEnd | (uint32_t)err << kTokErrShift});
+    return err;
 }
+
+// CONSUMER: the tokens of one block -> its out_len bytes at `out` (nothing behind out + out_len is touched).  Per
+// turn one token, OR a slice of the pending match: a lane that copies a 258-byte match does not hold the other lanes
+// of its wave for 258 turns.  The LZ77 window is the output itself (global memory on the device): matches read back
+// what the lane wrote.  The bytes of a match are LOADED in the turn that meets it and taken up in the next one: the trip
+// to memory runs beside the next token's handling, and memory is waited for ONCE per turn (BSIG_VM_DRAIN: the
+// compiler's own waits are all-or-nothing -- s_waitcnt vmcnt(0) wherever a loaded value is first used, the exact counts
+// being beyond it in a loop whose loads and stores sit under lane-dependent branches -- so every load whose value is
+// needed at once stalls the wave for a whole trip and drains what else is in flight).
+//
+// What bounds a full chip is the number of per-lane memory accesses, not their bytes (r05: TCP accesses per second
+// are the same at half and at full occupancy, and k_inflate is no faster with all lanes than with half of them): every
+// lane works in its own block, so each lane of each load or store is an access of its own to the CU's address
+// pipeline.  The output therefore goes through a 16-byte ACCUMULATOR in registers and reaches memory in whole
+// 16-byte stores, each byte once: literals (up to six bytes a token) and match bytes are shifted in behind each other;
+// a token costs about out_bytes / 16 stores instead of one per literal run plus one per 16 bytes of match, each
+// overshooting into bytes that were then written again.
+struct OutAcc {
+    uint64_t a, b;       // the bytes [op - fill, op), low byte first; zero beyond them
+    uint64_t prev;       // the eight bytes in front of them (the upper half of the chunk stored last)
+    uint32_t fill;       // 0..15
+};
+// the low n bytes of x (n >= 8: all of it)
+BSIG_HD uint64_t low_bytes(uint64_t x, uint32_t n) { return n >= 8u ? x : x & ((1ull << (8u * n)) - 1ull); }
+// x << s and x >> (64 - s) for s in 0..63, in bits (the second is 0 for s = 0)
+BSIG_HD uint64_t shl_bits(uint64_t x, uint32_t s) { return x << s; }
+BSIG_HD uint64_t carry_bits(uint64_t x, uint32_t s) { return s ? x >> (64u - s) : 0ull; }
+
+// k bytes (0..16: the low bytes of (x0, x1), the rest already zero) behind the accumulator's; a full chunk goes to
+// memory at out + (op - fill) and what is over starts the next one
+BSIG_HD void acc_append(OutAcc &A, uint8_t *out, uint32_t &op, uint64_t x0, uint64_t x1, uint32_t k)
+{
+    const uint32_t s = 8u * (A.fill & 7u);
+    const uint64_t p0 = shl_bits(x0, s), p1 = shl_bits(x1, s) | carry_bits(x0, s), p2 = carry_bits(x1, s);
+    const bool up = A.fill >= 8u;                       // the new bytes begin in the upper half
+    const uint64_t c0 = A.a | (up ? 0ull : p0), c1 = A.b | (up ? p0 : p1), c2 = up ? p1 : p2, c3 = up ? p2 : 0ull;
+    const uint32_t nf = A.fill + k;
+    const bool full = nf >= 16u;
+    if (full) {
+        store128(out + (op - A.fill), W16{c0, c1});
+        A.prev = c1;
+    }
+    A.a = full ? c2 : c0;
+    A.b = full ? c3 : c1;
+    A.fill = nf & 15u;
+    op += k;
+}
+
+template <typename Chan>
+BSIG_HD void consume(uint8_t *out, uint32_t out_len, Chan &ch)
+{
+    constexpr uint32_t kTail = 160;    // the last bytes of a block are written one by one (16-byte moves may not pass its end)
+    uint32_t op = 0;                   // bytes out, those in the accumulator included
+    OutAcc A{0, 0, 0, 0};
+    bool tail = false;                 // byte by byte from here on (the accumulator is empty)
+    uint32_t pend = 0, pdist = 0;
+    uint32_t pper = 0, pdone = 0;      // the match's period (its distance as coded) and how much of it is out
+    uint32_t dn = 0;                   // bytes of the pending match loaded last turn (v), to be taken up in this one
+    W16 v[kTurn / 16];
+    for (uint32_t k = 0; k < kTurn / 16; ++k) v[k] = W16{0, 0};
+    for (;;) {
+        uint64_t lit = 0;
+        uint32_t nlit = 0;
+        bool stop = false;
+        if (pend == 0) {
+            Token t;
+            if (ch.take(t)) {
+                lit = t.a & 0xFFFFFFFFFFFFull;
+                nlit = (uint32_t)(t.a >> 48) & 7u;
+                const uint32_t len = (uint32_t)(t.a >> 51) & 0x1FFu;
+                stop = (t.b & kTokEnd) != 0u;
+                if (len) { pend = len; pdist = (t.b >> 1) & 0xFFFFu; pper = pdist; pdone = 0; }
+            } else {
+                BSIG_SLEEP_IF_ALL(dn == 0);
+            }
+        }
+        // the previous turn's match bytes
+        BSIG_VM_DRAIN();
+        if (dn) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (uint32_t k = 0; k < kTurn / 16; ++k) {
+                if (16 * k < dn) {
+                    const uint32_t cnt = dn - 16 * k < 16u ? dn - 16 * k : 16u;
+#if !BSIG_ABL_NO_MSTORE
+                    acc_append(A, out, op, low_bytes(v[k].a, cnt), cnt > 8u ? low_bytes(v[k].b, cnt - 8u) : 0ull, cnt);
+#else
+                    op += cnt;
+#endif
+                }
+            }
+            dn = 0;
+        }
+        if (!tail && out_len - op < kTail) {
+            // the rest of the block byte by byte: what the accumulator holds first
+            for (uint32_t q = 0; q < A.fill; ++q) out[op - A.fill + q] = (uint8_t)((q < 8u ? A.a >> (8u * q) : A.b >> (8u * (q - 8u))) & 0xFFu);
+            A.a = A.b = 0; A.fill = 0;
+            tail = true;
+        }
+        if (stop) break;
+        if (tail) {
+            for (uint32_t q = 0; q < nlit; ++q) out[op + q] = (uint8_t)(lit >> (8 * q));
+            op += nlit;
+            if (pend) {
+                const uint8_t *from = out + op - pdist;
+                for (uint32_t k = 0; k < pend; ++k) out[op + k] = from[k];      // byte by byte: overlaps repeat
+                op += pend;
+                pend = 0;
+            }
+            continue;
+        }
+#if !BSIG_ABL_NO_LSTORE
+        acc_append(A, out, op, lit, 0ull, nlit);
+#else
+        op += nlit;
+#endif
+        if (pend) {
+            // up to kTurn bytes of the match per turn, in 16-byte loads (every lane's load is an access of its own)
+            uint32_t n = pend < kTurn ? pend : kTurn;
+            if (pdist < 8) {
+                // short period (runs, 2- and 3-byte patterns): the first 8 bytes come from a pattern built in
+                // registers out of the last bytes out -- they are at hand: the accumulator and the upper half of
+                // the chunk in front of it -- ; behind them the same bytes repeat at a distance that is a multiple of
+                // the period and >= 8, so the rest is ordinary moves.
+                const uint32_t at = 8u + A.fill - pdist;                      // byte offset in (prev, a, b): 1..22
+                const uint32_t sh = 8u * (at & 7u);
+                const uint64_t w0 = at < 8u ? A.prev : at < 16u ? A.a : A.b, w1 = at < 8u ? A.a : at < 16u ? A.b : 0ull;
+                const uint64_t w = (w0 >> sh) | (sh ? w1 << (64u - sh) : 0ull);   // its low `pdist` bytes are the period
+                uint64_t pat = 0;
+                uint32_t j = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int i = 0; i < 8; ++i) {
+                    pat |= ((w >> (8 * j)) & 0xFFull) << (8 * i);
+                    j = j + 1 == pdist ? 0 : j + 1;
+                }
+                const uint32_t m = n < 8u ? n : 8u;
+#if !BSIG_ABL_NO_LSTORE
+                acc_append(A, out, op, low_bytes(pat, m), 0ull, m);
+#else
+                op += m;
+#endif
+                pend -= m; n -= m;
+                // smallest multiple of the period >= 8 (periods 1..7: 8 8 9 8 10 12 14)
+                pdist = (0xECA8988u >> (4u * (pdist - 1u))) & 15u;
+                pper = pdist;
+                pdone = 0;
+            }
+            // a source that overlaps the destination (period < the slice): the bytes repeat with
+            // that period, so once enough of them are out the SAME bytes lie further back as
+            // well -- the distance doubles (it stays a multiple of the period) -- and until then
+            // the slice stops where the source would run into it.  Every slice is then loads
+            // from bytes that are all there, taken up next turn: no load-wait-store chain, which
+            // for the bare reads of the north star's file (a 36-byte record repeats most of the
+            // previous one: distances below 64 are the rule) was a quarter of a turn.
+            if (pdist < kTurn && pdone + pper >= 2u * pdist) pdist *= 2u;
+            // (what a load reads past the slice may not be written yet: it is masked off when it is taken up)
+            if (pdist < n) n = pdist;                                    // (>= 8: pdist >= 8 here)
+            // the source must be in MEMORY: its last bytes may still be in the accumulator, which then goes out
+            // as it is (the same chunk is stored again when it is full)
+            if (n && pdist - n < A.fill) store128(out + (op - A.fill), W16{A.a, A.b});
+#if BSIG_ABLATE == 6 || BSIG_ABLATE == 7
+            // (6 / 7: the match loads read 8 KB / 256 B FURTHER BACK than they should -- as many loads, but never from a
+            // cache line that is still being written)
+            const uint32_t back_ = BSIG_ABLATE == 6 ? 8192u : 256u, src_ = op - pdist;
+            const uint8_t *from = out + (src_ > back_ ? src_ - back_ : 0u);
+#else
+            const uint8_t *from = out + op - pdist;
+#endif
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (uint32_t k = 0; k < kTurn / 16; ++k) {
+#if !BSIG_ABL_NO_MLOAD
+                if (16 * k < n) v[k] = load128(from + 16 * k);
+#else
+                if (16 * k < n) v[k] = W16{(uint64_t)(from - out), k};
+#endif
+            }
+            dn = n;
+            pdone += n;
+            pend -= n;
+        }
+    }
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host: inflates one raw DEFLATE stream of in_len bytes into exactly out_len bytes -- the producer's tokens of the
+// whole block, then the consumer over them (the device runs the same two functions side by side, devdecode.hip:
+// k_inflate).  T: first-level tables; lens: kLensBytes of scratch, 8-byte aligned.  Returns OK or an ERR_ code; on
+// an error the bytes the tokens before it describe are written.
+inline int inflate_block(const uint8_t *in_p, uint32_t in_len, uint8_t *out, uint32_t out_len, LaneTables &T, uint8_t *lens,
+                         LaneProf *prof = nullptr)
+{
+    std::vector<Token> toks;
+    ChanVec ch{&toks, 0};
+    const int rc = produce(in_p, in_len, out_len, T, lens, ch, prof);
+    consume(out, out_len, ch);
+    return rc;
+}
+#endif
 
 }  // namespace bsig_inflate
 #endif
