@@ -269,13 +269,23 @@ struct bsig_plan {
     bool have_stats = false;
     bsig_plan_stats stats{};
     uint8_t *ptab = nullptr;            // the packed class's filter table for kp (BsigKParams::ptab)
-    BsigResolved *resolved = nullptr;   // large launches: the windows of every tile, written by k_resolve_tiles in every run
+    BsigResolved *resolved = nullptr;   // large launches: the windows of every tile, written by k_resolve_tiles
+    uint64_t resolved_gen = 0;          // ... for this layout of the reads (0: not yet): a later run on the same layout reuses them
+    uint64_t made_for_gen = 0;          // the layout the plan was made on: its tiles' heavy slices and the packed class's filter
+                                        // table are read off that layout, so a plan does not outlive it
 };
 static int64_t g_resolve_min_override = -1;     // bsig_debug_set_knob(4, n): two launches from n tiles on (sweeps)
 // does a run of this plan look its windows up in a launch of its own?  (measured at the north star's read density,
 // scripts/ns_variants.py: 15,000 tiles 28.3 us fused / 31.1 us in two launches, 25,000 43.3 / 46.2, 35,000 71.8 / 66.3,
 // 50,000 112.0 / 107.3, 100,000 189.7 / 177.1; config 5's share 180.6 / 157.5, config 4's call 407 / 370:
 // env BAMSIGNALS_RESOLVE_MIN_TILES, default 32,768)
+// are a large launch's tile windows kept with the plan after its first run (default), or looked up in every run?
+static bool windows_kept()
+{
+    const char *e = getenv("BAMSIGNALS_CACHE_WINDOWS");      // (read per run: a test flips it)
+    return !(e && !strcmp(e, "0"));
+}
+
 static bool plan_two_launches(const bsig_plan *p)
 {
     static const int64_t resolve_min = getenv("BAMSIGNALS_RESOLVE_MIN_TILES") ? atoll(getenv("BAMSIGNALS_RESOLVE_MIN_TILES")) : (int64_t)32768;
@@ -413,12 +423,19 @@ void bsig_host_free(void *ptr)
 
 // The resident layout from device columns; shared by bsig_reads_upload (host columns) and the
 // device-side BAM decode (devdecode.hip).
+uint64_t bsig::next_layout_gen()
+{
+    static std::atomic<uint64_t> g{0};
+    return ++g;
+}
+
 int bsig::layout_from_device(bsig_ctx *ctx, bsig_reads *R, int64_t n, int32_t n_ref, const int32_t *ref_len,
                              const int64_t *ref_off, const int32_t *d_pos, const int32_t *d_end,
                              const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tlen)
 {
     hipStream_t st = ctx->stream;
     HIP_TRY(hipSetDevice(ctx->device));
+    R->layout_gen = next_layout_gen();          // (whatever a plan cached for an earlier layout of R is stale from here on)
 
     // global coordinate: references back to back in 64-kbp units
     R->n_ref = n_ref;
@@ -1174,6 +1191,7 @@ int bsig_reads_load(bsig_ctx *ctx, const char *path, const char *stamp, bsig_rea
     R->ref_units.assign((const uint32_t *)p_un, (const uint32_t *)p_un + H.n_ref);
     R->info = bsig_reads_info{};
     R->info.n_reads = H.n_reads;
+    R->layout_gen = bsig::next_layout_gen();
     // no table, no packed reads; the converse does not hold: the pair sample may have seen short reads of which
     // none qualified for the packed class (all beyond their reference's end), and such a layout is saved as it is
     if (H.n_codes > BSIG_PACK_CODES || (H.n_codes == 0 && H.cls[BSIG_CLASS_PACKED].n != 0))
@@ -1313,6 +1331,7 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
 
     bsig_plan *P = new bsig_plan;
     P->ctx = ctx; P->reads = reads; P->mode = mode; P->n_ranges = n;
+    P->made_for_gen = reads->layout_gen;
     // default tile: the widest range if it fits 2048 cells (less LDS per workgroup = more
     // workgroups per CU), else 2048-cell tiles
     int64_t widest = 64;
@@ -1510,6 +1529,8 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     if (cells == 0) return BSIG_OK;
     if (!out_dev) return fail(BSIG_ERR_ARG, "output buffer is NULL");
     if (((uintptr_t)out_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device output buffer must be 16-byte aligned");
+    if (p->reads->layout_gen != p->made_for_gen)
+        return fail(BSIG_ERR_ARG, "the reads were laid out again after this plan was made: make a new plan");
     HIP_TRY(hipSetDevice(p->ctx->device));      // the caller's thread may have another GPU current
     hipStream_t st = p->ctx->stream;
     // (heavy tiles need no fill: their main item stores 0 and only the slices add)
@@ -1518,15 +1539,21 @@ int bsig_plan_run(bsig_plan *p, int32_t *out_dev)
     // Large launches look their tiles' windows up in a launch of their own (k_resolve_tiles, one lane per tile), so
     // that a pileup workgroup -- which holds its LDS and registers from its first instruction on -- gets its work
     // item and its windows in ONE memory round trip instead of two dependent ones; small launches, where a second
-    // launch costs more than it hides, look them up inside the pileup kernel.  Both forms are the step: the index
-    // lookup (bam_itr_queryi's counterpart, ref: :267) runs on every bsig_plan_run.
+    // launch costs more than it hides, look them up inside the pileup kernel (bam_itr_queryi's counterpart, ref: :267).
+    // A plan and a layout of the reads are both immutable, so the windows are a function of the two: the lookup
+    // launch runs in the plan's FIRST run on a layout and its result is kept with the plan (round 5; 9-11 us of every
+    // later step of a resident plan; env BAMSIGNALS_CACHE_WINDOWS=0: looked up in every run, as in round 4).  A file-
+    // level call makes its plan and runs it once: it looks its windows up once either way.
     const bool two_launches = plan_two_launches(p);
     if (two_launches) {
+        const bool keep = windows_kept();
         if (!p->resolved) HIP_TRY(p->pool.alloc(&p->resolved, (size_t)p->n_items));
+        const bool lookup = !keep || p->resolved_gen != p->reads->layout_gen;
         BsigKParams res = p->kp;
         res.resolved = 1;
         HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, res, p->items, p->n_items,
-                                    p->tile_cells, p->resolved, true, out_dev, st));
+                                    p->tile_cells, p->resolved, lookup, out_dev, st));
+        p->resolved_gen = p->reads->layout_gen;
     } else {
         HIP_TRY(bsig::launch_pileup(p->kernel_mode, p->kp.ss, p->threads, p->reads->dev, p->kp, p->items, p->n_items,
                                     p->tile_cells, nullptr, false, out_dev, st));
@@ -1625,10 +1652,15 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
         // reads + work items + index entries + result cells
         const int64_t per_item = (int64_t)sizeof(BsigWorkItem);
         t.algorithmic_bytes = t.bytes_per_visit_packed * t.visits_packed + t.bytes_per_visit_short * t.visits_short +
-                              t.bytes_per_visit_long * (t.visits - t.visits_short - t.visits_packed) + per_item * t.n_items +
-                              8 * t.n_items * p->reads->info.n_classes + 4 * t.cells;
-        // two launches: the work item is read twice and the tile's windows are written and read once
-        if (plan_two_launches(p)) t.algorithmic_bytes += (per_item + 2 * (int64_t)sizeof(BsigResolved)) * t.n_items;
+                              t.bytes_per_visit_long * (t.visits - t.visits_short - t.visits_packed) + per_item * t.n_items + 4 * t.cells;
+        if (plan_two_launches(p) && windows_kept()) {
+            // a resident plan's step reads the windows kept from its first run: no index entry is touched
+            t.algorithmic_bytes += (int64_t)sizeof(BsigResolved) * t.n_items;
+        } else {
+            t.algorithmic_bytes += 8 * t.n_items * p->reads->info.n_classes;          // the index entries
+            // two launches: the work item is read twice and the tile's windows are written and read once
+            if (plan_two_launches(p)) t.algorithmic_bytes += (per_item + 2 * (int64_t)sizeof(BsigResolved)) * t.n_items;
+        }
         p->have_stats = true;
     }
     *s = p->stats;
@@ -1636,6 +1668,14 @@ int bsig_plan_get_stats(bsig_plan *p, bsig_plan_stats *s)
 }
 
 void bsig_plan_free(bsig_plan *p) { delete p; }
+
+// (tests: what a re-layout of the resident columns does to the plans made before it)
+int bsig_debug_new_layout_gen(bsig_reads *reads)
+{
+    if (!reads) return 1;
+    reads->layout_gen = bsig::next_layout_gen();
+    return 0;
+}
 
 int bsig_debug_set_resolve_min(long long n_tiles)
 {

@@ -172,7 +172,11 @@ struct bsig_reads {
     std::vector<uint32_t> fmtab;                  // host copy of dev.fmtab (BSIG_PACK_CODES entries, or empty)
     std::vector<uint32_t> ref_unit0, ref_units;
     std::vector<int32_t> ref_len;
+    // which layout this is: a number no other layout of the process has (next_layout_gen(), taken whenever the resident
+    // columns and indexes are (re)built or loaded).  A plan's cached tile windows are valid for exactly one layout.
+    uint64_t layout_gen = 0;
 };
+namespace bsig { uint64_t next_layout_gen(); }
 
 namespace bsig {
 struct BaiIndex;

@@ -1135,7 +1135,10 @@ def main():
                                        + ("RCCL grouped send/recv" if a.backend == "nccl" else "gloo through host memory, testing only")
                                        + ") + reassembly in rank 0's HBM, all inside the timed region") if world > 1
                                       else "one GPU: a step = the launch, nothing to gather",
-                       "launch": "one launch per step from the host loop",
+                       "launch": "one bsig_plan_run per step from the host loop; the tiles' index windows are looked up (k_resolve_tiles) in "
+                                 "a plan's first run and kept with the plan, which is immutable like the layout of the reads: the timed steps "
+                                 "read them back" if os.environ.get("BAMSIGNALS_CACHE_WINDOWS") != "0" else
+                                 "one bsig_plan_run per step from the host loop: k_resolve_tiles + the pileup launch in every step (BAMSIGNALS_CACHE_WINDOWS=0)",
                        "threads": w.params.threads or 64,
                        "tile_cells": w.params.tile_cells or "auto (widest range, at most 2048)"},
             "roofline": w.roofline(kernel_ms, traffic, traffic_src),

@@ -171,8 +171,11 @@ typedef struct {
     int64_t visits;            /* reads in the exact candidate windows of all tiles (V)         */
     int64_t visits_short;      /* ... of them in span classes 0-1 (span <= 4096: no end column) */
     int64_t streamed;          /* reads actually loaded (windows rounded to index buckets)      */
-    int64_t algorithmic_bytes; /* sum(bytes_per_visit*V) + 32*items + 8*items*classes + 4*cells
-                                * (+ (32 + 2*48)*items when the windows are looked up by a launch of their own) */
+    int64_t algorithmic_bytes; /* of one run of the resident plan: sum(bytes_per_visit*V) + 32*items + 4*cells
+                                * + 8*items*classes (the index entries; small launches look them up in the pileup kernel)
+                                * or + 48*items (large launches: the windows kept with the plan from its first run;
+                                * with BAMSIGNALS_CACHE_WINDOWS=0, looked up by a launch of their own in every run:
+                                * 8*items*classes + (32 + 2*48)*items) */
     int32_t bytes_per_visit_short;   /* 8  (pos + flag|mapq|span - 1), 12 with the tlen column  */
     int32_t bytes_per_visit_long;    /* 12 (pos + end + flag|mapq), 16 with the tlen column     */
     int64_t visits_packed;     /* ... of V in the packed class (not part of visits_short)       */

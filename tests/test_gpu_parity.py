@@ -317,6 +317,50 @@ def test_large_launches_look_their_windows_up_in_a_launch_of_their_own(ctx, synt
         knob(1, 0); knob(2, 0)
 
 
+def test_a_plans_windows_are_kept_after_its_first_run_and_die_with_the_layout(ctx, synth, monkeypatch):
+    """A large launch looks its tiles' windows up (k_resolve_tiles, bam_itr_queryi's counterpart, ref:
+    src/bamsignals.cpp:267) in the plan's FIRST run and keeps them: a plan and a layout of the reads are immutable, so the
+    windows are a function of the two.  Runs 1, 2 and 3 of one plan are identical to the oracle with the windows kept and
+    with BAMSIGNALS_CACHE_WINDOWS=0 (looked up in every run); results written into a second buffer do not depend on
+    what the first run left in the first; and a plan refuses to run once the reads have been laid out again -- its kept
+    windows, its heavy-tile slices and its filter table were read off the old layout."""
+    import ctypes
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, Reads, make_params
+    from bamsignals_amd.synth import synth_ranges
+    from oracle import oracle_c
+    gpu, orc, cols, _, _ = synth["pe"]
+    rg = synth_ranges(40_000, 900, cols["ref_len"], seed=4321, jitter=200)
+    for mode, kind, a in ((_lib.MODE_PROFILE, "pileup", dict(binsize=1, ss=True, shift=15)), (_lib.MODE_COVERAGE, "coverage", dict(mapqual=5))):
+        want, _ = (oracle_c.coverage_core if kind == "coverage" else oracle_c.pileup_core)(orc, rg, **a)
+        for keep in ("1", "0"):
+            monkeypatch.setenv("BAMSIGNALS_CACHE_WINDOWS", keep)
+            plan = Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(mode, **a))
+            st = plan.stats()
+            for run in range(3):
+                got = plan.run_host()
+                assert np.array_equal(got, want), (kind, keep, run)
+            # the step's algorithmic bytes say which form ran: kept windows are read back (48 B per tile), not looked up
+            per_tile = (st["algorithmic_bytes"] - 4 * st["cells"]) / st["n_items"]
+            plan.close()
+            if keep == "1":
+                kept_per_tile = per_tile
+            else:
+                assert per_tile > kept_per_tile, (kind, per_tile, kept_per_tile)
+    monkeypatch.delenv("BAMSIGNALS_CACHE_WINDOWS")
+    # a plan does not outlive the layout it was made on
+    small = Reads(ctx, cols["ref_len"], cols["ref_off"], cols["pos"], cols["flag"], cols["mapq"], cols["tlen"], end=cols["end"])
+    plan = Plan(ctx, small, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=1))
+    plan.run_host()
+    fn = _lib.load().bsig_debug_new_layout_gen
+    fn.argtypes = [ctypes.c_void_p]
+    assert fn(small._h) == 0
+    with pytest.raises(_lib.BsigError, match="laid out again"):
+        plan.run_host()
+    plan.close()
+    small.close()
+
+
 @pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
 def test_pileup_vs_oracle(ctx, synth, which, cases):
     from oracle import oracle_c
