@@ -93,6 +93,8 @@ struct BsigKParams {
     int32_t binsize;        // >= 1 (profile)
     uint32_t div_magic;     // exact n / binsize for 0 <= n < 2^31:
     int32_t div_shift;      //   __umulhi(n, div_magic) >> div_shift        (binsize >= 2)
+    uint32_t div_m15;       // ... and for 0 <= n < 2^15 (a range shorter than 32,768 bases) at the full rate of the
+    int32_t div_s15;        //   vector unit: (n * div_m15) >> div_s15, a 24-bit multiply (binsize 2..8192; else 0)
     int32_t ext;            // window extension on both sides (src/bamsignals.cpp:457,487)
     int32_t tile_cells;     // output cells per tile (sizes the dynamic LDS image)
     int32_t accumulate;     // 1: add the tile image into the result with integer atomics (slices of

@@ -194,44 +194,54 @@ struct SmallOne {
         const int lc = cell - c0;
         if ((unsigned)lc < (unsigned)nc) atomicAdd(&mine[lc * S + (SS ? anti : 0)], 1);
     }
-    // four packed reads at once, as ProfileOne::quad, with the bin of the range-oriented position by the exact magic
-    // multiply (the position must lie inside the range for it: that test cannot ride on the cell test here)
+    // four packed reads at once, as ProfileOne::quad, with the bin of the range-oriented position by an exact magic
+    // multiply (the position must lie inside the range for it: that test cannot ride on the cell test here).  Round 5:
+    // the count family's dword table (build_ctab: bit 0 reverse strand -- taken as a 24-bit factor --, bit 31
+    // rejected), no read-by-read "is it one of the window's" on an inner pass, and for ranges shorter than 32,768
+    // bases the bin by a 24-bit multiply at the vector unit's full rate instead of the quarter-rate v_mul_hi_u32:
+    // about 20 vector instructions a read where round 4 took 33.
     __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
                                          const uint8_t *__restrict__ ptab) const
     {
-        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
-        const bool tl_rule = (P.has_tlen_filter | P.midpoint) != 0;    // (uniform)
+        // (table bytes -> bit 0 reverse strand, bit 31 rejected.  The count family's dword table was tried here: the
+        // 1.5 KB more of LDS per workgroup cost a fifth of the launch, 0.162 -> 0.196 ms -- this kernel lives on how
+        // many workgroups a CU holds, not on its instructions: the same read body with 25 % fewer of them is no faster)
+        auto e = [](uint32_t x) { return ((x >> 1) & 1u) | (x << 31); };
+        const uint32_t b0 = e(ptab[w.x >> 23]), b1 = e(ptab[w.y >> 23]), b2 = e(ptab[w.z >> 23]), b3 = e(ptab[w.w >> 23]);
+        // (uniform, like everything these branches ask.  Three forms only -- the orientation of the range is a sign and
+        // a strand bit, not a fourth template argument: the kernel inlines this at four places, and 32 copies of the
+        // read body were 35 KB of code that ran a third SLOWER than round 4's 16)
+        const bool tl_rule = (P.has_tlen_filter | P.midpoint) != 0;
+        const bool narrow = len < 32768 && P.div_s15 != 0;
         const int A = base - loc + P.shift;
-        if (neg_range) {
-            if (tl_rule) four<true, true>(w, t, b0, b1, b2, b3, dj, nj, base, len - 1 - A);
-            else four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, len - 1 - A);
-        } else {
-            if (tl_rule) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, A);
-            else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, A);
-        }
+        const int K = neg_range ? len - 1 - A : A, sgn = neg_range ? -1 : 1;
+        if (tl_rule) four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn);
+        else if (narrow) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn);
+        else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn);
     }
-    template <bool REV, bool TL>
+    template <bool TL, bool NARROW>
     __device__ __forceinline__ void four(const uint4 &w, const int4 &t, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj,
-                                         uint32_t nj, int base, int K) const
+                                         uint32_t nj, int base, int K, int sgn) const
     {
-        const uint32_t cd = (uint32_t)(-2 * P.shift);
-        const bool binned = P.binsize != 1;                            // (uniform)
+        const int cd = -2 * P.shift;                                   // (binsize > 1 here: bins of one base run k_profile)
+        const uint32_t flip = sgn < 0 ? 1u : 0u;
         auto rd = [&](uint32_t x, uint32_t b, int tl, uint32_t k) {
-            const uint32_t d = (x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u);
-            const uint32_t sp = (x >> BSIG_PACK_POS_BITS) & 0xFFu;
-            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31);
-            uint32_t rj = (uint32_t)((int32_t)(b << 31) >> 31), h = 0;
+            const int d = (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
+            int spcd = (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu) + cd, h = 0;
+            uint32_t rj = b & 0x80000000u;
             if (TL) {
                 const int a = tl < 0 ? -tl : tl;
-                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? 0xFFFFFFFFu : 0u;
-                if (P.midpoint) h = (uint32_t)(a >> 1);
+                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? 0x80000000u : 0u;
+                if (P.midpoint) { h = a >> 1; spcd -= 2 * h; }
             }
-            const uint32_t fwd = d + h + (nm & (sp + cd - 2u * h));
-            const uint32_t rel = (REV ? (uint32_t)K - fwd : (uint32_t)K + fwd) | rj;      // position in range orientation
-            const uint32_t cell = binned ? __umulhi(rel, P.div_magic) >> P.div_shift : rel;
+            // (|spcd| and fwd < 2^23: a window that takes this path is narrower than 32,768 bases, and so are shift and h)
+            // (the strand bit as a mask -- v_bfe_i32 -- : as a factor the compiler made a 64-bit multiply-add of it here)
+            const int fwd = (__builtin_amdgcn_sbfe((int)b, 0, 1) & spcd) + d + h;
+            const uint32_t rel = (uint32_t)(__mul24(fwd, sgn) + K) | rj;       // position in range orientation
+            const uint32_t cell = NARROW ? __umul24(rel, P.div_m15) >> P.div_s15 : __umulhi(rel, P.div_magic) >> P.div_shift;
             const uint32_t lc = cell - (uint32_t)c0;
             const bool ok = (dj + k < nj) & (rel < (uint32_t)len) & (lc < (uint32_t)nc);
-            const uint32_t idx = SS ? 2u * lc + ((REV ? ~nm : nm) & 1u) : lc;
+            const uint32_t idx = SS ? 2u * lc + ((b ^ flip) & 1u) : lc;
             if (ok) atomicAdd(&mine[idx], 1);
         };
         rd(w.x, b0, t.x, 0u);
@@ -338,17 +348,21 @@ struct CountOne {
     {
         count_one(P, glo, gn, p, e, neg, rej, tl, valid, acc);
     }
-    // four reads of the packed class (words w, table bytes from ptab; read k is one of the window's iff dj + k < nj,
-    // unsigned).  Without a template-length rule the 5' end relative to the interval comes straight out of the word:
-    // pos - glo + shift = d + cp and end - glo - shift = d + span + cm with d = (word - base) & mask.
+    // four reads of the packed class (words w; read k is one of the window's iff dj + k < nj, unsigned -- not asked
+    // at all on an INNER pass, one that lies inside the window with all its reads).  The count family has a table of
+    // its own, one DWORD per code (build_ctab: bit 0 reverse strand, bit 31 rejected), which the arithmetic takes as
+    // it comes: as a 24-bit factor it is the strand bit, and-ed with the sign bit it is the rejection.  Without a
+    // template-length rule the 5' end relative to the interval comes straight out of the word:
+    // pos - glo + shift = d + cp and end - glo - shift = d + span + cp + cd with d = (word - base) & mask:
+    // rel = d + cp + strand * (span + cd), 13 vector instructions a read (11 on an inner pass; 19 in round 4).
     __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
-                                         const uint8_t *__restrict__ ptab) const
+                                         const uint32_t *__restrict__ ctab, bool inner) const
     {
-        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
+        const uint32_t b0 = ctab[w.x >> 23], b1 = ctab[w.y >> 23], b2 = ctab[w.z >> 23], b3 = ctab[w.w >> 23];
         if (P.has_tlen_filter | P.midpoint) {                  // (uniform)
             auto dec = [&](uint32_t x, uint32_t b, int tl, bool valid) {
                 const int pos = base + (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
-                count_one(P, glo, gn, pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 2u) != 0u, (b & 1u) != 0u, tl, valid, acc);
+                count_one(P, glo, gn, pos, pos + (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu), (b & 1u) != 0u, (b >> 31) != 0u, tl, valid, acc);
             };
             dec(w.x, b0, t.x, dj < nj);
             dec(w.y, b1, t.y, dj + 1u < nj);
@@ -356,21 +370,24 @@ struct CountOne {
             dec(w.w, b3, t.w, dj + 3u < nj);
             return;
         }
-        // (plain arithmetic, no select: the compiler turns `neg ? a : b` into a diamond of exec masks here.  nm = all
-        // ones for a reverse-strand read, rj = all ones for a rejected one -- which pushes rel out of every interval)
-        const uint32_t cp = (uint32_t)(base - glo + P.shift), cd = (uint32_t)(-2 * P.shift);
-        auto rd = [&](uint32_t x, uint32_t b, uint32_t k) {
-            const uint32_t d = (x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u);
-            const uint32_t sp = (x >> BSIG_PACK_POS_BITS) & 0xFFu;
-            const uint32_t nm = (uint32_t)((int32_t)(b << 30) >> 31), rj = (uint32_t)((int32_t)(b << 31) >> 31);
-            const uint32_t rel = (d + cp + (nm & (sp + cd))) | rj;
-            const bool ok = (dj + k < nj) & (rel < (uint32_t)gn);
-            acc += ok ? ((nm & 0x10000u) | 1u) : 0u;
+        const int cp = base - glo + P.shift, cd = -2 * P.shift;
+        auto rel_of = [&](uint32_t x, uint32_t b) {
+            const int d = (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
+            const int spcd = (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu) + cd;
+            // (|spcd| < 2^23: a window that takes this path is narrower than 32,768 bases, and so is the shift)
+            return ((uint32_t)(__mul24((int)b, spcd) + d + cp)) | (b & 0x80000000u);
         };
-        rd(w.x, b0, 0u);
-        rd(w.y, b1, 1u);
-        rd(w.z, b2, 2u);
-        rd(w.w, b3, 3u);
+        if (inner) {
+            acc += rel_of(w.x, b0) < (uint32_t)gn ? (b0 << 16 | 1u) : 0u;
+            acc += rel_of(w.y, b1) < (uint32_t)gn ? (b1 << 16 | 1u) : 0u;
+            acc += rel_of(w.z, b2) < (uint32_t)gn ? (b2 << 16 | 1u) : 0u;
+            acc += rel_of(w.w, b3) < (uint32_t)gn ? (b3 << 16 | 1u) : 0u;
+        } else {
+            acc += ((dj < nj) & (rel_of(w.x, b0) < (uint32_t)gn)) ? (b0 << 16 | 1u) : 0u;
+            acc += ((dj + 1u < nj) & (rel_of(w.y, b1) < (uint32_t)gn)) ? (b1 << 16 | 1u) : 0u;
+            acc += ((dj + 2u < nj) & (rel_of(w.z, b2) < (uint32_t)gn)) ? (b2 << 16 | 1u) : 0u;
+            acc += ((dj + 3u < nj) & (rel_of(w.w, b3) < (uint32_t)gn)) ? (b3 << 16 | 1u) : 0u;
+        }
     }
 };
 
@@ -392,6 +409,17 @@ __device__ __forceinline__ void build_ptab(uint8_t *ptab, const BsigReadsDev &R,
     const uint4 *src = reinterpret_cast<const uint4 *>(P.ptab);
     uint4 *dst = reinterpret_cast<uint4 *>(ptab);
     for (int v = tid; v < BSIG_PACK_CODES / 16; v += NT) dst[v] = src[v];
+}
+// ... and the count family's form of it: one dword per code, bit 0 reverse strand, bit 31 rejected (CountOne::quad)
+template <int NT>
+__device__ __forceinline__ void build_ctab(uint32_t *ctab, const BsigKParams &P, int tid)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptab);
+    for (int v = tid; v < BSIG_PACK_CODES / 4; v += NT) {
+        const uint32_t b = src[v];
+        auto e = [](uint32_t x) { return ((x >> 1) & 1u) | (x << 31); };
+        reinterpret_cast<uint4 *>(ctab)[v] = make_uint4(e(b & 0xFFu), e((b >> 8) & 0xFFu), e((b >> 16) & 0xFFu), e(b >> 24));
+    }
 }
 __global__ __launch_bounds__(128) void k_make_ptab(const BsigReadsDev R, const BsigKParams P, uint8_t *__restrict__ out)
 {
@@ -557,12 +585,13 @@ struct has_quad : std::false_type {};
 template <typename F>
 struct has_quad<F, std::void_t<decltype(&std::remove_reference_t<F>::quad)>> : std::true_type {};
 
-template <typename F>
+template <typename Tab, typename F>
 __device__ __forceinline__ void four_packed(const uint4 &w, const int4 &t, uint32_t j, uint32_t j_lo, uint32_t nj, int base,
-                                            const uint8_t *__restrict__ ptab, F &&one)
+                                            const Tab *__restrict__ ptab, F &&one, bool inner = false)
 {
     if constexpr (has_quad<F>::value) {
-        one.quad(w, t, j - j_lo, nj, base, ptab);
+        if constexpr (std::is_same_v<Tab, uint32_t>) one.quad(w, t, j - j_lo, nj, base, ptab, inner);      // (the count family)
+        else one.quad(w, t, j - j_lo, nj, base, ptab);
         return;
     }
     // the four table bytes are requested before the first one is used
@@ -584,10 +613,10 @@ __device__ __forceinline__ void four_packed(const uint4 &w, const int4 &t, uint3
 // (kPre * 4 * NT reads) of the packed class, where nearly all reads live, and the first pass of classes 0
 // and 1.  Longer windows and the two long-span classes continue in plain loops.
 // (The packed class's later chunks -- windows wider than kPackChunk bases -- are walked by packed_later_chunks.)
-template <int NT, int kPre = 2, typename F>
+template <int NT, int kPre = 2, typename Tab, typename F>
 __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigKParams &P,
                                               const uint2 (&win)[BSIG_MAX_CLASSES], int pbase,
-                                              const uint8_t *__restrict__ ptab, int tid, F &&one)
+                                              const Tab *__restrict__ ptab, int tid, F &&one)
 {
     uint4 w0[kPre];
     int4 t0[kPre];
@@ -626,13 +655,16 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
     // after j_hi: only reads in [j_lo, j_hi) count -> `dj < nj` with unsigned wrap-around.
     {   // ---- packed class (span <= 256, a frequent flag/mapq pair): one word per read -------------------
         const uint32_t j_lo = win[BSIG_CLASS_PACKED].x, j_hi = win[BSIG_CLASS_PACKED].y, nj = j_hi - j_lo;
+        // a pass whose 4 * NT reads all belong to the window (uniform): nobody has to ask read by read
+        const uint32_t jp0 = j_lo & ~3u;
+        auto inner_pass = [&](uint32_t first) { return first >= j_lo && first + 4u * NT <= j_hi; };
 #pragma unroll
         for (int k = 0; k < kPre; ++k) {
             const uint32_t j = jbp + 4u * NT * k;
-            if (j < j_hi) four_packed(w0[k], t0[k], j, j_lo, nj, pbase, ptab, one);
+            if (j < j_hi) four_packed(w0[k], t0[k], j, j_lo, nj, pbase, ptab, one, inner_pass(jp0 + 4u * NT * k));
         }
         // deeper windows: two passes per trip, both requested before either is consumed
-        for (uint32_t j = jbp + 4u * NT * kPre; j < j_hi; j += 8u * NT) {
+        for (uint32_t j = jbp + 4u * NT * kPre, jf = jp0 + 4u * NT * kPre; j < j_hi; j += 8u * NT, jf += 8u * NT) {
             const uint32_t j2 = j + 4u * NT;
             const uint4 wa = *reinterpret_cast<const uint4 *>(CP.fm + j);
             int4 xa = make_int4(0, 0, 0, 0), xb = make_int4(0, 0, 0, 0);
@@ -642,8 +674,8 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
                 wb = *reinterpret_cast<const uint4 *>(CP.fm + j2);
                 if (P.use_tlen) xb = *reinterpret_cast<const int4 *>(CP.tlen + j2);
             }
-            four_packed(wa, xa, j, j_lo, nj, pbase, ptab, one);
-            if (j2 < j_hi) four_packed(wb, xb, j2, j_lo, nj, pbase, ptab, one);
+            four_packed(wa, xa, j, j_lo, nj, pbase, ptab, one, inner_pass(jf));
+            if (j2 < j_hi) four_packed(wb, xb, j2, j_lo, nj, pbase, ptab, one, inner_pass(jf + 4u * NT));
         }
     }
     {   // ---- class 0 (span <= 256, a rare pair): no end column, end = pos + (fm >> 24) ------------------
@@ -731,9 +763,9 @@ __device__ __forceinline__ bool packed_window(const BsigClassCols &C, const Bsig
 // The packed class's chunks behind the first (a window wider than kPackChunk bases: a shift or a template
 // length filter of tens of kilobases -- rare, so plain loops): every chunk is looked up in the index by
 // itself and clipped to `clip` (the read range of a slice of a heavy tile; everything otherwise).
-template <int NT, typename F>
+template <int NT, typename Tab, typename F>
 __device__ __forceinline__ void packed_later_chunks(const BsigReadsDev &R, const BsigKParams &P, int mode, const BsigWorkItem &w,
-                                                    int n_chunks, uint2 clip, const uint8_t *__restrict__ ptab, int tid, F &&one)
+                                                    int n_chunks, uint2 clip, const Tab *__restrict__ ptab, int tid, F &&one)
 {
     const BsigClassCols &C = R.cls[BSIG_CLASS_PACKED];
     int64_t tlo, thi, rlo, rhi;
@@ -1001,12 +1033,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, 8)
 // bank.  Here the lanes add into replicas of the tile image (up to 32, odd stride:
 // the same cell of different replicas lies in different banks); the replicas are summed at the end.
 constexpr int kSmallCells = 256;     // at most this many values (cells * S) per tile
-// replicas of the image: as many as keep it near 8 KiB (more LDS would cost resident workgroups)
+// replicas of the image (lanes add into replica `tid & (r - 1)`, the replicas are summed at the end): FEW.  Rounds 2-4
+// kept up to 32 of them (8 KiB) so that no two lanes of a wave would meet on a cell; measured in round 5 (100,000 x 2 kb
+// ranges, 1e8 reads, one box; 32 / 4 / 2 / 1 replicas): binsize 200 with strands (20 values) 0.157 / 0.112 / 0.112 / 0.120
+// ms, binsize 50 with strands (80 values) 0.167 / 0.117 / 0.114 / 0.107, binsize 16 (125 values) 0.174 / 0.116 / 0.113 /
+// 0.107.  Clearing and summing r x values dwords per tile and the LDS they take cost more than lanes taking turns on a
+// cell: four replicas for images of up to 32 values, two up to 64, one beyond.
 __host__ __device__ inline int small_replicas(int stride)
 {
-    int r = 32;
-    while (r > 2 && r * stride * 4 > 8448) r >>= 1;
-    return r;
+    return stride <= 32 ? 4 : stride <= 64 ? 2 : 1;
 }
 template <int NT, bool SS>
 __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
@@ -1032,7 +1067,10 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
     int32_t *mine = lds + (tid & (n_rep - 1)) * stride;
 
     const SmallOne<SS> one{P, mine, w.loc, w.len, w.c0, w.nc, neg_range};
-    for_each_read<NT>(R, P, win, pk.base, ptab, tid, one);
+#ifndef BSIG_SMALL_PRE
+#define BSIG_SMALL_PRE 4
+#endif
+    for_each_read<NT, BSIG_SMALL_PRE>(R, P, win, pk.base, ptab, tid, one);
     if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_PROFILE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();
 
@@ -1055,14 +1093,14 @@ __global__ __launch_bounds__(NT) void k_count(const BsigWorkItem *__restrict__ i
                                               const BsigReadsDev R, const BsigKParams P)
 {
     __shared__ int32_t wsum[2 * (NT / kWave)];
-    __shared__ __attribute__((aligned(16))) uint8_t ptab[BSIG_PACK_CODES];
+    __shared__ __attribute__((aligned(16))) uint32_t ptab[BSIG_PACK_CODES];      // (the count family's table: build_ctab)
     const int tid = threadIdx.x;
     const uint32_t tile = tile_of_block(blockIdx.x, n_tiles);
     const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES], clip;
     PackedWin pk;
     load_windows(R, P, BSIG_MODE_COUNT, w, items, windows, win, tile, pk, clip);
-    build_ptab<NT>(ptab, R, P, tid);
+    build_ctab<NT>(ptab, P, tid);
     block_sync<NT>();
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
     const int glo = w.loc + w.c0;           // sub-interval of the range, genomic coordinates
@@ -1117,7 +1155,7 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
                                                        const BsigReadsDev R, const BsigKParams P)
 {
     __shared__ uint32_t stage[T][16];      // per tile: 5 windows, first base, bases, flags, packed base and chunks
-    __shared__ __attribute__((aligned(16))) uint8_t ptab[BSIG_PACK_CODES];
+    __shared__ __attribute__((aligned(16))) uint32_t ptab[BSIG_PACK_CODES];      // (the count family's table: build_ctab)
     const int lane = threadIdx.x;
     const uint32_t n_groups = (n_tiles + T - 1) / T;
     const uint32_t first = tile_of_block(blockIdx.x, n_groups) * T;
@@ -1140,7 +1178,7 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
         out_off = w.out_off;
         atomic = (w.units_strand & BSIG_ITEM_ATOMIC) != 0u;
     }
-    build_ptab<kWave>(ptab, R, P, lane);
+    build_ctab<kWave>(ptab, P, lane);
     block_sync<kWave>();
     int my_sense = 0, my_anti = 0;
 #pragma unroll 1

@@ -1374,6 +1374,15 @@ int bsig_plan_create(bsig_ctx *ctx, const bsig_reads *reads, int64_t n, const in
     K.ext = (int32_t)ext;
     K.tile_cells = P->tile_cells;
     bsig::magic_u31(K.binsize, &K.div_magic, &K.div_shift);
+    K.div_m15 = 0; K.div_s15 = 0;
+    if (K.binsize >= 2 && K.binsize <= 8192) {
+        // s = 15 + ceil(log2 b), m = ceil(2^s / b): n * m / 2^s = n / b + n * e / (b * 2^s) with e < b, and the second
+        // term stays below 2^-ceil(log2 b) <= 1 / b for n < 2^15, so the floor is exact; n * m < 2^32, m < 2^17
+        int L = 0;
+        while ((1 << L) < K.binsize) ++L;
+        K.div_s15 = 15 + L;
+        K.div_m15 = (uint32_t)((((uint64_t)1 << K.div_s15) + (uint64_t)K.binsize - 1) / (uint64_t)K.binsize);
+    }
 
     const int32_t lay_binsize = mode == BSIG_MODE_COUNT ? -1 : K.binsize;
     P->off.resize(n + 1);
