@@ -17,7 +17,7 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU): the SAME worklo
 ("scaling": "strong").  Ranges are independent units (each owns its output, ref: src/bamsignals.cpp:164,181,186):
 the (rid, loc)-sorted ranges (ref: :222-226,246) are dealt round-robin to the ranks, every rank holds the reads,
 and a step is the whole north-star path -- the kernels on the rank's shard, the gather of the shards to rank 0
-over RCCL (grouped send / recv: every peer sends straight to the root over its own xGMI link), and the
+over RCCL (torch.distributed.gather: grouped send / recv, every peer straight to the root over its own xGMI link), and the
 reassembly into the caller's range order in rank 0's HBM (bsig_segmap_run).  All three are inside the timed
 region; `value` = the whole range set's bases x K / the slowest rank's time.  At N = 1 there is nothing to gather
 and the step is the launch alone.  The result assembled on rank 0 is compared with the oracle, every range of
@@ -483,7 +483,7 @@ class Workload:
     and, on every rank, a second set of plans holds the whole batch (rank 0: what the assembled result must equal;
     all ranks: the informational replica run)."""
 
-    def __init__(self, a, name, rank, world, local, stream, n_reads=0, n_ranges=0, width=0, nb=0, cols=None, t_gen=0.0):
+    def __init__(self, a, name, rank, world, local, stream, n_reads=0, n_ranges=0, width=0, nb=0, cols=None, t_gen=0.0, gathered=None):
         import torch
 
         from bamsignals_amd import _lib
@@ -492,6 +492,9 @@ class Workload:
         self.name, self.cfg = name, CONFIGS[name]
         cfg = self.cfg
         self.rank, self.world = rank, world
+        # is a step "shard -> gather to rank 0 -> reassembly"?  With more than one rank always; with one rank only when
+        # asked (--force-dist: the same code path over a one-rank communicator, for a box with one GPU)
+        self.gathered = (world > 1) if gathered is None else bool(gathered)
         self.n_reads = n_reads or cfg["reads"]
         self.n_ranges = n_ranges or cfg["ranges"]            # of the WHOLE job, whatever the number of ranks
         self.width = width or cfg["width"]
@@ -531,13 +534,13 @@ class Workload:
             self.step_bases = [int(g["len"].astype(np.int64).sum()) for g in self.full]      # of the whole job
             # the shards travel as equal-sized messages (the largest shard of any batch, in cells)
             self.shard_offs = [[layout(g["len"][r::world], cfg["args"].get("binsize", 1), ss) for r in range(world)] for g in self.full] \
-                if world > 1 else None
-            self.pad = max(4, max(int(o[-1]) for offs in self.shard_offs for o in offs)) if world > 1 else 0
+                if self.gathered else None
+            self.pad = max(4, max(int(o[-1]) for offs in self.shard_offs for o in offs)) if self.gathered else 0
             self.outs = [torch.empty(max(p.cells, 4, self.pad), dtype=torch.int32, device="cuda") for p in self.plans]
             for b in range(nb):                      # every result buffer is produced at least once
                 self.plans[b].run_device(self.outs[b].data_ptr())
             self.full_plans, self.full_outs = self.plans, self.outs
-            if world > 1:
+            if self.gathered:
                 self.full_plans = [Plan(self.ctx, self.reads, g["rid"], g["loc"], g["len"], g["strand"], self.params) for g in self.full]
                 self.full_outs = [torch.empty(max(p.cells, 4), dtype=torch.int32, device="cuda") for p in self.full_plans]
         self.final = self.outs                        # where a step's whole result ends up (N > 1: setup_gather)
@@ -557,7 +560,7 @@ class Workload:
         cfg, world = self.cfg, self.world
         ss = bool(cfg["args"].get("ss", False))
         n = len(self.full[0]["rid"])
-        self.bufs = [None] + [torch.empty(self.pad, dtype=torch.int32, device="cuda") for _ in range(1, world)]
+        self.bufs = [torch.empty(self.pad, dtype=torch.int32, device="cuda") for _ in range(world)]
         self.final = [torch.zeros(max(p.cells, 4), dtype=torch.int32, device="cuda") for p in self.full_plans]
         self.maps = []
         for b in range(self.nb):
@@ -573,24 +576,15 @@ class Workload:
         import torch
         dist, b = self.dist, q % self.nb
         root = self.rank == 0
-        works = []
-        if self.backend == "nccl" and root:
-            # posted first: the receives depend on nothing this step computes (RCCL's stream waits for what is on
-            # this stream now, the previous step's reads of these buffers), so the peers' shards arrive while
-            # the root runs its own shard
-            works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, self.bufs[r], r) for r in range(1, self.world)])
         if ev:
             ev[0].record()
         self.plans[b].run_device(self.outs[b].data_ptr())
         if ev:
             ev[1].record()
         if self.backend == "nccl":
-            if not root:
-                works = dist.batch_isend_irecv([dist.P2POp(dist.isend, self.outs[b][:self.pad], 0)])
-            else:
-                self.maps[b][0].run(self.outs[b].data_ptr(), self.final[b].data_ptr())      # its own shard, meanwhile
-            for wk in works:
-                wk.wait()                                   # (the stream waits, not the host)
+            # torch.distributed.gather over RCCL: grouped ncclSend / ncclRecv, every peer straight to the root over its
+            # own link (the root's own shard is a copy on the device)
+            dist.gather(self.outs[b][:self.pad], self.bufs if root else None, dst=0)
         else:
             # gloo (the code path on a box with fewer GPUs than ranks): through host memory
             torch.cuda.synchronize()
@@ -598,19 +592,18 @@ class Workload:
             got = [torch.empty_like(mine) for _ in range(self.world)] if root else None
             dist.gather(mine, got, dst=0)
             if root:
-                self.maps[b][0].run(self.outs[b].data_ptr(), self.final[b].data_ptr())
-                for r in range(1, self.world):
+                for r in range(self.world):
                     self.bufs[r].copy_(got[r])
         if ev:
             ev[2].record()
         if root:
-            for r in range(1, self.world):
+            for r in range(self.world):
                 self.maps[b][r].run(self.bufs[r].data_ptr(), self.final[b].data_ptr())
         if ev:
             ev[3].record()
 
     def run_steps(self, k, full=False):
-        if self.world > 1 and not full:
+        if self.gathered and not full:
             for q in range(k):
                 self.strong_step(q)
             return
@@ -681,7 +674,7 @@ class Workload:
             refs_seen.update(np.unique(g["rid"]).tolist())
         return orc, dict(ranges_per_batch=len(self.full[0]["rid"]), batches=self.nb, cells=cells,
                          how="every range of every batch, cell by cell, against oracle/bamsignals_oracle.c"
-                             + (f" (the result assembled on rank 0 from the {self.world} ranks' shards)" if self.world > 1 else ""),
+                             + (f" (the result assembled on rank 0 from the {self.world} ranks' shards)" if self.gathered else ""),
                          references_covered=len(refs_seen), references=len(self.cfg["ref_len"]))
 
     def roofline(self, kernel_ms, traffic=None, traffic_src=None):
@@ -1005,11 +998,13 @@ def main():
     cfg = CONFIGS[a.config]
     stream = torch.cuda.Stream()
     shared = SharedReads(a.config, a.reads or cfg["reads"], cfg["ref_len"], a.seed, cfg["paired"], rank, world, host_barrier)
-    w = Workload(a, a.config, rank, world, local, stream, a.reads, a.ranges, a.width, a.batches, cols=shared.cols, t_gen=shared.t_gen)
+    gathered = world > 1 or a.force_dist
+    w = Workload(a, a.config, rank, world, local, stream, a.reads, a.ranges, a.width, a.batches, cols=shared.cols, t_gen=shared.t_gen,
+                 gathered=gathered)
     shared.release(host_barrier)
     if rank != 0:
         w.cols = None                    # (only rank 0 checks against the oracle: the mapped columns can go)
-    if world > 1:
+    if gathered:
         w.setup_gather(dist, a.backend)
         with torch.cuda.stream(stream):
             for q in range(w.nb):                # every batch's whole result is assembled at least once (all ranks take part)
@@ -1027,7 +1022,7 @@ def main():
     # ---- N > 1, informational: where a step's time goes (events between its parts, a second run of the same steps),
     # and every rank running the WHOLE range set alone with nothing exchanged (N replicas; rounds 1-4's `value`)
     phases = replicas = None
-    if world > 1:
+    if gathered:
         ksteps = min(a.steps, 20)
         ph = w.phases(ksteps, stream, barrier)
         allph = [None] * world
@@ -1037,13 +1032,12 @@ def main():
         t = torch.tensor([el_r], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
-            phases = dict(steps=ksteps, rank0_ms=dict(kernel=float(ph[0]), gather_wait=float(ph[1]), place_peers=float(ph[2])),
+            phases = dict(steps=ksteps, rank0_ms=dict(kernel=float(ph[0]), gather=float(ph[1]), place=float(ph[2])),
                           kernel_ms_by_rank=[p[0] for p in allph],
                           gather_bytes_into_rank0=w.gather_bytes[0],
                           gather_GBps=(w.gather_bytes[0] / (float(ph[1]) * 1e-3) / 1e9) if ph[1] > 0 else None,
-                          note="HIP events between the parts of a step, on a second run of the same steps; rank 0's receives are "
-                               "posted before its own launch, so gather_wait is what is left of the transfer after the root's own "
-                               "shard and its placement; place_peers = bsig_segmap_run over the peers' shards")
+                          note="HIP events between the parts of a step, on a second run of the same steps: the launches on the "
+                               "rank's shard, torch.distributed.gather to rank 0, bsig_segmap_run over every rank's shard")
             replicas = dict(value=sum(w.step_bases[q % nb] for q in range(ksteps)) * world / float(t.item()) / 1e6, unit="Mbases/s",
                             ms_per_step=float(t.item()) / ksteps * 1e3, steps=ksteps, kernel_ms_rank0=kms_r,
                             what=f"every one of the {world} ranks runs the WHOLE range set by itself, nothing exchanged: {world} "
@@ -1078,7 +1072,7 @@ def main():
         ctx2.close()
 
     # ---- correctness of what was just timed, then the CPU baseline (rank 0) ----------------------
-    got = w.outs[0][:plan.cells].cpu().numpy() if world == 1 else None
+    got = w.outs[0][:plan.cells].cpu().numpy() if not gathered else None
     parity = cpu = e2e = None
     bases = w.step_bases[0]
     # (the oracle is the checker and the CPU baseline: loaded on rank 0 only, after the timed region)
@@ -1133,7 +1127,7 @@ def main():
                        "parallelism": (f"fixed total size: sorted ranges round-robin over {world} GPUs, reads replicated; a step = "
                                        f"kernels on the shard + gather to rank 0 ({a.backend}: "
                                        + ("RCCL grouped send/recv" if a.backend == "nccl" else "gloo through host memory, testing only")
-                                       + ") + reassembly in rank 0's HBM, all inside the timed region") if world > 1
+                                       + ") + reassembly in rank 0's HBM, all inside the timed region") if gathered
                                       else "one GPU: a step = the launch, nothing to gather",
                        "launch": "one bsig_plan_run per step from the host loop; the tiles' index windows are looked up (k_resolve_tiles) in "
                                  "a plan's first run and kept with the plan, which is immutable like the layout of the reads: the timed steps "

@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r03}
 shift || true
-CASES=${*:-ns c2 c3 c4 c5 count decode decodereal}
+CASES=${*:-ns c2 c3 c4 c5 count bins decode decodereal}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -30,6 +30,7 @@ for c in $CASES; do
     c3)    run_case c3 python3 $R/scripts/profile_case.py C3 || exit 1 ;;
     c4)    run_case c4 python3 $R/scripts/profile_case.py C4 || exit 1 ;;
     count) run_case count python3 $R/scripts/profile_case.py count || exit 1 ;;
+    bins)  run_case bins python3 $R/scripts/profile_case.py bins || exit 1 ;;
     decode)
         # the device-side decode kernels (whole file + index-driven) on the 5e7-read BAM
         timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decode_trace" -- python3 $R/scripts/decode_device_time.py > "$OUT/${TAG}_decode_trace.log" 2>&1 || exit 1

@@ -21,6 +21,7 @@ CASES = {
     "c3": ("k_coverage<64", "python3 scripts/profile_case.py C3"),
     "c4": ("k_profile<64, true", "python3 scripts/profile_case.py C4"),
     "count": ("k_count", "python3 scripts/profile_case.py count"),
+    "bins": ("k_profile_small", "python3 scripts/profile_case.py bins"),
 }
 
 
