@@ -54,8 +54,6 @@ namespace {
 
 constexpr int kMaxRecPerSeg = 1824;          // a record is >= 36 bytes, a block <= 65536
 static_assert(kMaxRecPerSeg % 4 == 0, "k_bam_walk stores four 16-bit offsets at a time");
-constexpr int kWalkWin = 256;                // bytes of its block a lane of k_bam_walk takes into LDS per trip to memory
-constexpr int kWalkStride = kWalkWin + 4;    // (an odd number of dwords from lane to lane: the same offset in different banks)
 constexpr uint32_t kFlagBad = 1u;            // malformed / truncated / too many records
 constexpr uint32_t kFlagUnsorted = 2u;
 constexpr uint32_t kFlagIncomplete = 8u;     // the record at `end` runs past this chunk of the stream
@@ -156,56 +154,6 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t *__restrict__ str
     uint32_t np = 0, nu = 0, flags = 0;
     uint64_t pack = 0;
     int32_t frid = -1, fpos = -1, prid = -1, ppos = -1;
-    // One record = one link of the chain = one trip to memory (1.5-3 us on a busy chip; 1,260 bare records per block:
-    // 1.7 ms a launch, 14 ms of a north-star decode in round 4).  The lane now takes kWalkWin bytes of its block into a
-    // window of its own in LDS with loads that are all in flight together, and follows the links INSIDE the window
-    // (an LDS read each): six bare records per trip instead of one; a record whose fixed part is cut off by the window's
-    // end starts the next window.  The lanes of a launch are few (one per block: three or four waves per CU), so the
-    // 16.6 KB a wave takes are there.
-    __shared__ __attribute__((aligned(16))) uint8_t win_lds[64 * kWalkStride];
-    uint8_t *win = win_lds + threadIdx.x * kWalkStride;
-    while (o < limit && o + kWalkWin <= total) {
-        const uint64_t wb = o;
-        {
-            uint4 t[kWalkWin / 16];
-#pragma unroll
-            for (int k = 0; k < kWalkWin / 16; ++k) __builtin_memcpy(&t[k], stream + wb + 16 * k, 16);
-#pragma unroll
-            for (int k = 0; k < kWalkWin / 16; ++k) __builtin_memcpy(win + 16 * k, &t[k], 16);
-        }
-        bool stop = false;
-        while (o < limit && o + 20 <= wb + kWalkWin) {
-            const uint8_t *q = win + (o - wb);
-            uint32_t h[4];
-            __builtin_memcpy(h, q, 16);
-            uint32_t h4;
-            __builtin_memcpy(&h4, q + 16, 4);
-            const int32_t bs = (int32_t)h[0];
-            if (bs < 32) { flags |= kFlagBad; stop = true; break; }
-            const uint64_t next = o + 4 + (uint64_t)bs;
-            if (next > total) { flags |= is_last ? kFlagBad : kFlagIncomplete; stop = true; break; }
-            const int32_t rid = (int32_t)h[1];
-            if (rid < 0) { ++nu; o = next; continue; }                   // unplaced: skipped
-            if (rid >= n_ref) { flags |= kFlagBad; stop = true; break; }
-            const int32_t pos = (int32_t)h[2];
-            const uint32_t l_name = h[3] & 0xFFu;
-            const uint32_t n_cig = h4 & 0xFFFFu;
-            if (36 + (uint64_t)l_name + 4 * (uint64_t)n_cig > 4 + (uint64_t)bs) { flags |= kFlagBad; stop = true; break; }
-            if (np == 0) { frid = rid; fpos = pos; }
-            else if (rid < prid || (rid == prid && pos < ppos)) flags |= kFlagUnsorted;
-            if (np >= (uint32_t)kMaxRecPerSeg) { flags |= kFlagBad; stop = true; break; }
-            pack |= (uint64_t)(uint16_t)(o - base) << (16u * (np & 3u));
-            if ((np & 3u) == 3u) {
-                __builtin_memcpy(mine + (np - 3u), &pack, 8);
-                pack = 0;
-            }
-            ++np;
-            prid = rid; ppos = pos;
-            o = next;
-        }
-        if (stop) { limit = o; break; }            // (the record-by-record loop below must not go on either)
-    }
-    // ... and record by record where a window would pass the end of the view
     while (o < limit) {
         const uint32_t cut = is_last ? kFlagBad : kFlagIncomplete;     // the record is cut off by the view
         if (o + 36 > total) { flags |= cut; break; }

@@ -642,208 +642,233 @@ BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, Lane
     const SlotsMem lit_offs{reinterpret_cast<uint16_t *>(T.dfast)}, lit_next{reinterpret_cast<uint16_t *>(T.dfast) + 16};
     DSyms ds;
     ds.clear();
+    // Per lane: kHeader = a deflate block's header (and its code tables) comes next, kSyms = its symbols, kEnd.
+    // (One loop over both, not a loop of turns inside a loop of blocks: a file written at zlib level 6, htslib's
+    // default, has six deflate blocks per BGZF block, and the lanes of a wave reach theirs at different times.  Letting a
+    // lane WAIT at a header until others of its wave have reached theirs -- a table build keeps the whole wave for
+    // 0.4 million cycles -- was measured: company of 1 / 8 / 16 / 28 lanes, patience of 1 / 128 / 384 / 2,000 turns, all
+    // 44.2-44.3 ms for a round of level-6 blocks.  The builds are not what that file's time is.)
+    enum { kHeader = 0, kSyms = 1, kEnd = 2 };
+    int st = kHeader;
+    uint32_t last = 0;
+    WalkStart lws{0, 0}, dws{0, 0};
     for (;;) {
-        const uint64_t prof_t0 = BSIG_PROF_CLOCK();
-        (void)prof_t0;
-        refill(in);
-        const uint32_t last = take(in, 1);
-        const uint32_t type = take(in, 2);
-        if (type == 0) {
-            // stored: skip to the byte boundary, LEN / NLEN, raw bytes -- sent as literals, six per token (rare in a
-            // BAM: only data that does not compress)
-            take(in, in.cnt & 7);
+        const bool go = st == kHeader;
+        if (go) do {
+            const uint64_t prof_t0 = BSIG_PROF_CLOCK();
+            (void)prof_t0;
+            bool stored = false;
             refill(in);
-            const uint32_t len = take(in, 16), nlen = take(in, 16);
-            if ((len ^ 0xFFFFu) != nlen) { err = ERR_STORED; break; }
-            // bytes still in the bit buffer belong to the raw data
-            const uint8_t *src = in.p - (in.cnt >> 3);
-            if (src + len > in.end) { err = ERR_INPUT; break; }
-            if (op + len > out_len) { err = ERR_OUTPUT; break; }
-            for (uint32_t k = 0; k < len;) {
-                if (!ch.ready()) { BSIG_SLEEP_IF_ALL(true); continue; }
-                const uint32_t m = len - k < 6u ? len - k : 6u;
-                uint64_t w = 0;
-                for (uint32_t q = 0; q < m; ++q) w |= (uint64_t)src[k + q] << (8 * q);
-                ch.send(Token{w | (uint64_t)m << 48, kTokValid});
-                k += m;
-            }
-            op += len;
-            in.p = src + len; in.buf = 0; in.cnt = 0;
-            request(in);
-        } else if (type == 3) {
-            err = ERR_CODE;
-            break;
-        } else {
-            if (type == 1) {
-                // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
-                auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
-                auto fd = [](int) { return 5; };
-                construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl, lit_offs, lit_next);
-                construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
-            } else {
-                const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
-                if (nlen > 286 || ndist > 30) { err = ERR_TABLE; break; }
-                // the code-length code: its 19 lengths (3 bits each, in the order of RFC 1951, 3.2.7) in one register
-                uint64_t clw = 0;
-                for (int k = 0; k < ncode; ++k) {
-                    if (in.cnt < 8) refill(in);
-                    clw |= (uint64_t)take(in, 3) << (3 * cl_order(k));
-                }
-                Counts cc;
-                // Its codes are at most 7 bits long, so a 7-bit table answers every one of them: it is built in the
-                // hot symbols' LDS (128 bytes, rewritten with the literal/length table below).  (The symbols are
-                // sorted into ds as well -- free until the distance code is built -- for builds with fewer hot symbols.)
-                constexpr bool kClTable = kHotSyms >= 128;
-                if (!construct<kClTable ? 7 : 0>(cc, Fast8{kClTable ? T.lsym_hot : nullptr}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); })) {
-                    err = ERR_TABLE;
-                    break;
-                }
-                // literal/length + distance code lengths, run-length coded.  They are collected in the first-level
-                // literal table's LDS (free until that table is rebuilt below) and copied to the scratch in one go:
-                // a store per length to global memory made every wait of this loop -- each refill's -- a wait for
-                // the stores before it (2,000 cycles per code length: 630,000 of a header's 1.2 million).
-                int idx = 0, prev_len = 0;
-                uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
-                uint8_t *ll_near = reinterpret_cast<uint8_t *>(T.lfast);
-                static_assert(sizeof(T.lfast) >= 320, "the code lengths are staged in the literal table's storage");
-                // (zeroed first: the runs of unused symbols -- codes 17 and 18, up to 138 lengths each, and every
-                // lane of a wave waits for the longest -- then only move the index)
-                for (int k = 0; k < 320 / 4; ++k) reinterpret_cast<uint32_t *>(T.lfast)[k] = 0;
-                while (idx < nlen + ndist) {
-                    if (in.cnt < 24) refill(in);                  // 15 bits of code + 7 of repeat count
-                    int s;
-                    if (kClTable) {
-                        const uint32_t e = T.lsym_hot[in.buf & 127u];
-                        if (!e) { err = ERR_CODE; break; }
-                        in.buf >>= (e & 7u);
-                        in.cnt -= (int)(e & 7u);
-                        s = (int)(e >> 3);
-                    } else {
-                        s = decode_walk(in, cc, ds);
-                    }
-                    if (s < 0) { err = ERR_CODE; break; }
-                    if (s < 16) {
-                        ll_near[idx++] = (uint8_t)s;
-                        prev_len = s;
-                    } else {
-                        int prev = 0, rep;
-                        if (s == 16) {
-                            if (idx == 0) { err = ERR_TABLE; break; }
-                            prev = prev_len;
-                            rep = 3 + (int)take(in, 2);
-                        } else if (s == 17) {
-                            rep = 3 + (int)take(in, 3);
-                        } else {
-                            rep = 11 + (int)take(in, 7);
-                        }
-                        if (idx + rep > nlen + ndist) { err = ERR_TABLE; break; }
-                        if (prev) {
-                            while (rep--) ll_near[idx++] = (uint8_t)prev;      // (code 16: at most six)
-                        } else {
-                            idx += rep;
-                        }
-                        prev_len = prev;
-                    }
-                    if (overrun(in)) { err = ERR_INPUT; break; }
-                }
-                if (err) break;
-                for (int k = 0; k < nlen + ndist; k += 8) store64(ll + k, load64(ll_near + k));      // (<= 320 bytes either side)
-                {
-                    LenReader eob(ll + 256);
-                    if (eob(0) == 0) { err = ERR_TABLE; break; }  // no end-of-block code
-                }
-                if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next)) { err = ERR_TABLE; break; }
-                if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) { err = ERR_TABLE; break; }
-            }
-            // ---- the compressed data of this block: per turn ONE token -- a run of up to six literals the first-level
-            // table knows and/or the match behind them.  The only memory a turn touches is the input word requested a
-            // turn ahead (and, rarely, a cold symbol), so a turn is the decode chain and nothing else. ----
-            const WalkStart lws = walk_start<kLFast>(lc), dws = walk_start<kDFast>(dc);
-            BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
-            for (;;) {
-                // Is the mailbox empty?  Asked NOW, needed only when the token is ready: the answer arrives beside the
-                // first table lookup instead of standing in front of the chain, and the token is decoded while the
-                // consumer may still be busy with the previous one.
-                const bool room = ch.ready();
-                uint64_t lit = 0;
-                uint32_t nlit = 0, mlen = 0, mdist = 0;
-                bool eob = false;
-                BSIG_PROF(prof->turns++);
+            last = take(in, 1);
+            const uint32_t type = take(in, 2);
+            if (type == 0) {
+                // stored: skip to the byte boundary, LEN / NLEN, raw bytes -- sent as literals, six per token (rare in a
+                // BAM: only data that does not compress)
+                take(in, in.cnt & 7);
                 refill(in);
-                BSIG_PROF(if (lfast_at(T, in.buf) == 0) prof->walks++);
-                int s = decode<kLFast>(in, T, lc, ls, lws);
-                uint32_t opx = op;                 // where the next symbol's bytes will go
-                if (s < 256) {
-                    if (s < 0) { err = ERR_CODE; }
-                    else if (op >= out_len) { err = ERR_OUTPUT; }
-                    else {
-                        // a literal; up to five more if the first-level table says the next symbols
-                        // are literals too (<= 8 bits each: the 56 bits of the refill cover 15 + 5 x 8)
-                        lit = (uint64_t)s;
-                        nlit = 1;
-                        s = -2;                    // nothing more this turn, unless a match follows
-                        if (kLFast > 0 && kMultiLit) {
+                const uint32_t len = take(in, 16), nlen = take(in, 16);
+                if ((len ^ 0xFFFFu) != nlen) { err = ERR_STORED; break; }
+                // bytes still in the bit buffer belong to the raw data
+                const uint8_t *src = in.p - (in.cnt >> 3);
+                if (src + len > in.end) { err = ERR_INPUT; break; }
+                if (op + len > out_len) { err = ERR_OUTPUT; break; }
+                for (uint32_t k = 0; k < len;) {
+                    if (!ch.ready()) { BSIG_SLEEP_IF_ALL(true); continue; }
+                    const uint32_t m = len - k < 6u ? len - k : 6u;
+                    uint64_t w = 0;
+                    for (uint32_t q = 0; q < m; ++q) w |= (uint64_t)src[k + q] << (8 * q);
+                    ch.send(Token{w | (uint64_t)m << 48, kTokValid});
+                    k += m;
+                }
+                op += len;
+                in.p = src + len; in.buf = 0; in.cnt = 0;
+                request(in);
+                stored = true;
+            } else if (type == 3) {
+                err = ERR_CODE;
+                break;
+            } else {
+                if (type == 1) {
+                    // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
+                    auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
+                    auto fd = [](int) { return 5; };
+                    construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl, lit_offs, lit_next);
+                    construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
+                } else {
+                    const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
+                    if (nlen > 286 || ndist > 30) { err = ERR_TABLE; break; }
+                    // the code-length code: its 19 lengths (3 bits each, in the order of RFC 1951, 3.2.7) in one register
+                    uint64_t clw = 0;
+                    for (int k = 0; k < ncode; ++k) {
+                        if (in.cnt < 8) refill(in);
+                        clw |= (uint64_t)take(in, 3) << (3 * cl_order(k));
+                    }
+                    Counts cc;
+                    // Its codes are at most 7 bits long, so a 7-bit table answers every one of them: it is built in the
+                    // hot symbols' LDS (128 bytes, rewritten with the literal/length table below).  (The symbols are
+                    // sorted into ds as well -- free until the distance code is built -- for builds with fewer hot symbols.)
+                    constexpr bool kClTable = kHotSyms >= 128;
+                    if (!construct<kClTable ? 7 : 0>(cc, Fast8{kClTable ? T.lsym_hot : nullptr}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); })) {
+                        err = ERR_TABLE;
+                        break;
+                    }
+                    // literal/length + distance code lengths, run-length coded.  They are collected in the first-level
+                    // literal table's LDS (free until that table is rebuilt below) and copied to the scratch in one go:
+                    // a store per length to global memory made every wait of this loop -- each refill's -- a wait for
+                    // the stores before it (2,000 cycles per code length: 630,000 of a header's 1.2 million).
+                    int idx = 0, prev_len = 0;
+                    uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
+                    uint8_t *ll_near = reinterpret_cast<uint8_t *>(T.lfast);
+                    static_assert(sizeof(T.lfast) >= 320, "the code lengths are staged in the literal table's storage");
+                    // (zeroed first: the runs of unused symbols -- codes 17 and 18, up to 138 lengths each, and every
+                    // lane of a wave waits for the longest -- then only move the index)
+                    for (int k = 0; k < 320 / 4; ++k) reinterpret_cast<uint32_t *>(T.lfast)[k] = 0;
+                    while (idx < nlen + ndist) {
+                        if (in.cnt < 24) refill(in);                  // 15 bits of code + 7 of repeat count
+                        int s;
+                        if (kClTable) {
+                            const uint32_t e = T.lsym_hot[in.buf & 127u];
+                            if (!e) { err = ERR_CODE; break; }
+                            in.buf >>= (e & 7u);
+                            in.cnt -= (int)(e & 7u);
+                            s = (int)(e >> 3);
+                        } else {
+                            s = decode_walk(in, cc, ds);
+                        }
+                        if (s < 0) { err = ERR_CODE; break; }
+                        if (s < 16) {
+                            ll_near[idx++] = (uint8_t)s;
+                            prev_len = s;
+                        } else {
+                            int prev = 0, rep;
+                            if (s == 16) {
+                                if (idx == 0) { err = ERR_TABLE; break; }
+                                prev = prev_len;
+                                rep = 3 + (int)take(in, 2);
+                            } else if (s == 17) {
+                                rep = 3 + (int)take(in, 3);
+                            } else {
+                                rep = 11 + (int)take(in, 7);
+                            }
+                            if (idx + rep > nlen + ndist) { err = ERR_TABLE; break; }
+                            if (prev) {
+                                while (rep--) ll_near[idx++] = (uint8_t)prev;      // (code 16: at most six)
+                            } else {
+                                idx += rep;
+                            }
+                            prev_len = prev;
+                        }
+                        if (overrun(in)) { err = ERR_INPUT; break; }
+                    }
+                    if (err) break;
+                    for (int k = 0; k < nlen + ndist; k += 8) store64(ll + k, load64(ll_near + k));      // (<= 320 bytes either side)
+                    {
+                        LenReader eob(ll + 256);
+                        if (eob(0) == 0) { err = ERR_TABLE; break; }  // no end-of-block code
+                    }
+                    if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next)) { err = ERR_TABLE; break; }
+                    if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) { err = ERR_TABLE; break; }
+                }
+
+                lws = walk_start<kLFast>(lc);
+                dws = walk_start<kDFast>(dc);
+                BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
+            }
+            if (stored) {
+                if (overrun(in)) { err = ERR_INPUT; break; }
+                st = last ? kEnd : kHeader;
+            } else {
+                st = kSyms;
+            }
+        } while (0);
+        if (err) st = kEnd;
+        // ---- the compressed data of a block: per turn ONE token -- a run of up to six literals the first-level table
+        // knows and/or the match behind them.  The only memory a turn touches is the input word requested a turn ahead
+        // (and, rarely, a cold symbol), so a turn is the decode chain and nothing else. ----
+        if (st == kSyms) do {
+            // Is the mailbox empty?  Asked NOW, needed only when the token is ready: the answer arrives beside the
+            // first table lookup instead of standing in front of the chain, and the token is decoded while the
+            // consumer may still be busy with the previous one.
+            const bool room = ch.ready();
+            uint64_t lit = 0;
+            uint32_t nlit = 0, mlen = 0, mdist = 0;
+            bool eob = false;
+            BSIG_PROF(prof->turns++);
+            refill(in);
+            BSIG_PROF(if (lfast_at(T, in.buf) == 0) prof->walks++);
+            int s = decode<kLFast>(in, T, lc, ls, lws);
+            uint32_t opx = op;                 // where the next symbol's bytes will go
+            if (s < 256) {
+                if (s < 0) { err = ERR_CODE; }
+                else if (op >= out_len) { err = ERR_OUTPUT; }
+                else {
+                    // a literal; up to five more if the first-level table says the next symbols
+                    // are literals too (<= 8 bits each: the 56 bits of the refill cover 15 + 5 x 8)
+                    lit = (uint64_t)s;
+                    nlit = 1;
+                    s = -2;                    // nothing more this turn, unless a match follows
+                    if (kLFast > 0 && kMultiLit) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-                            for (int q = 1; q < 6; ++q) {
-                                const uint32_t e = lfast_at(T, in.buf);
-                                if (e == 0 || (e >> 4) >= 256u || in.cnt < 2 * kLFast || op + (uint32_t)q >= out_len) break;
-                                const int len = (int)(e & 15u);
-                                in.buf >>= len;
-                                in.cnt -= len;
-                                lit |= (uint64_t)(e >> 4) << (8 * q);
-                                nlit = (uint32_t)q + 1;
-                            }
-                            // a match right behind the literals rides in the same token (its bits come
-                            // with a second refill; the word it needs was requested a turn ago)
-                            if (in.cnt >= kLFast) {
-                                const uint32_t e = lfast_at(T, in.buf);
-                                if (e && (e >> 4) > 256u) {
-                                    refill(in);
-                                    s = decode<kLFast>(in, T, lc, ls, lws);
-                                }
-                            }
+                        for (int q = 1; q < 6; ++q) {
+                            const uint32_t e = lfast_at(T, in.buf);
+                            if (e == 0 || (e >> 4) >= 256u || in.cnt < 2 * kLFast || op + (uint32_t)q >= out_len) break;
+                            const int len = (int)(e & 15u);
+                            in.buf >>= len;
+                            in.cnt -= len;
+                            lit |= (uint64_t)(e >> 4) << (8 * q);
+                            nlit = (uint32_t)q + 1;
                         }
-                        opx = op + nlit;
-                    }
-                }
-                if (err == OK) {
-                    if (s == 256) {
-                        eob = true;
-                    } else if (s > 256) {
-                        s -= 257;
-                        if (s >= 29) { err = ERR_CODE; }
-                        else {
-                            const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
-                            BSIG_PROF(if (T.dfast[in.buf & ((1u << kDFast) - 1)] == 0) prof->long_dist++);
-                            const int d = decode_dist(in, T.dfast, dc, ds, dws);             // <= 20 + 28 of the 56 bits
-                            if (d < 0 || d >= 30) { err = ERR_CODE; }
-                            else {
-                                const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
-                                if (dist > opx) { err = ERR_DIST; }
-                                else if (opx + len > out_len) { err = ERR_OUTPUT; }
-                                else if (overrun(in)) { err = ERR_INPUT; }
-                                else { mlen = len; mdist = dist; }
+                        // a match right behind the literals rides in the same token (its bits come
+                        // with a second refill; the word it needs was requested a turn ago)
+                        if (in.cnt >= kLFast) {
+                            const uint32_t e = lfast_at(T, in.buf);
+                            if (e && (e >> 4) > 256u) {
+                                refill(in);
+                                s = decode<kLFast>(in, T, lc, ls, lws);
                             }
                         }
                     }
+                    opx = op + nlit;
                 }
-                if (err) break;
-                BSIG_PROF(if (nlit) { prof->lit_turns++; prof->lits += nlit; } if (mlen) prof->match_turns++);
-                if (nlit | mlen) {
-                    // (the consumer still holds the previous token: a long match, or its memory is slow)
-                    if (!room)
-                        while (!ch.ready()) BSIG_SLEEP_IF_ALL(true);
-                    ch.send(Token{lit | (uint64_t)nlit << 48 | (uint64_t)mlen << 51, kTokValid | mdist << 1});
-                    op = opx + mlen;
-                }
-                if (eob) break;
             }
-            if (err) break;
-        }
-        if (overrun(in)) { err = ERR_INPUT; break; }
-        if (last) break;
+            if (err == OK) {
+                if (s == 256) {
+                    eob = true;
+                } else if (s > 256) {
+                    s -= 257;
+                    if (s >= 29) { err = ERR_CODE; }
+                    else {
+                        const uint32_t len = (uint32_t)len_base(s) + take(in, len_extra(s));
+                        BSIG_PROF(if (T.dfast[in.buf & ((1u << kDFast) - 1)] == 0) prof->long_dist++);
+                        const int d = decode_dist(in, T.dfast, dc, ds, dws);             // <= 20 + 28 of the 56 bits
+                        if (d < 0 || d >= 30) { err = ERR_CODE; }
+                        else {
+                            const uint32_t dist = (uint32_t)dist_base(d) + take(in, dist_extra(d));
+                            if (dist > opx) { err = ERR_DIST; }
+                            else if (opx + len > out_len) { err = ERR_OUTPUT; }
+                            else if (overrun(in)) { err = ERR_INPUT; }
+                            else { mlen = len; mdist = dist; }
+                        }
+                    }
+                }
+            }
+            if (err) { st = kEnd; break; }
+            BSIG_PROF(if (nlit) { prof->lit_turns++; prof->lits += nlit; } if (mlen) prof->match_turns++);
+            if (nlit | mlen) {
+                // (the consumer still holds the previous token: a long match, or its memory is slow)
+                if (!room)
+                    while (!ch.ready()) BSIG_SLEEP_IF_ALL(true);
+                ch.send(Token{lit | (uint64_t)nlit << 48 | (uint64_t)mlen << 51, kTokValid | mdist << 1});
+                op = opx + mlen;
+            }
+            if (eob) {
+                if (overrun(in)) { err = ERR_INPUT; st = kEnd; }
+                else st = last ? kEnd : kHeader;
+            }
+        } while (0);
+        if (st == kEnd) break;
     }
     if (err == OK && op != out_len) err = ERR_OUTPUT;
     while (!ch.ready()) BSIG_SLEEP_IF_ALL(true);
