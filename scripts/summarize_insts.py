@@ -13,7 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 print("| case | kernel | launches | waves | VALU / wave | SALU / wave | LDS / wave | VMEM_RD / wave | VALU x 4 cycles / 1,024 SIMDs @ 2.4 GHz | launch (same run) | share |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
-for case in ("ns", "C3", "C4", "count"):
+for case in ("ns", "C3", "C4", "count", "bins"):
     f = sorted(glob.glob(os.path.join(G, f"{tag}_insts_{case}", "*", "*counter_collection.csv")))
     t = sorted(glob.glob(os.path.join(G, f"{tag}_insts_{case}", "*", "*kernel_trace.csv")))
     if not f:

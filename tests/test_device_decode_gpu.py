@@ -478,8 +478,44 @@ def test_inflate_kernel_keeps_its_state_in_registers(ctx):
     regs, scratch, rnd = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int64(0)
     assert fn(0, ctypes.byref(regs), ctypes.byref(scratch), ctypes.byref(rnd)) == 0
     assert scratch.value == 0, scratch.value
-    assert 0 < regs.value <= 168, regs.value                       # three waves per SIMD
-    assert rnd.value >= 256 * 7 * 32, rnd.value                    # at least seven workgroups of 32 lanes per CU
+    # round 5: two waves per workgroup (one decodes, one copies): seven workgroups per CU are 14 waves, up to four on a SIMD
+    assert 0 < regs.value <= 128, regs.value
+    assert rnd.value >= 256 * 7 * 32, rnd.value                    # at least seven workgroups of 32 blocks per CU
+
+
+@pytest.mark.parametrize("shape", ["bare, level 1", "real-shaped, level 6", "stored blocks"])
+def test_inflate_kernel_alone_in_every_form(ctx, tmp_path, monkeypatch, shape):
+    """k_inflate by itself (bsig_debug_inflate_bench: the compressed bytes resident, every block's CRC32 against its
+    BGZF trailer afterwards) with 4, 8, 16, 32 and 64 blocks per workgroup -- two waves each, a decoding lane and a copying
+    lane per block, a 12-byte mailbox between them -- and with padded LDS, on bare records (matches at distances below
+    64 whose sources reach into the copier's 16-byte accumulator), on real-shaped records at zlib level 6 (six deflate
+    blocks per BGZF block: headers met at different times by the lanes of a wave) and on stored blocks (literal tokens
+    only).  Also: a launch of fewer blocks than a workgroup holds, and one block."""
+    import ctypes
+    from bamsignals_amd import _lib, write_columns_as_bam
+    from bamsignals_amd.synth import synth_reads
+    lib = _lib.load()
+    fn = lib.bsig_debug_inflate_bench
+    fn.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+    cols = synth_reads(300_000 if shape.startswith("bare") else 60_000, [5_000_000, 900_000], seed=77)
+    path = str(tmp_path / "k.bam")
+    level, l_seq = {"bare, level 1": (1, 0), "real-shaped, level 6": (6, 100), "stored blocks": (0, 50)}[shape]
+    write_columns_as_bam(path, ["a", "b"], cols, level=level, l_seq=l_seq, seed=5)
+
+    def run(first, n):
+        ms, by, st = (ctypes.c_double * 2)(), (ctypes.c_int64 * 3)(), ctypes.c_int(-1)
+        rc = fn(0, path.encode(), first, n, 1, ms, by, ctypes.byref(st))
+        return rc, st.value, by[2], by[1]
+
+    rc, st, n_all, out_all = run(0, 1 << 20)
+    assert (rc, st) == (0, 0) and n_all >= 40 and out_all > 2_000_000, (rc, st, n_all, out_all)
+    for lanes, pad in (("4", "0"), ("8", "0"), ("16", "100"), ("32", "0"), ("32", "288"), ("64", "0")):
+        monkeypatch.setenv("BAMSIGNALS_INFLATE_LANES", lanes)
+        monkeypatch.setenv("BAMSIGNALS_INFLATE_LDS_PAD", pad)
+        for first, n in ((0, 1 << 20), (3, 1), (1, 7), (2, 33)):
+            rc, st, nb, _ = run(first, n)
+            assert (rc, st) == (0, 0) and nb == min(n, n_all - first), (shape, lanes, pad, first, n, rc, st, nb)
 
 
 def test_passes_are_whole_rounds_of_inflate_lanes(ctx, tmp_path, monkeypatch, capfd):
