@@ -46,6 +46,9 @@ constexpr int kLFast = BSIG_LFAST, kDFast = BSIG_DFAST;   // first-level table b
 #ifndef BSIG_MULTI_LIT
 #define BSIG_MULTI_LIT 1
 #endif
+#ifndef BSIG_LIT_LOOP_BRANCHES
+#define BSIG_LIT_LOOP_BRANCHES 0
+#endif
 constexpr bool kMultiLit = BSIG_MULTI_LIT != 0;
 constexpr uint32_t kTurn = 64;     // bytes of a pending match copied per turn of the main loop
 // (diagnostic builds only, scripts/inflate_bench.py: what a turn costs WITHOUT part of its memory traffic -- the
@@ -91,9 +94,11 @@ struct ColdTables {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BSIG_KEEP_APART() asm volatile("" ::: "memory")
 #define BSIG_ALL_LANES(c) __all(c)          // true for every lane of the wave that is here
+#define BSIG_ANY_LANES(c) __any(c)
 #else
 #define BSIG_KEEP_APART() do { } while (0)
 #define BSIG_ALL_LANES(c) (c)
+#define BSIG_ANY_LANES(c) (c)
 #endif
 
 // the sorted symbols of the literal/length code: the low 8 bits as bytes, bit 8 as a bit
@@ -808,6 +813,7 @@ BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, Lane
                     nlit = 1;
                     s = -2;                    // nothing more this turn, unless a match follows
                     if (kLFast > 0 && kMultiLit) {
+#if BSIG_LIT_LOOP_BRANCHES
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -820,6 +826,26 @@ BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, Lane
                             lit |= (uint64_t)(e >> 4) << (8 * q);
                             nlit = (uint32_t)q + 1;
                         }
+#else
+                        // (no branch per literal: the lanes of a wave leave such a loop at five different places, and
+                        // every exit is an exec-mask dance the whole wave pays -- a literal cost 500 cycles of which
+                        // the table lookup is 100.  A lane whose run has ended goes through the remaining steps
+                        // consuming zero bits.)
+                        bool run = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                        for (int q = 1; q < 6; ++q) {
+                            const uint32_t e = lfast_at(T, in.buf);
+                            run = run & (e != 0u) & ((e >> 4) < 256u) & (in.cnt >= 2 * kLFast) & (op + (uint32_t)q < out_len);
+                            const int len = run ? (int)(e & 15u) : 0;
+                            in.buf >>= len;
+                            in.cnt -= len;
+                            lit |= (uint64_t)(run ? e >> 4 : 0u) << (8 * q);
+                            nlit += run ? 1u : 0u;
+                            if (!BSIG_ANY_LANES(run)) break;          // (uniform: nobody's run goes on)
+                        }
+#endif
                         // a match right behind the literals rides in the same token (its bits come
                         // with a second refill; the word it needs was requested a turn ago)
                         if (in.cnt >= kLFast) {
