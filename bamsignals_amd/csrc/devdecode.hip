@@ -322,7 +322,6 @@ __global__ __launch_bounds__(kInflateThreads) __attribute__((amdgpu_waves_per_eu
                                                    int *__restrict__ status, uint32_t lds_pad)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    LaneSlot *slots = reinterpret_cast<LaneSlot *>(lds_raw);
     // (behind the tables and whatever the occupancy knob pads them with: 8-byte words, then 4-byte words)
     uint8_t *mail = lds_raw + (((size_t)LANES * (sizeof(LaneSlot) + lds_pad) + 7) & ~(size_t)7);
     uint64_t *tok_a = reinterpret_cast<uint64_t *>(mail);
@@ -331,8 +330,12 @@ __global__ __launch_bounds__(kInflateThreads) __attribute__((amdgpu_waves_per_eu
     if (threadIdx.x < LANES) tok_b[threadIdx.x] = 0;          // every mailbox starts empty
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * LANES + lane;
-    if (lane >= LANES || i >= n) return;
-    const InflateJob j = jobs[i];
+    if (lane >= LANES) return;
+    // (a lane of the PRODUCER wave without a block -- the launch's last workgroup -- stays: the wave builds its lanes' code
+    // tables together, and every lane id below LANES is expected to take part)
+    const bool present = i < n;
+    if (!present && role == 1) return;
+    const InflateJob j = present ? jobs[i] : InflateJob{0, 0, 0, 0, 0, 0};
     bsig_inflate::ChanLds ch(tok_a + lane, tok_b + lane);
     if (role == 1) {
         bsig_inflate::consume(out + j.out_off, j.isize, ch);
@@ -340,13 +343,15 @@ __global__ __launch_bounds__(kInflateThreads) __attribute__((amdgpu_waves_per_eu
     }
     // the decode chain is the longer one: its wave goes first wherever the two meet on a SIMD
     __builtin_amdgcn_s_setprio(BSIG_PRODUCER_PRIO);
+    const uint32_t lane_stride = (uint32_t)sizeof(LaneSlot) + lds_pad;
+    bsig_inflate::LaneTables &T = *reinterpret_cast<bsig_inflate::LaneTables *>(lds_raw + (size_t)lane * lane_stride);
 #ifdef BSIG_INFLATE_PROF
     bsig_inflate::LaneProf pf{};
     const uint64_t t0 = clock64();
-    const int rc = bsig_inflate::produce(comp + j.in_off, j.in_len, j.isize, slots[lane].t, lens + i * bsig_inflate::kLensBytes, ch, &pf);
-    if (i < kProfLanes) g_prof_rows[i] = ProfRow{pf, (uint64_t)clock64() - t0, j.isize, j.in_len};
+    const int rc = bsig_inflate::produce<LANES>(comp + j.in_off, j.in_len, j.isize, T, lens + i * bsig_inflate::kLensBytes, ch, &pf, present, lane, lane_stride);
+    if (present && i < kProfLanes) g_prof_rows[i] = ProfRow{pf, (uint64_t)clock64() - t0, j.isize, j.in_len};
 #else
-    const int rc = bsig_inflate::produce(comp + j.in_off, j.in_len, j.isize, slots[lane].t, lens + i * bsig_inflate::kLensBytes, ch);
+    const int rc = bsig_inflate::produce<LANES>(comp + j.in_off, j.in_len, j.isize, T, lens + i * bsig_inflate::kLensBytes, ch, nullptr, present, lane, lane_stride);
 #endif
     if (rc) atomicMax(status, rc);
 }

@@ -551,6 +551,185 @@ struct LaneProf {
 #define BSIG_PROF_CLOCK() 0ull
 #endif
 
+// ---- a code's tables built by the WAVE for one of its lanes (device) -------------------------------------------------
+// A lane that builds its tables by itself (construct above) goes through ~4,000 LDS operations one behind the other,
+// and its wave stands still meanwhile: a round of headers costs a launch 3-4 ms -- a sixth of a level-1 launch, half of a
+// level-6 one (six deflate blocks per BGZF block; profiles/NOTES_r05.md, section 8).  The canonical code is all counting
+// and ranking, which a wave does in a few ballots: the W lanes of the producer wave build the tables of ONE lane
+// together, each holding the code lengths of the symbols hx, hx + W, hx + 2W, ...  Per length: how many symbols have it
+// (ballot + count), the first code and the first sorted position (a 15-step scan, the same in every lane), then per
+// symbol its rank among the symbols of its length (the lanes below it in the ballot + what earlier rounds counted) --
+// code = first + rank -- and every lane writes its symbols' first-level entries and sorted positions.  No LDS
+// read-modify-write, no chain: about 1,500 instructions of the wave per literal/length code.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+template <int W>
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)          // OR over the W lanes (W a power of two; lanes >= W are not here)
+{
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v)
+{
+    return (uint64_t)wave_or<W>((uint32_t)v) | (uint64_t)wave_or<W>((uint32_t)(v >> 32)) << 32;
+}
+// first-level tables as the wave fills them: ENTRY bytes per entry, 1 << FAST entries at `t` (LDS of the target lane)
+template <int FAST, typename Entry, int SHIFT>
+struct CoopFast {
+    Entry *t;
+    template <int W> __device__ __forceinline__ void zero(int hx) const
+    {
+        constexpr int bytes = (int)sizeof(Entry) << FAST;
+        static_assert(bytes % 16 == 0, "whole 16-byte vectors");
+        for (int o = 16 * hx; o < bytes; o += 16 * W) {
+            const W16 z{0, 0};
+            __builtin_memcpy(reinterpret_cast<uint8_t *>(t) + o, &z, 16);
+        }
+    }
+    __device__ __forceinline__ void put(uint32_t k, uint32_t sym, uint32_t l) const { t[k] = (Entry)((sym << SHIFT) | l); }
+};
+// ml[r]: the code length of symbol hx + W * r (0: unused or beyond the code).  on_symbol(sorted position, symbol, length)
+// is called by the symbol's lane for every used symbol.  c: the counts per length (the same in every lane); base: the
+// first sorted position of a code longer than FAST.  false: over-subscribed (the same in every lane).
+template <int FAST, int W, int ROUNDS, typename FastT, typename OnSymbol>
+__device__ __forceinline__ bool coop_construct(const uint32_t (&ml)[ROUNDS], int hx, const FastT &fast, Counts &c, int &base,
+                                               OnSymbol on_symbol)
+{
+    uint32_t cnt[16], first[16], offs[16], run[16];
+#pragma unroll
+    for (int len = 1; len <= 15; ++len) {
+        uint32_t k = 0;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) k += (uint32_t)__popcll(__ballot(ml[r] == (uint32_t)len));
+        cnt[len] = k;
+        run[len] = 0;
+    }
+    int left = 1;
+    uint32_t code = 0, shorter = 0, acc = 0;
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.w[k] = 0;
+#pragma unroll
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= (int)cnt[len];
+        over = over | (left < 0);
+        c.w[len >> 1] |= cnt[len] << ((len & 1) * 16);
+        code = (code + shorter) << 1;                // first canonical code of this length
+        first[len] = code;
+        shorter = cnt[len];
+        offs[len] = acc;                             // ... and where its symbols begin in the sorted order
+        acc += cnt[len];
+    }
+    if (over) return false;
+    base = FAST < 15 ? (int)offs[FAST + 1] : (int)acc;
+    fast.template zero<W>(hx);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t l = ml[r];
+        uint32_t cd = 0, ix = 0;
+#pragma unroll
+        for (int len = 1; len <= 15; ++len) {
+            if (cnt[len] == 0u) continue;                 // (uniform: a code uses eight to ten of the fifteen lengths)
+            const bool mine = l == (uint32_t)len;
+            const uint64_t m = __ballot(mine);
+            const uint32_t rk = run[len] + lanes_below(m);
+            cd = mine ? first[len] + rk : cd;
+            ix = mine ? offs[len] + rk : ix;
+            run[len] += (uint32_t)__popcll(m);
+        }
+        const uint32_t sym = (uint32_t)(hx + W * r);
+        if (l != 0u) {
+            if (l <= (uint32_t)FAST)
+                for (uint32_t k = bit_reverse(cd, (int)l); k < (1u << FAST); k += 1u << l) fast.put(k, sym, l);
+            on_symbol(ix, sym, l);
+        }
+    }
+    return true;
+}
+
+// the code-length code of lane L (its 19 lengths, 3 bits each, in clw): a 7-bit table in L's hot-symbol LDS
+template <int W>
+__device__ __forceinline__ bool coop_cl_table(uint64_t clw, int hx, LaneTables *TL)
+{
+    constexpr int R = (19 + W - 1) / W;
+    uint32_t ml[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = hx + W * r;
+        ml[r] = i < 19 ? (uint32_t)((clw >> (3 * i)) & 7ull) : 0u;
+    }
+    Counts cc;
+    int base;
+    return coop_construct<7, W, R>(ml, hx, CoopFast<7, uint8_t, 3>{TL->lsym_hot}, cc, base, [](uint32_t, uint32_t, uint32_t) {});
+}
+
+// the literal/length and distance tables of lane L from the code lengths staged in L's literal table storage (nlen
+// literal/length lengths, then ndist distance lengths; `fixed`: the fixed code of RFC 1951, 3.2.6 instead).  What
+// lives in registers of the target lane -- counts, the hot symbols' ninth bits, the distance symbols -- comes back
+// through lc / dc / hot_hi / dsw / base, valid in EVERY lane (lane L keeps them).  false: a code is over-subscribed.
+template <int W>
+__device__ __forceinline__ bool coop_tables(int hx, LaneTables *TL, uint8_t *lensL, int nlen, int ndist, bool fixed,
+                                            Counts &lc, Counts &dc, uint64_t (&hot_hi)[kHotSyms / 64], uint64_t (&dsw)[3], int &base)
+{
+    constexpr int RL = (288 + W - 1) / W, RD = (32 + W - 1) / W;
+    uint32_t ml[RL], md[RD];
+    const uint8_t *stage = reinterpret_cast<const uint8_t *>(TL->lfast);
+#pragma unroll
+    for (int r = 0; r < RL; ++r) {
+        const int i = hx + W * r;
+        ml[r] = fixed ? (i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : i < 288 ? 8u : 0u) : i < nlen ? (uint32_t)stage[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RD; ++r) {
+        const int i = hx + W * r;
+        md[r] = fixed ? (i < 30 ? 5u : 0u) : i < ndist ? (uint32_t)stage[nlen + i] : 0u;
+    }
+    ColdTables &Cd = *reinterpret_cast<ColdTables *>(lensL + kLensCodes);
+    for (int k = hx; k < 9; k += W) Cd.lhi[k] = 0;
+    uint64_t hh[kHotSyms / 64];
+#pragma unroll
+    for (int k = 0; k < kHotSyms / 64; ++k) hh[k] = 0;
+    int lbase = 0;
+    // (base is known inside coop_construct before any symbol is placed: the callback reads it through the reference)
+    const bool ok_l = coop_construct<kLFast, W, RL>(ml, hx, CoopFast<kLFast, uint16_t, 4>{TL->lfast}, lc, lbase,
+        [&](uint32_t ix, uint32_t sym, uint32_t l) {
+            if (l <= (uint32_t)kLFast) return;                         // the first-level table answers it
+            const uint32_t h = ix - (uint32_t)lbase;
+            if (h < (uint32_t)kHotSyms) {
+                TL->lsym_hot[h] = (uint8_t)sym;
+                const uint64_t bit = (uint64_t)(sym >> 8) << (h & 63u);
+#pragma unroll
+                for (int k = 0; k < kHotSyms / 64; ++k) hh[k] |= (int)(h >> 6) == k ? bit : 0ull;
+            } else {
+                Cd.lsym[ix] = (uint8_t)sym;
+                if (sym >> 8) atomicOr(&Cd.lhi[ix >> 5], 1u << (ix & 31u));
+            }
+        });
+#pragma unroll
+    for (int k = 0; k < kHotSyms / 64; ++k) hot_hi[k] = wave_or64<W>(hh[k]);
+    base = lbase;
+    uint64_t dw[3] = {0, 0, 0};
+    int dbase = 0;
+    const bool ok_d = coop_construct<kDFast, W, RD>(md, hx, CoopFast<kDFast, uint8_t, 3>{TL->dfast}, dc, dbase,
+        [&](uint32_t ix, uint32_t sym, uint32_t) {
+            const uint32_t q = ix >= 24u ? 2u : ix >= 12u ? 1u : 0u;
+            const uint64_t v = (uint64_t)(sym & 31u) << (5u * (ix - 12u * q));
+            dw[0] |= q == 0u ? v : 0ull;
+            dw[1] |= q == 1u ? v : 0ull;
+            dw[2] |= q == 2u ? v : 0ull;
+        });
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dsw[k] = wave_or64<W>(dw[k]);
+    return ok_l && ok_d;
+}
+#endif
+
 // ---- the two halves of a block's work and the channel between them ------------------------------------------------
 // Huffman decoding and LZ77 copying are two dependent chains of their own -- bits -> table -> bits ..., and
 // load -> wait -> store ... -- and one lane that runs both pays their SUM per turn (r05 ablation, one round of 57,344
@@ -629,40 +808,46 @@ struct ChanVec {
 // (tests/asan checks that).  Every token is checked before it is sent (distance within what is out, length within
 // out_len), so the consumer needs no checks of its own.  Ends the stream with an end token that carries the return
 // value: OK or an ERR_ code.
-template <typename Chan>
+// Device: W = the lanes of the producer wave (lane ids 0 .. W-1, ALL of them here: a lane without a block comes with
+// present = false and only helps with the others' tables); lane_stride / lens of neighbouring lanes lie
+// (their lane - mine) * lane_stride / * kLensBytes bytes from T / lens.
+template <int W = 1, typename Chan>
 BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, LaneTables &T, uint8_t *lens, Chan &ch,
-                    LaneProf *prof = nullptr)
+                    LaneProf *prof = nullptr, bool present = true, int hx = 0, uint32_t lane_stride = 0)
 {
-    (void)prof;
+    (void)prof; (void)hx; (void)lane_stride;
     BitIn in;
     in.p = in_p; in.end = in_p + in_len; in.buf = 0; in.cnt = 0;
-    request(in);
+    if (present) request(in); else { in.ahead = 0; in.amask = 0; }
     uint32_t op = 0;                   // bytes the tokens sent so far make
     int err = OK;
     Counts lc, dc;
+    for (int k = 0; k < 8; ++k) lc.w[k] = dc.w[k] = 0;
     ColdTables &Cd = *reinterpret_cast<ColdTables *>(lens + kLensCodes);
     LSyms ls{Cd.lsym, Cd.lhi, T.lsym_hot, {}, 0};
-    // (the slots of the literal/length table's construction: the distance table's 64 bytes, rebuilt right after it)
-    static_assert(sizeof(T.dfast) >= 64, "the distance table's LDS doubles as the literal table's construction slots");
-    const SlotsMem lit_offs{reinterpret_cast<uint16_t *>(T.dfast)}, lit_next{reinterpret_cast<uint16_t *>(T.dfast) + 16};
     DSyms ds;
     ds.clear();
-    // Per lane: kHeader = a deflate block's header (and its code tables) comes next, kSyms = its symbols, kEnd.
-    // (One loop over both, not a loop of turns inside a loop of blocks: a file written at zlib level 6, htslib's
-    // default, has six deflate blocks per BGZF block, and the lanes of a wave reach theirs at different times.  Letting a
-    // lane WAIT at a header until others of its wave have reached theirs -- a table build keeps the whole wave for
-    // 0.4 million cycles -- was measured: company of 1 / 8 / 16 / 28 lanes, patience of 1 / 128 / 384 / 2,000 turns, all
-    // 44.2-44.3 ms for a round of level-6 blocks.  The builds are not what that file's time is.)
-    enum { kHeader = 0, kSyms = 1, kEnd = 2 };
-    int st = kHeader;
+    // Per lane, one loop over the states of a deflate block:
+    //   kHeader    its first bits; a stored block is sent off as literals at once
+    //   kWantCl    (dynamic code) the 19 lengths of the code-length code are read: its table is to be built
+    //   kLens      ... with which the literal/length and distance code lengths are decoded into the literal table's
+    //              storage
+    //   kWantTabs  the two codes' tables are to be built
+    //   kSyms      one token per turn
+    // On the device the two builds are the WAVE's work, one lane's tables at a time (coop_* above); the host, one lane,
+    // builds them with construct().
+    enum { kHeader = 0, kWantCl = 1, kLens = 2, kWantTabs = 3, kSyms = 4, kEnd = 5 };
+    int st = present ? kHeader : kEnd;
     uint32_t last = 0;
+    uint64_t clw = 0;                  // the code-length code's lengths, 3 bits each
+    int nlen = 0, ndist = 0;
+    bool fixed = false;
     WalkStart lws{0, 0}, dws{0, 0};
+    uint8_t *ll_near = reinterpret_cast<uint8_t *>(T.lfast);
+    static_assert(sizeof(T.lfast) >= 320, "the code lengths are staged in the literal table's storage");
     for (;;) {
-        const bool go = st == kHeader;
-        if (go) do {
-            const uint64_t prof_t0 = BSIG_PROF_CLOCK();
-            (void)prof_t0;
-            bool stored = false;
+        // ---- a block's first bits
+        if (st == kHeader) do {
             refill(in);
             last = take(in, 1);
             const uint32_t type = take(in, 2);
@@ -671,8 +856,8 @@ BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, Lane
                 // BAM: only data that does not compress)
                 take(in, in.cnt & 7);
                 refill(in);
-                const uint32_t len = take(in, 16), nlen = take(in, 16);
-                if ((len ^ 0xFFFFu) != nlen) { err = ERR_STORED; break; }
+                const uint32_t len = take(in, 16), nl = take(in, 16);
+                if ((len ^ 0xFFFFu) != nl) { err = ERR_STORED; break; }
                 // bytes still in the bit buffer belong to the raw data
                 const uint8_t *src = in.p - (in.cnt >> 3);
                 if (src + len > in.end) { err = ERR_INPUT; break; }
@@ -688,105 +873,138 @@ BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, Lane
                 op += len;
                 in.p = src + len; in.buf = 0; in.cnt = 0;
                 request(in);
-                stored = true;
-            } else if (type == 3) {
-                err = ERR_CODE;
-                break;
-            } else {
-                if (type == 1) {
-                    // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
-                    auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
-                    auto fd = [](int) { return 5; };
-                    construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl, lit_offs, lit_next);
-                    construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
-                } else {
-                    const int nlen = (int)take(in, 5) + 257, ndist = (int)take(in, 5) + 1, ncode = (int)take(in, 4) + 4;
-                    if (nlen > 286 || ndist > 30) { err = ERR_TABLE; break; }
-                    // the code-length code: its 19 lengths (3 bits each, in the order of RFC 1951, 3.2.7) in one register
-                    uint64_t clw = 0;
-                    for (int k = 0; k < ncode; ++k) {
-                        if (in.cnt < 8) refill(in);
-                        clw |= (uint64_t)take(in, 3) << (3 * cl_order(k));
-                    }
-                    Counts cc;
-                    // Its codes are at most 7 bits long, so a 7-bit table answers every one of them: it is built in the
-                    // hot symbols' LDS (128 bytes, rewritten with the literal/length table below).  (The symbols are
-                    // sorted into ds as well -- free until the distance code is built -- for builds with fewer hot symbols.)
-                    constexpr bool kClTable = kHotSyms >= 128;
-                    if (!construct<kClTable ? 7 : 0>(cc, Fast8{kClTable ? T.lsym_hot : nullptr}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); })) {
-                        err = ERR_TABLE;
-                        break;
-                    }
-                    // literal/length + distance code lengths, run-length coded.  They are collected in the first-level
-                    // literal table's LDS (free until that table is rebuilt below) and copied to the scratch in one go:
-                    // a store per length to global memory made every wait of this loop -- each refill's -- a wait for
-                    // the stores before it (2,000 cycles per code length: 630,000 of a header's 1.2 million).
-                    int idx = 0, prev_len = 0;
-                    uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
-                    uint8_t *ll_near = reinterpret_cast<uint8_t *>(T.lfast);
-                    static_assert(sizeof(T.lfast) >= 320, "the code lengths are staged in the literal table's storage");
-                    // (zeroed first: the runs of unused symbols -- codes 17 and 18, up to 138 lengths each, and every
-                    // lane of a wave waits for the longest -- then only move the index)
-                    for (int k = 0; k < 320 / 4; ++k) reinterpret_cast<uint32_t *>(T.lfast)[k] = 0;
-                    while (idx < nlen + ndist) {
-                        if (in.cnt < 24) refill(in);                  // 15 bits of code + 7 of repeat count
-                        int s;
-                        if (kClTable) {
-                            const uint32_t e = T.lsym_hot[in.buf & 127u];
-                            if (!e) { err = ERR_CODE; break; }
-                            in.buf >>= (e & 7u);
-                            in.cnt -= (int)(e & 7u);
-                            s = (int)(e >> 3);
-                        } else {
-                            s = decode_walk(in, cc, ds);
-                        }
-                        if (s < 0) { err = ERR_CODE; break; }
-                        if (s < 16) {
-                            ll_near[idx++] = (uint8_t)s;
-                            prev_len = s;
-                        } else {
-                            int prev = 0, rep;
-                            if (s == 16) {
-                                if (idx == 0) { err = ERR_TABLE; break; }
-                                prev = prev_len;
-                                rep = 3 + (int)take(in, 2);
-                            } else if (s == 17) {
-                                rep = 3 + (int)take(in, 3);
-                            } else {
-                                rep = 11 + (int)take(in, 7);
-                            }
-                            if (idx + rep > nlen + ndist) { err = ERR_TABLE; break; }
-                            if (prev) {
-                                while (rep--) ll_near[idx++] = (uint8_t)prev;      // (code 16: at most six)
-                            } else {
-                                idx += rep;
-                            }
-                            prev_len = prev;
-                        }
-                        if (overrun(in)) { err = ERR_INPUT; break; }
-                    }
-                    if (err) break;
-                    for (int k = 0; k < nlen + ndist; k += 8) store64(ll + k, load64(ll_near + k));      // (<= 320 bytes either side)
-                    {
-                        LenReader eob(ll + 256);
-                        if (eob(0) == 0) { err = ERR_TABLE; break; }  // no end-of-block code
-                    }
-                    if (!construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next)) { err = ERR_TABLE; break; }
-                    if (!construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen))) { err = ERR_TABLE; break; }
-                }
-
-                lws = walk_start<kLFast>(lc);
-                dws = walk_start<kDFast>(dc);
-                BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
-            }
-            if (stored) {
                 if (overrun(in)) { err = ERR_INPUT; break; }
                 st = last ? kEnd : kHeader;
+            } else if (type == 3) {
+                err = ERR_CODE;
+            } else if (type == 1) {
+                fixed = true;
+                nlen = 288; ndist = 30;
+                st = kWantTabs;
             } else {
-                st = kSyms;
+                fixed = false;
+                nlen = (int)take(in, 5) + 257; ndist = (int)take(in, 5) + 1;
+                const int ncode = (int)take(in, 4) + 4;
+                if (nlen > 286 || ndist > 30) { err = ERR_TABLE; break; }
+                // the code-length code: its 19 lengths (3 bits each, in the order of RFC 1951, 3.2.7) in one register
+                clw = 0;
+                for (int k = 0; k < ncode; ++k) {
+                    if (in.cnt < 8) refill(in);
+                    clw |= (uint64_t)take(in, 3) << (3 * cl_order(k));
+                }
+                st = kWantCl;
             }
         } while (0);
         if (err) st = kEnd;
+        // ---- the code-length code's table: 7 bits answer every one of its codes; it is built in the hot symbols' LDS
+        // (128 bytes, rewritten with the literal/length table below)
+        static_assert(kHotSyms >= 128, "the code-length code's 7-bit table lives in the hot symbols' storage");
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (uint64_t need = __ballot(st == kWantCl); need; need &= need - 1) {
+            const int L = __ffsll((unsigned long long)need) - 1;
+            const uint64_t clwL = (uint64_t)(uint32_t)__shfl((int)(uint32_t)clw, L) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(clw >> 32), L) << 32;
+            LaneTables *TL = reinterpret_cast<LaneTables *>(reinterpret_cast<uint8_t *>(&T) + (L - hx) * (int)lane_stride);
+            const bool ok = coop_cl_table<W>(clwL, hx, TL);
+            if (hx == L) { if (ok) st = kLens; else { err = ERR_TABLE; st = kEnd; } }
+        }
+#else
+        if (st == kWantCl) {
+            Counts cc;
+            if (construct<7>(cc, Fast8{T.lsym_hot}, ds, 19, [&](int i) { return (int)((clw >> (3 * i)) & 7ull); })) st = kLens;
+            else { err = ERR_TABLE; st = kEnd; }
+        }
+#endif
+        if (st == kLens) do {
+            // literal/length + distance code lengths, run-length coded.  They are collected in the first-level
+            // literal table's LDS (free until that table is rebuilt below): a store per length to global memory made
+            // every wait of this loop -- each refill's -- a wait for the stores before it (2,000 cycles per code length).
+            int idx = 0, prev_len = 0;
+            // (zeroed first: the runs of unused symbols -- codes 17 and 18, up to 138 lengths each, and every
+            // lane of a wave waits for the longest -- then only move the index)
+            for (int k = 0; k < 320 / 4; ++k) reinterpret_cast<uint32_t *>(T.lfast)[k] = 0;
+            while (idx < nlen + ndist) {
+                if (in.cnt < 24) refill(in);                  // 15 bits of code + 7 of repeat count
+                const uint32_t e = T.lsym_hot[in.buf & 127u];
+                if (!e) { err = ERR_CODE; break; }
+                in.buf >>= (e & 7u);
+                in.cnt -= (int)(e & 7u);
+                const int s = (int)(e >> 3);
+                if (s < 16) {
+                    ll_near[idx++] = (uint8_t)s;
+                    prev_len = s;
+                } else {
+                    int prev = 0, rep;
+                    if (s == 16) {
+                        if (idx == 0) { err = ERR_TABLE; break; }
+                        prev = prev_len;
+                        rep = 3 + (int)take(in, 2);
+                    } else if (s == 17) {
+                        rep = 3 + (int)take(in, 3);
+                    } else {
+                        rep = 11 + (int)take(in, 7);
+                    }
+                    if (idx + rep > nlen + ndist) { err = ERR_TABLE; break; }
+                    if (prev) {
+                        while (rep--) ll_near[idx++] = (uint8_t)prev;      // (code 16: at most six)
+                    } else {
+                        idx += rep;
+                    }
+                    prev_len = prev;
+                }
+                if (overrun(in)) { err = ERR_INPUT; break; }
+            }
+            if (err) break;
+            if (ll_near[256] == 0) { err = ERR_TABLE; break; }            // no end-of-block code
+            st = kWantTabs;
+        } while (0);
+        if (err) st = kEnd;
+        // ---- the literal/length and the distance code's tables
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (uint64_t need = __ballot(st == kWantTabs); need; need &= need - 1) {
+            const int L = __ffsll((unsigned long long)need) - 1;
+            const uint64_t prof_t0 = BSIG_PROF_CLOCK();
+            (void)prof_t0;
+            LaneTables *TL = reinterpret_cast<LaneTables *>(reinterpret_cast<uint8_t *>(&T) + (L - hx) * (int)lane_stride);
+            uint8_t *lensL = lens + (L - hx) * kLensBytes;
+            Counts c1, c2;
+            uint64_t hh[kHotSyms / 64], dw[3];
+            int base = 0;
+            const bool ok = coop_tables<W>(hx, TL, lensL, __shfl(nlen, L), __shfl(ndist, L), __shfl((int)fixed, L) != 0, c1, c2, hh, dw, base);
+            if (hx == L) {
+                if (ok) {
+                    lc = c1; dc = c2;
+                    for (int k = 0; k < kHotSyms / 64; ++k) ls.hot_hi[k] = hh[k];
+                    ls.base = base;
+                    ds.w[0] = dw[0]; ds.w[1] = dw[1]; ds.w[2] = dw[2];
+                    lws = walk_start<kLFast>(lc);
+                    dws = walk_start<kDFast>(dc);
+                    st = kSyms;
+                    BSIG_PROF(prof->hdrs++; prof->hdr_cycles += BSIG_PROF_CLOCK() - prof_t0);
+                } else { err = ERR_TABLE; st = kEnd; }
+            }
+        }
+#else
+        if (st == kWantTabs) {
+            // (the slots of the literal/length table's construction: the distance table's 64 bytes, rebuilt right after it)
+            static_assert(sizeof(T.dfast) >= 64, "the distance table's LDS doubles as the literal table's construction slots");
+            const SlotsMem lit_offs{reinterpret_cast<uint16_t *>(T.dfast)}, lit_next{reinterpret_cast<uint16_t *>(T.dfast) + 16};
+            bool ok;
+            if (fixed) {
+                // fixed code: lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287); 30 distances of 5 bits
+                auto fl = [](int i) { return i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8; };
+                auto fd = [](int) { return 5; };
+                ok = construct<kLFast>(lc, Fast16{T.lfast}, ls, 288, fl, lit_offs, lit_next) && construct<kDFast>(dc, Fast8{T.dfast}, ds, 30, fd);
+            } else {
+                // (the lengths leave the literal table's storage before that table is built in it)
+                uint8_t *ll = lens + 32;                          // up to 286 + 30 entries (kLensBytes)
+                for (int k = 0; k < nlen + ndist; k += 8) store64(ll + k, load64(ll_near + k));      // (<= 320 bytes either side)
+                ok = construct<kLFast>(lc, Fast16{T.lfast}, ls, nlen, LenReader(ll), lit_offs, lit_next) &&
+                     construct<kDFast>(dc, Fast8{T.dfast}, ds, ndist, LenReader(ll + nlen));
+            }
+            if (ok) { lws = walk_start<kLFast>(lc); dws = walk_start<kDFast>(dc); st = kSyms; }
+            else { err = ERR_TABLE; st = kEnd; }
+        }
+#endif
         // ---- the compressed data of a block: per turn ONE token -- a run of up to six literals the first-level table
         // knows and/or the match behind them.  The only memory a turn touches is the input word requested a turn ahead
         // (and, rarely, a cold symbol), so a turn is the decode chain and nothing else. ----
@@ -894,8 +1112,13 @@ BSIG_HD int produce(const uint8_t *in_p, uint32_t in_len, uint32_t out_len, Lane
                 else st = last ? kEnd : kHeader;
             }
         } while (0);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__all(st == kEnd)) break;          // (a lane that is done stays: the others' tables need it)
+#else
         if (st == kEnd) break;
+#endif
     }
+    if (!present) return OK;
     if (err == OK && op != out_len) err = ERR_OUTPUT;
     while (!ch.ready()) BSIG_SLEEP_IF_ALL(true);
     ch.send(Token{0, kTokValid | kTokEnd | (uint32_t)err << kTokErrShift});
