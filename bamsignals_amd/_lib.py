@@ -149,6 +149,12 @@ def load():
     lib.bsig_segmap_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bsig_segmap_free.argtypes = [C.c_void_p]
     lib.bsig_segmap_free.restype = None
+    lib.bsig_narrow_bytes.argtypes = [C.c_int64, C.c_int64]
+    lib.bsig_narrow_bytes.restype = C.c_int64
+    lib.bsig_narrow_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    lib.bsig_narrow_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.bsig_segmap_run_narrow.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.bsig_segmap_narrow_overflowed.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.bsig_last_call_timing.argtypes = [C.POINTER(C.c_double)]
     lib.bsig_last_call_timing.restype = None
     lib.bsig_last_call_timing_ex.argtypes = [C.POINTER(C.c_double), C.c_int32]

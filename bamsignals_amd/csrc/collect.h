@@ -54,6 +54,11 @@ bool exchange_root_reads_peers(ExchangeUse &use);
 // drops the registry's references (communicators in use by a running call live until it returns)
 void exchange_close_all();
 
+// a result shard as two bits a cell + a list of exceptions (collect.hip): message size, packing, placement
+int64_t narrow_message_bytes(int64_t n_cells, int64_t cap);
+hipError_t launch_narrow_pack(const int32_t *src, int64_t n_cells, void *msg, int64_t cap, hipStream_t st);
+hipError_t launch_place_narrow(int64_t n_seg, const void *msg, int64_t n_cells, int64_t cap, const int64_t *src_off, int32_t *dst,
+                               const int64_t *dst_off, const int64_t *which, int *overflow, hipStream_t st);
 // Segment k of src (src_off[k] .. src_off[k+1]) goes to dst at dst_off[which[k]]: bsig_scatter_segments
 // on the device (all pointers are device pointers), so that gathered shards are put into the caller's
 // range order in HBM and leave for the host in ONE copy.

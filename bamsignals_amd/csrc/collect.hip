@@ -322,6 +322,150 @@ __global__ __launch_bounds__(256) void k_place_segments(int64_t n, const int32_t
 }
 }  // namespace
 
+// ---- a narrow wire for result shards (round 5) ----------------------------------------------------------------------
+// The cells of a per-base profile are almost all 0, 1 or 2 (the north star's reads: 0.2 per base), and a gather of
+// int32 shards into ONE GPU is bounded by that GPU's ingress (7 links x ~55 GB/s against 5 TB/s of local writes):
+// 700 MB of 800 travel for an 8-GPU north-star step.  A shard therefore travels as two bits a cell -- the value, or 3 =
+// "see the exception list" -- plus a list of (cell, value) pairs for everything else (any int32: negative coverage
+// differences, counts of 3 and more):  [0] number of exceptions, [1..3] 0, [4 .. 4 + ceil(n / 16)) codes,
+// then `cap` pairs.  Lossless; the sizes are fixed by (n, cap), so every rank's message has the same length.
+namespace {
+constexpr int kNarrowHead = 4;               // dwords in front of the codes
+// One wave codes 1,024 cells a turn: four coalesced 16-byte loads a lane (lane l of load j holds cells 256 j + 4 l ..+3 =
+// one byte of codes; four neighbouring lanes' bytes make a word, put together with two DPP-sized shuffles).  Exceptions
+// are rare and scattered (one in ~900 cells of a north-star profile), so one atomic on the message's counter per
+// exception -- 230,000 on ONE address a launch -- was what the first form of this kernel spent its time on (2.5 ms for
+// 800 MB): a wave keeps its exceptions in a list of its own in LDS and claims room in the message for a whole list at
+// a time (when the list is half full, and when the wave is done).
+constexpr int kNarrowList = 256;             // entries of a wave's list in LDS
+__global__ __launch_bounds__(256) void k_narrow_pack(const int32_t *__restrict__ src, int64_t n, uint32_t *__restrict__ msg,
+                                                     int64_t n_words, int64_t cap)
+{
+    __shared__ uint2 lst[4][kNarrowList];
+    __shared__ uint32_t cnt[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint2 *exc = reinterpret_cast<uint2 *>(msg + kNarrowHead + n_words);
+    if (lane == 0) cnt[wv] = 0;
+    auto flush = [&]() {                     // (wave-uniform: every lane of the wave comes here together)
+        const uint32_t have = min(cnt[wv], (uint32_t)kNarrowList);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned int *>(msg), have);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (uint32_t i = lane; i < have; i += 64)
+            if ((int64_t)(base + i) < cap) exc[base + i] = lst[wv][i];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) cnt[wv] = 0;
+    };
+    const int64_t n_turns = (n + 1023) >> 10;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wv; t < n_turns; t += (int64_t)gridDim.x * 4) {
+        const int64_t c0 = t << 10;
+        int4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + 256 * j + 4 * lane;
+            if (c + 4 <= n) v[j] = *reinterpret_cast<const int4 *>(src + c);      // (src is 16-B aligned, c a multiple of 4)
+            else v[j] = make_int4(c < n ? src[c] : 0, c + 1 < n ? src[c + 1] : 0, c + 2 < n ? src[c + 2] : 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + 256 * j + 4 * lane;
+            uint32_t byte = 0;
+            auto one = [&](int32_t x, int k) {
+                const uint32_t code = (uint32_t)x < 3u ? (uint32_t)x : 3u;
+                byte |= code << (2 * k);
+                if (code == 3u) {
+                    const uint32_t slot = atomicAdd(&cnt[wv], 1u);
+                    if (slot < (uint32_t)kNarrowList) lst[wv][slot] = make_uint2((uint32_t)(c + k), (uint32_t)x);
+                    else {                   // (a turn with more exceptions than the list holds: one by one)
+                        const uint32_t g = atomicAdd(reinterpret_cast<unsigned int *>(msg), 1u);
+                        if ((int64_t)g < cap) exc[g] = make_uint2((uint32_t)(c + k), (uint32_t)x);
+                    }
+                }
+            };
+            one(v[j].x, 0); one(v[j].y, 1); one(v[j].z, 2); one(v[j].w, 3);
+            uint32_t two = byte | (uint32_t)__shfl_down((int)byte, 1) << 8;
+            two |= (uint32_t)__shfl_down((int)two, 2) << 16;
+            const int64_t w = (c0 >> 4) + 16 * j + (lane >> 2);
+            if ((lane & 3) == 0 && w < n_words) msg[kNarrowHead + w] = two;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (cnt[wv] > (uint32_t)kNarrowList / 2) flush();
+    }
+    if (cnt[wv] > 0) flush();
+}
+
+// segment k of the coded source -> dst at dst_off[which[k]] (one wave per segment; exceptions come as 3 and are patched below)
+__global__ __launch_bounds__(256) void k_place_narrow(int64_t n, const uint32_t *__restrict__ codes, const int64_t *__restrict__ src_off,
+                                                      int32_t *__restrict__ dst, const int64_t *__restrict__ dst_off,
+                                                      const int64_t *__restrict__ which)
+{
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t a = src_off[k], len = src_off[k + 1] - a;
+    int32_t *dp = dst + dst_off[which[k]];
+    const int head = (int)((4 - ((uintptr_t)dp >> 2)) & 3);             // cells in front of the first 16-B aligned one
+    for (int64_t i = lane; i < head && i < len; i += 64) { const int64_t c = a + i; dp[i] = (int32_t)((codes[c >> 4] >> (2 * (c & 15))) & 3u); }
+    const int64_t nv = len > head ? (len - head) >> 2 : 0;
+    for (int64_t q = lane; q < nv; q += 64) {
+        const int64_t c = a + head + 4 * q;                              // four cells: at most two code words
+        // (cells c .. c+3 are eight bits from bit 2 * (c & 15) of the 64 bits "this word, then the word of cell c + 3" --
+        // the same word twice unless the four cells straddle two)
+        const uint64_t two = (uint64_t)codes[c >> 4] | (uint64_t)codes[(c + 3) >> 4] << 32;
+        const uint32_t bits = (uint32_t)(two >> (2u * (uint32_t)(c & 15)));
+        reinterpret_cast<int4 *>(dp + head)[q] = make_int4((int)(bits & 3u), (int)((bits >> 2) & 3u), (int)((bits >> 4) & 3u), (int)((bits >> 6) & 3u));
+    }
+    for (int64_t i = head + 4 * nv + lane; i < len; i += 64) { const int64_t c = a + i; dp[i] = (int32_t)((codes[c >> 4] >> (2 * (c & 15))) & 3u); }
+}
+
+// the exceptions of a coded shard, each put at its cell's place: the segment of a source cell by binary search
+__global__ __launch_bounds__(256) void k_patch_narrow(const uint32_t *__restrict__ msg, int64_t n_words, int64_t cap, int64_t n_seg,
+                                                      const int64_t *__restrict__ src_off, int32_t *__restrict__ dst,
+                                                      const int64_t *__restrict__ dst_off, const int64_t *__restrict__ which,
+                                                      int *__restrict__ overflow)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_exc = (int64_t)msg[0];
+    if (e == 0 && n_exc > cap) *overflow = 1;                            // (the sender had more than its list holds: the result is wrong)
+    if (e >= n_exc || e >= cap) return;
+    const uint2 x = reinterpret_cast<const uint2 *>(msg + kNarrowHead + n_words)[e];
+    const int64_t c = (int64_t)x.x;
+    int64_t lo = 0, hi = n_seg;                                          // the last segment with src_off <= c
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (src_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    if (c < src_off[lo] || c >= src_off[lo + 1]) return;                // (a cell of the padding: not in any segment)
+    dst[dst_off[which[lo]] + (c - src_off[lo])] = (int32_t)x.y;
+}
+}  // namespace
+
+int64_t narrow_words(int64_t n_cells) { return (n_cells + 15) / 16; }
+int64_t narrow_message_bytes(int64_t n_cells, int64_t cap) { return 4 * (kNarrowHead + narrow_words(n_cells) + 2 * std::max<int64_t>(cap, 0)); }
+
+hipError_t launch_narrow_pack(const int32_t *src, int64_t n_cells, void *msg, int64_t cap, hipStream_t st)
+{
+    const int64_t nw = narrow_words(n_cells);
+    hipError_t e = hipMemsetAsync(msg, 0, 4 * kNarrowHead, st);
+    if (e != hipSuccess || nw == 0) return e;
+    const int64_t turns = (n_cells + 1023) >> 10;                     // a wave's turn = 1,024 cells; 2,048 blocks of 4 waves at most
+    hipLaunchKernelGGL(k_narrow_pack, dim3((unsigned)std::min<int64_t>((turns + 3) / 4, 2048)), dim3(256), 0, st, src, n_cells, (uint32_t *)msg, nw,
+                       std::max<int64_t>(cap, 0));
+    return hipGetLastError();
+}
+
+hipError_t launch_place_narrow(int64_t n_seg, const void *msg, int64_t n_cells, int64_t cap, const int64_t *src_off, int32_t *dst,
+                               const int64_t *dst_off, const int64_t *which, int *overflow, hipStream_t st)
+{
+    if (n_seg <= 0) return hipSuccess;
+    const int64_t nw = narrow_words(n_cells);
+    const uint32_t *m = (const uint32_t *)msg;
+    hipLaunchKernelGGL(k_place_narrow, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, st, n_seg, m + kNarrowHead, src_off, dst, dst_off, which);
+    hipLaunchKernelGGL(k_patch_narrow, dim3((unsigned)((std::max<int64_t>(cap, 1) + 255) / 256)), dim3(256), 0, st, m, nw, std::max<int64_t>(cap, 0), n_seg,
+                       src_off, dst, dst_off, which, overflow);
+    return hipGetLastError();
+}
+
 namespace { __global__ void k_warm_collect() {} }
 hipError_t warm_collect_module(hipStream_t st)
 {

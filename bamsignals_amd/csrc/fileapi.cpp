@@ -1295,6 +1295,8 @@ struct bsig_segmap {
     bsig_ctx *ctx = nullptr;
     int64_t n = 0;
     int64_t *d_src_off = nullptr, *d_dst_off = nullptr, *d_which = nullptr;
+    int *d_overflow = nullptr;      // set by a narrow run whose sender had more exceptions than its list holds
+    int64_t src_cells = 0;          // src_off[n]: a narrow message must code at least this many cells
 };
 
 int bsig_segmap_create(bsig_ctx *ctx, int64_t n, const int64_t *src_off, int64_t n_dst, const int64_t *dst_off,
@@ -1312,11 +1314,14 @@ int bsig_segmap_create(bsig_ctx *ctx, int64_t n, const int64_t *src_off, int64_t
     std::unique_ptr<bsig_segmap> M(new bsig_segmap);
     M->ctx = ctx;
     M->n = n;
+    M->src_cells = n ? src_off[n] : 0;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     hipError_t e = hipMalloc((void **)&M->d_src_off, (size_t)(n + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&M->d_dst_off, (size_t)(n_dst + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&M->d_which, (size_t)std::max<int64_t>(n, 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&M->d_overflow, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(M->d_overflow, 0, sizeof(int), st);
     const int64_t zero = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(M->d_src_off, n ? src_off : &zero, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(M->d_dst_off, dst_off ? dst_off : &zero, (size_t)(n_dst + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
@@ -1340,10 +1345,58 @@ int bsig_segmap_run(bsig_segmap *M, const int32_t *src_dev, int32_t *dst_dev)
     return BSIG_OK;
 }
 
+int64_t bsig_narrow_bytes(int64_t n_cells, int64_t cap)
+{
+    return n_cells < 0 || cap < 0 ? 0 : bsig::narrow_message_bytes(n_cells, cap);
+}
+
+int bsig_narrow_pack(bsig_ctx *ctx, const int32_t *src_dev, int64_t n_cells, void *msg_dev, int64_t cap)
+{
+    if (!ctx || !msg_dev || (n_cells > 0 && !src_dev) || n_cells < 0 || cap < 0) return fail(BSIG_ERR_ARG, "bad argument to bsig_narrow_pack");
+    if (((uintptr_t)src_dev & 15) != 0 || ((uintptr_t)msg_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device buffers must be 16-byte aligned");
+    if (n_cells > (int64_t)UINT32_MAX) return fail(BSIG_ERR_ARG, "a narrow message holds at most 2^32 - 1 cells (an exception names its cell in 32 bits)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(bsig::launch_narrow_pack(src_dev, n_cells, msg_dev, cap, ctx->stream));
+    return BSIG_OK;
+}
+
+int bsig_narrow_count(bsig_ctx *ctx, const void *msg_dev, int64_t *n_exceptions)
+{
+    if (!ctx || !msg_dev || !n_exceptions) return fail(BSIG_ERR_ARG, "NULL argument to bsig_narrow_count");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t k = 0;
+    HIP_TRY(hipMemcpyAsync(&k, msg_dev, sizeof k, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *n_exceptions = (int64_t)k;
+    return BSIG_OK;
+}
+
+int bsig_segmap_run_narrow(bsig_segmap *M, const void *msg_dev, int64_t n_cells, int64_t cap, int32_t *dst_dev)
+{
+    if (!M) return fail(BSIG_ERR_ARG, "segment map is NULL");
+    if (M->n == 0) return BSIG_OK;
+    if (!msg_dev || !dst_dev || n_cells < 0 || cap < 0) return fail(BSIG_ERR_ARG, "bad argument to bsig_segmap_run_narrow");
+    if (n_cells < M->src_cells) return fail(BSIG_ERR_ARG, "the message codes %lld cells, the map's segments span %lld", (long long)n_cells, (long long)M->src_cells);
+    if (((uintptr_t)msg_dev & 15) != 0) return fail(BSIG_ERR_ARG, "device buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(M->ctx->device));
+    HIP_TRY(bsig::launch_place_narrow(M->n, msg_dev, n_cells, cap, M->d_src_off, dst_dev, M->d_dst_off, M->d_which, M->d_overflow, M->ctx->stream));
+    return BSIG_OK;
+}
+
+int bsig_segmap_narrow_overflowed(bsig_segmap *M, int *overflowed)
+{
+    if (!M || !overflowed) return fail(BSIG_ERR_ARG, "NULL argument to bsig_segmap_narrow_overflowed");
+    HIP_TRY(hipSetDevice(M->ctx->device));
+    HIP_TRY(hipMemcpyAsync(overflowed, M->d_overflow, sizeof(int), hipMemcpyDeviceToHost, M->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(M->ctx->stream));
+    return BSIG_OK;
+}
+
 void bsig_segmap_free(bsig_segmap *M)
 {
     if (!M) return;
     (void)hipSetDevice(M->ctx->device);
+    if (M->d_overflow) (void)hipFree(M->d_overflow);
     if (M->d_src_off) (void)hipFree(M->d_src_off);
     if (M->d_dst_off) (void)hipFree(M->d_dst_off);
     if (M->d_which) (void)hipFree(M->d_which);

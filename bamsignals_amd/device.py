@@ -320,6 +320,16 @@ class SegmentMap:
     def run(self, src_ptr, dst_ptr):
         _lib.check(self._lib.bsig_segmap_run(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr)))
 
+    def run_narrow(self, msg_ptr, n_cells, cap, dst_ptr):
+        """``run`` from a shard that travelled as a narrow message (``narrow_pack``): two bits a cell + exceptions."""
+        _lib.check(self._lib.bsig_segmap_run_narrow(self._h, C.c_void_p(msg_ptr), int(n_cells), int(cap), C.c_void_p(dst_ptr)))
+
+    def narrow_overflowed(self):
+        """Did any narrow message so far hold more exceptions than its list had room for?  (Synchronises.)"""
+        v = C.c_int(0)
+        _lib.check(self._lib.bsig_segmap_narrow_overflowed(self._h, C.byref(v)))
+        return bool(v.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.bsig_segmap_free(self._h)
@@ -327,6 +337,24 @@ class SegmentMap:
 
     def __del__(self):
         self.close()
+
+
+def narrow_bytes(n_cells, cap):
+    """Bytes of the narrow message of a shard of ``n_cells`` cells with room for ``cap`` exceptions (bsig_narrow_bytes)."""
+    return int(_lib.load().bsig_narrow_bytes(int(n_cells), int(cap)))
+
+
+def narrow_pack(ctx, src_ptr, n_cells, msg_ptr, cap):
+    """Pack the int32 shard at ``src_ptr`` (device, 16-B aligned) into the narrow message at ``msg_ptr``: asynchronous, on
+    the context's stream."""
+    _lib.check(_lib.load().bsig_narrow_pack(ctx._h, C.c_void_p(src_ptr), int(n_cells), C.c_void_p(msg_ptr), int(cap)))
+
+
+def narrow_count(ctx, msg_ptr):
+    """Exceptions of the packed shard at ``msg_ptr`` (synchronises): what ``cap`` has to hold."""
+    v = C.c_int64(0)
+    _lib.check(_lib.load().bsig_narrow_count(ctx._h, C.c_void_p(msg_ptr), C.byref(v)))
+    return int(v.value)
 
 
 def layout(length, binsize, ss):

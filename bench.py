@@ -536,7 +536,8 @@ class Workload:
             self.shard_offs = [[layout(g["len"][r::world], cfg["args"].get("binsize", 1), ss) for r in range(world)] for g in self.full] \
                 if self.gathered else None
             self.pad = max(4, max(int(o[-1]) for offs in self.shard_offs for o in offs)) if self.gathered else 0
-            self.outs = [torch.empty(max(p.cells, 4, self.pad), dtype=torch.int32, device="cuda") for p in self.plans]
+            # (zeros: the cells between a shard's end and the common message length travel too)
+            self.outs = [torch.zeros(max(p.cells, 4, self.pad), dtype=torch.int32, device="cuda") for p in self.plans]
             for b in range(nb):                      # every result buffer is produced at least once
                 self.plans[b].run_device(self.outs[b].data_ptr())
             self.full_plans, self.full_outs = self.plans, self.outs
@@ -547,20 +548,37 @@ class Workload:
         self.bufs = self.maps = None
         torch.cuda.synchronize()
 
-    def setup_gather(self, dist, backend):
+    def setup_gather(self, dist, backend, wire="int32", host_group=None):
         """N > 1: rank 0's receive buffers (one per peer), the whole job's result buffer of every batch, and the
         segment maps that put shard r's ranges at their place in the caller's order (range i of the batch is range
         i // world of shard i % world)."""
         import torch
 
         from bamsignals_amd.device import SegmentMap, layout
-        self.dist, self.backend = dist, backend
+        self.dist, self.backend, self.wire = dist, backend, wire
+        self.cap = 0
+        if wire == "narrow":
+            # The narrow wire's exception lists must have room: a plan's result is a function of plan and reads, so the
+            # count of this rank's shard of every batch (all of which have been run once) is exact; every rank sends
+            # messages of ONE length, sized by the largest shard and the longest list of any rank and batch.
+            from bamsignals_amd.device import narrow_bytes, narrow_count, narrow_pack
+            probe = torch.empty(narrow_bytes(self.pad, 0) // 4, dtype=torch.int32, device="cuda")
+            worst = 0
+            for b in range(self.nb):
+                narrow_pack(self.ctx, self.outs[b].data_ptr(), self.pad, probe.data_ptr(), 0)
+                worst = max(worst, narrow_count(self.ctx, probe.data_ptr()))
+            allw = [None] * self.world
+            dist.all_gather_object(allw, int(worst), group=host_group)
+            self.cap = int(max(allw))
+            self.msg_words = narrow_bytes(self.pad, self.cap) // 4
+            self.msg = [torch.empty(self.msg_words, dtype=torch.int32, device="cuda") for _ in range(self.nb)]
+            del probe
         if self.rank != 0:
             return
         cfg, world = self.cfg, self.world
         ss = bool(cfg["args"].get("ss", False))
         n = len(self.full[0]["rid"])
-        self.bufs = [torch.empty(self.pad, dtype=torch.int32, device="cuda") for _ in range(world)]
+        self.bufs = [torch.empty(self.msg_words if wire == "narrow" else self.pad, dtype=torch.int32, device="cuda") for _ in range(world)]
         self.final = [torch.zeros(max(p.cells, 4), dtype=torch.int32, device="cuda") for p in self.full_plans]
         self.maps = []
         for b in range(self.nb):
@@ -568,7 +586,8 @@ class Workload:
             assert int(off_all[-1]) == self.full_plans[b].cells
             self.maps.append([SegmentMap(self.ctx, self.shard_offs[b][r], off_all, np.arange(r, n, world, dtype=np.int64))
                               for r in range(world)])
-        self.gather_bytes = [int(sum(int(o[-1]) for o in offs[1:]) * 4) for offs in self.shard_offs]
+        self.gather_bytes = [int(sum(int(o[-1]) for o in offs[1:]) * 4) if wire != "narrow" else 4 * self.msg_words * (world - 1)
+                             for offs in self.shard_offs]
         torch.cuda.synchronize()
 
     def strong_step(self, q, ev=None):
@@ -581,26 +600,36 @@ class Workload:
         self.plans[b].run_device(self.outs[b].data_ptr())
         if ev:
             ev[1].record()
+        narrow = self.wire == "narrow"
+        if narrow:
+            from bamsignals_amd.device import narrow_pack
+            narrow_pack(self.ctx, self.outs[b].data_ptr(), self.pad, self.msg[b].data_ptr(), self.cap)
+        send = self.msg[b] if narrow else self.outs[b][:self.pad]
+        if ev:
+            ev[2].record()
         if self.backend == "nccl":
             # torch.distributed.gather over RCCL: grouped ncclSend / ncclRecv, every peer straight to the root over its
             # own link (the root's own shard is a copy on the device)
-            dist.gather(self.outs[b][:self.pad], self.bufs if root else None, dst=0)
+            dist.gather(send, self.bufs if root else None, dst=0)
         else:
             # gloo (the code path on a box with fewer GPUs than ranks): through host memory
             torch.cuda.synchronize()
-            mine = self.outs[b][:self.pad].cpu()
+            mine = send.cpu()
             got = [torch.empty_like(mine) for _ in range(self.world)] if root else None
             dist.gather(mine, got, dst=0)
             if root:
                 for r in range(self.world):
                     self.bufs[r].copy_(got[r])
         if ev:
-            ev[2].record()
+            ev[3].record()
         if root:
             for r in range(self.world):
-                self.maps[b][r].run(self.bufs[r].data_ptr(), self.final[b].data_ptr())
+                if narrow:
+                    self.maps[b][r].run_narrow(self.bufs[r].data_ptr(), self.pad, self.cap, self.final[b].data_ptr())
+                else:
+                    self.maps[b][r].run(self.bufs[r].data_ptr(), self.final[b].data_ptr())
         if ev:
-            ev[3].record()
+            ev[4].record()
 
     def run_steps(self, k, full=False):
         if self.gathered and not full:
@@ -639,16 +668,17 @@ class Workload:
 
     def phases(self, steps, stream, barrier):
         """After the timed region (N > 1): the same steps once more with HIP events between their parts; returns
-        this rank's mean (kernel, gather, place) in ms -- rank 0's say where a step's time goes, and the kernel part
-        is the launch duration the roofline figure is quoted on."""
+        this rank's mean (kernel, pack, gather, place) in ms -- rank 0's say where a step's time goes, and the kernel
+        part is the launch duration the roofline figure is quoted on (pack: the narrow wire's bsig_narrow_pack, 0 for
+        the int32 wire)."""
         import torch
         with torch.cuda.stream(stream):
             torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
             for q in range(steps):
                 self.strong_step(q, evs[q])
             torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-            return np.asarray([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
+            return np.asarray([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in evs]).mean(axis=0)
 
     def check_parity(self, oracle_c, seed=0, sample=None):
         """What was just timed against the oracle: EVERY range of every batch, cell by cell (the oracle runs all of
@@ -809,7 +839,7 @@ def strong_block(a, rank, world, stream, ctx, reads, cols, use_dist, dist, cdev,
                        n_gpus=world, ranges_total=n_ranges_total, ranges_per_gpu=len(mine), reads=int(reads.n_reads), steps=steps,
                        timed_region="kernel on the rank's shard + gather of the shards to rank 0 + reassembly in rank 0's HBM",
                        backend=backend, ms_per_step=elapsed / steps * 1e3, value=bases * steps / elapsed / 1e6, unit="Mbases/s",
-                       gather_bytes=int(sum(sizes[1:]) * 4))
+                       gather_bytes=int(sum(sizes[1:]) * 4), wire="int32")
             if ev:
                 ph = np.asarray([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in ev]).mean(axis=0)
                 out["phases_ms_rank0"] = dict(kernel=float(ph[0]), gather=float(ph[1]), place=float(ph[2]))
@@ -918,6 +948,10 @@ def main():
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same steps issued alternately on two streams (informational; off by "
                          "default so that a profiler sees only the one-stream launches the metric is defined on)")
+    ap.add_argument("--wire", default="narrow", choices=["narrow", "int32"],
+                    help="how a rank's result shard travels to rank 0 at N > 1: 'narrow' = two bits a cell + a list of exceptions "
+                         "(bsig_narrow_pack / bsig_segmap_run_narrow: lossless, ~1/15 of the bytes for a per-base profile), "
+                         "'int32' = the cells as they are")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even with one rank (exercises RCCL "
                          "on a 1-GPU box)")
@@ -1005,7 +1039,7 @@ def main():
     if rank != 0:
         w.cols = None                    # (only rank 0 checks against the oracle: the mapped columns can go)
     if gathered:
-        w.setup_gather(dist, a.backend)
+        w.setup_gather(dist, a.backend, a.wire, host_group)
         with torch.cuda.stream(stream):
             for q in range(w.nb):                # every batch's whole result is assembled at least once (all ranks take part)
                 w.strong_step(q)
@@ -1032,12 +1066,13 @@ def main():
         t = torch.tensor([el_r], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
-            phases = dict(steps=ksteps, rank0_ms=dict(kernel=float(ph[0]), gather=float(ph[1]), place=float(ph[2])),
+            phases = dict(steps=ksteps, rank0_ms=dict(kernel=float(ph[0]), pack=float(ph[1]), gather=float(ph[2]), place=float(ph[3])),
                           kernel_ms_by_rank=[p[0] for p in allph],
                           gather_bytes_into_rank0=w.gather_bytes[0],
-                          gather_GBps=(w.gather_bytes[0] / (float(ph[1]) * 1e-3) / 1e9) if ph[1] > 0 else None,
+                          gather_GBps=(w.gather_bytes[0] / (float(ph[2]) * 1e-3) / 1e9) if ph[2] > 0 else None,
                           note="HIP events between the parts of a step, on a second run of the same steps: the launches on the "
-                               "rank's shard, torch.distributed.gather to rank 0, bsig_segmap_run over every rank's shard")
+                               "rank's shard, bsig_narrow_pack (the narrow wire only), torch.distributed.gather to rank 0, "
+                               "bsig_segmap_run[_narrow] over every rank's shard")
             replicas = dict(value=sum(w.step_bases[q % nb] for q in range(ksteps)) * world / float(t.item()) / 1e6, unit="Mbases/s",
                             ms_per_step=float(t.item()) / ksteps * 1e3, steps=ksteps, kernel_ms_rank0=kms_r,
                             what=f"every one of the {world} ranks runs the WHOLE range set by itself, nothing exchanged: {world} "
@@ -1079,6 +1114,8 @@ def main():
     if rank == 0:
         from oracle import oracle_c
         orc, parity = w.check_parity(oracle_c)
+        if gathered and a.wire == "narrow" and any(m.narrow_overflowed() for ms in w.maps for m in ms):
+            raise SystemExit("a narrow message had more exceptions than its list holds: refusing to report a number")
         log(f"parity ok ({parity}); step {kernel_ms * 1e3:.1f} us")
         if not a.no_cpu_baseline and world == 1:          # (the contract: rank 0 at N = 1 only)
             # the oracle (C restatement of overlapAndPileup + Pileupper, single thread) on the
@@ -1140,6 +1177,11 @@ def main():
             "end_to_end": None,
             "parity_checked": parity,
             "pipelined_two_streams": pipelined,
+            "wire": (dict(kind=a.wire, exceptions_room=w.cap, message_bytes=4 * getattr(w, "msg_words", 0) if a.wire == "narrow" else 4 * w.pad,
+                          int32_bytes=4 * w.pad,
+                          what="a rank's shard travels as two bits a cell (0, 1, 2 or 'see the list') + a list of (cell, value) "
+                               "exceptions sized by a first run: lossless; rank 0 widens it while placing it (bsig_segmap_run_narrow)"
+                               if a.wire == "narrow" else "a rank's shard travels as its int32 cells") if gathered else None),
             "step_phases": phases,
             "no_collective": replicas,
             "strong": None,

@@ -388,6 +388,20 @@ typedef struct bsig_segmap bsig_segmap;
 int bsig_segmap_create(bsig_ctx *ctx, int64_t n, const int64_t *src_off, int64_t n_dst, const int64_t *dst_off,
                        const int64_t *which, bsig_segmap **map);
 int bsig_segmap_run(bsig_segmap *map, const int32_t *src_dev, int32_t *dst_dev);
+/* A NARROW WIRE for result shards that travel between GPUs (round 5; the gather of the shards to one GPU is bounded by that
+ * GPU's ingress, and the cells of a per-base profile are almost all 0, 1 or 2): a shard of n_cells int32 cells as a message
+ * of bsig_narrow_bytes(n_cells, cap) bytes -- two bits a cell (the value, or 3 = see the list) and a list of up to `cap`
+ * (cell, value) exceptions; lossless for any int32.  bsig_narrow_pack writes the message on the context's stream (src_dev
+ * and msg_dev 16-B aligned); bsig_narrow_count (synchronises) says how many exceptions a packed shard has -- a plan's result
+ * is a function of plan and reads, so a first run tells the `cap` of every later one; bsig_segmap_run_narrow is
+ * bsig_segmap_run from such a message; bsig_segmap_narrow_overflowed (synchronises) reports whether any message so far had
+ * more exceptions than its list held (its result is then wrong).  Replaces nothing of the reference: each range owns its
+ * output there (ref: src/bamsignals.cpp:164,181,186), which is what makes shards -- and their reassembly -- legal.       */
+int64_t bsig_narrow_bytes(int64_t n_cells, int64_t cap);
+int bsig_narrow_pack(bsig_ctx *ctx, const int32_t *src_dev, int64_t n_cells, void *msg_dev, int64_t cap);
+int bsig_narrow_count(bsig_ctx *ctx, const void *msg_dev, int64_t *n_exceptions);
+int bsig_segmap_run_narrow(bsig_segmap *map, const void *msg_dev, int64_t n_cells, int64_t cap, int32_t *dst_dev);
+int bsig_segmap_narrow_overflowed(bsig_segmap *map, int *overflowed);
 void bsig_segmap_free(bsig_segmap *map);
 
 #ifdef __cplusplus

@@ -26,13 +26,16 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_emit_strong_and_in_process_blocks():
+@pytest.mark.parametrize("wire", ["narrow", "int32"])
+def test_two_ranks_emit_strong_and_in_process_blocks(wire):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BAMSIGNALS_DEVICES", "BAMSIGNALS_DEVICE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "C5",
-           "--reads", "3000000", "--ranges", "3000", "--strong-ranges", "6000", "--strong-steps", "3", "--steps", "6", "--warmup", "2"]
+           "--reads", "3000000", "--ranges", "3000", "--strong-ranges", "6000", "--strong-steps", "3", "--steps", "6", "--warmup", "2", "--wire", wire]
+    if wire == "int32":
+        cmd += ["--no-in-process"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=560, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1]
@@ -47,7 +50,16 @@ def test_two_ranks_emit_strong_and_in_process_blocks():
     par = res["parity_checked"]
     assert par["ranges_per_batch"] == 3000 and "assembled on rank 0" in par["how"] and par["cells"] == par["batches"] * bases
     ph = res["step_phases"]
-    assert ph["gather_bytes_into_rank0"] == 1500 * cfg["range_width"] * 4 and len(ph["kernel_ms_by_rank"]) == 2
+    cells = 1500 * cfg["range_width"]
+    wr = res["wire"]
+    assert wr["kind"] == wire and wr["int32_bytes"] == 4 * cells
+    if wire == "narrow":
+        # two bits a cell + 16 bytes in front + 8 bytes for every exception the longest list has room for
+        assert wr["message_bytes"] == 16 + 4 * ((cells + 15) // 16) + 8 * wr["exceptions_room"] < cells
+        assert ph["gather_bytes_into_rank0"] == wr["message_bytes"] and ph["rank0_ms"]["pack"] > 0
+    else:
+        assert ph["gather_bytes_into_rank0"] == 4 * cells
+    assert len(ph["kernel_ms_by_rank"]) == 2
     # a step cannot be shorter than rank 0's kernel + what it waits for the shards + their placement
     assert res["ms_per_step"] > 0.5 * sum(ph["rank0_ms"].values())
     # the replicas (no collective) are informational and are NOT the headline
@@ -57,6 +69,8 @@ def test_two_ranks_emit_strong_and_in_process_blocks():
     assert st["n_gpus"] == 2 and st["ranges_total"] == 6000 and st["ranges_per_gpu"] == 3000
     assert "identical to the 1-GPU result" in st["checked"] and "identical to the oracle" in st["checked"]
     assert st["ms_per_step"] > 0 and st["one_gpu_ms"] > 0 and 0 < st["efficiency_vs_1gpu"]
+    if wire == "int32":
+        return
     ip = res["in_process"]
     assert ip["devices"] == "0,0"
     assert [r["kind"] for r in ip["xgmi"]] == ["cold", "warm", "warm"]

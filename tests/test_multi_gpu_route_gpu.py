@@ -670,6 +670,62 @@ def test_segment_map_on_the_device(synth_bam):
         ctx.close()
 
 
+def test_narrow_wire_is_lossless(synth_bam):
+    """bsig_narrow_pack + bsig_segmap_run_narrow against bsig_segmap_run on the same shard: two bits a cell and a list of
+    exceptions must give back every int32 (negative coverage differences, big counts, INT32_MIN), whatever the
+    alignment of a segment's destination, with cells of the shard's padding (in no segment) carrying exceptions of
+    their own; a list that is too short is reported, never silently wrong."""
+    import torch
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Context, SegmentMap, narrow_bytes, narrow_count, narrow_pack
+    rng = np.random.default_rng(11)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = Context(0, stream=stream.cuda_stream)
+        for n_seg, max_len, tail, dense in ((4000, 3000, 37, 0.02), (1, 70_001, 0, 0.3), (300, 5, 16, 1.0), (64, 1 << 14, 5, 0.0)):
+            lens = rng.integers(0, max_len + 1, n_seg).astype(np.int64)
+            dst_off = np.concatenate([[0], np.cumsum(lens)])
+            which = rng.permutation(n_seg).astype(np.int64)
+            src_off = np.concatenate([[0], np.cumsum(lens[which])])
+            n_src = int(src_off[-1]) + tail                     # (`tail` cells of padding behind the last segment)
+            src = rng.integers(0, 3, n_src).astype(np.int32)
+            odd = rng.random(n_src) < dense
+            src[odd] = rng.integers(-(1 << 31), 1 << 31, int(odd.sum()), dtype=np.int64).astype(np.int32)
+            if n_src > 40:
+                src[[0, 15, 16, n_src - 1]] = [-1, 3, np.iinfo(np.int32).min, np.iinfo(np.int32).max]
+            n_exc = int(((src < 0) | (src > 2)).sum())
+            want = np.full(int(dst_off[-1]) + 3, -7, np.int32)
+            d_src = torch.from_numpy(src).cuda()
+            m = SegmentMap(ctx, src_off, dst_off, which)
+            for shift in (0, 1, 3):                             # destinations that are not 16-B aligned
+                d_plain = torch.full((len(want),), -7, dtype=torch.int32, device="cuda")
+                m.run(d_src.data_ptr(), d_plain.data_ptr() + 4 * shift)
+                for cap in (n_exc, n_exc + 100):
+                    msg = torch.full((narrow_bytes(n_src, cap) // 4,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+                    narrow_pack(ctx, d_src.data_ptr(), n_src, msg.data_ptr(), cap)
+                    assert narrow_count(ctx, msg.data_ptr()) == n_exc
+                    d_dst = torch.full((len(want),), -7, dtype=torch.int32, device="cuda")
+                    m.run_narrow(msg.data_ptr(), n_src, cap, d_dst.data_ptr() + 4 * shift)
+                    torch.cuda.synchronize()
+                    assert torch.equal(d_dst, d_plain), (n_seg, shift, cap)
+                    assert not m.narrow_overflowed()
+            assert narrow_bytes(n_src, n_exc) == 4 * (4 + (n_src + 15) // 16 + 2 * n_exc)
+            if n_exc > 1:                                       # a list one short: told, and nothing written out of place
+                msg = torch.zeros(narrow_bytes(n_src, n_exc - 1) // 4, dtype=torch.int32, device="cuda")
+                narrow_pack(ctx, d_src.data_ptr(), n_src, msg.data_ptr(), n_exc - 1)
+                assert narrow_count(ctx, msg.data_ptr()) == n_exc
+                d_dst = torch.full((len(want),), -7, dtype=torch.int32, device="cuda")
+                m.run_narrow(msg.data_ptr(), n_src, n_exc - 1, d_dst.data_ptr())
+                assert m.narrow_overflowed()
+                assert int((d_dst[int(dst_off[-1]):] != -7).sum()) == 0
+            with pytest.raises(_lib.BsigError):
+                m.run_narrow(d_src.data_ptr(), int(src_off[-1]) - 1, 0, d_src.data_ptr())      # fewer cells than the segments span
+            m.close()
+        with pytest.raises(_lib.BsigError):
+            narrow_pack(ctx, d_src.data_ptr() + 4, 16, d_src.data_ptr(), 0)                    # not 16-B aligned
+        ctx.close()
+
+
 def test_arena_reserved_with_the_context(synth_bam, monkeypatch):
     """BAMSIGNALS_ARENA_GB: one allocation made when a context comes up; scratch, resident reads and result
     buffers are carved out of it (and come back to it), what does not fit takes the ordinary route; the results
