@@ -18,7 +18,9 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU): the SAME worklo
 the (rid, loc)-sorted ranges (ref: :222-226,246) are dealt round-robin to the ranks, every rank holds the reads,
 and a step is the whole north-star path -- the kernels on the rank's shard, the gather of the shards to rank 0
 over RCCL (torch.distributed.gather: grouped send / recv, every peer straight to the root over its own xGMI link), and the
-reassembly into the caller's range order in rank 0's HBM (bsig_segmap_run).  All three are inside the timed
+reassembly into the caller's range order in rank 0's HBM (bsig_segmap_run).  A shard travels as two bits a cell + a
+list of exceptions (--wire narrow, the default: lossless, ~1/15 of the int32 bytes; packed by bsig_narrow_pack and widened
+by bsig_segmap_run_narrow while it is put in place; --wire int32 sends the cells as they are).  All of it is inside the timed
 region; `value` = the whole range set's bases x K / the slowest rank's time.  At N = 1 there is nothing to gather
 and the step is the launch alone.  The result assembled on rank 0 is compared with the oracle, every range of
 every batch.  The reads are generated ONCE per node (local rank 0 -> .npy files in /dev/shm, the other ranks map
@@ -1162,7 +1164,8 @@ def main():
             "config": {"workload": a.config + ": " + cfg["desc"], "reads": w.n_reads,
                        "ranges_total": len(rg["rid"]), "ranges_per_gpu": len(w.batches[0]["rid"]), "range_width": w.width, "batches": nb,
                        "parallelism": (f"fixed total size: sorted ranges round-robin over {world} GPUs, reads replicated; a step = "
-                                       f"kernels on the shard + gather to rank 0 ({a.backend}: "
+                                       f"kernels on the shard + {'the narrow pack (two bits a cell + exceptions) + ' if a.wire == 'narrow' else ''}"
+                                       f"gather to rank 0 ({a.backend}: "
                                        + ("RCCL grouped send/recv" if a.backend == "nccl" else "gloo through host memory, testing only")
                                        + ") + reassembly in rank 0's HBM, all inside the timed region") if gathered
                                       else "one GPU: a step = the launch, nothing to gather",
