@@ -5,7 +5,8 @@ JSON line with the HIP-event time per launch and the plan's algorithmic bytes.
    C4     bamProfile PE filter tlenFilter=c(50,500) shift=75 ss=TRUE, 100k x 2 kb, 1e8 PE reads on 250 Mbp -> k_profile<64, true>
    C4mid  the same with paired.end="midpoint"
    count  bamCount on C3's tiling                                             -> k_count_multi
-   bins   bamProfile binsize=200 ss=TRUE, 100k x 2 kb on the C3 reads (the wide-bin form a ChIP-seq caller uses) -> k_profile_small"""
+   bins   bamProfile binsize=200 ss=TRUE, 100k x 2 kb on the C3 reads (the wide-bin form a ChIP-seq caller uses) -> k_profile_small
+   t500 / t1000   bamProfile binsize=1 over 400,000 x 500 bp / 200,000 x 1 kb (2e8 bases) on the C3 reads -> k_profile_multi / k_profile<.., 8, true>"""
 import json
 import os
 import sys
@@ -37,6 +38,12 @@ def main():
             rgs = [synth_ranges(100_000, 2000, [L], seed=20 + b) for b in range(2)]
             prm = make_params(_lib.MODE_PROFILE, binsize=200, ss=True)
             name = "bamProfile binsize=200 ss=TRUE, 100k x 2kb, 1e8 SE reads on 249 Mbp"
+        elif case in ("t500", "t1000"):
+            L, w = 248_956_422, int(case[1:])
+            cols = synth_reads(100_000_000, [L], seed=3, with_cigar=False)
+            rgs = [synth_ranges(200_000_000 // w, w, [L], seed=30 + b) for b in range(2)]
+            prm = make_params(_lib.MODE_PROFILE, binsize=1)
+            name = f"bamProfile binsize=1, {200_000_000 // w} x {w} bp, 1e8 SE reads on 249 Mbp"
         elif case in ("C4", "C4mid"):
             cols = synth_reads(100_000_000, [250_000_000], seed=9, paired=True, with_cigar=False)
             rgs = [synth_ranges(100_000, 2000, [250_000_000], seed=10 + b) for b in range(2)]

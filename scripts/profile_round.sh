@@ -31,6 +31,8 @@ for c in $CASES; do
     c4)    run_case c4 python3 $R/scripts/profile_case.py C4 || exit 1 ;;
     count) run_case count python3 $R/scripts/profile_case.py count || exit 1 ;;
     bins)  run_case bins python3 $R/scripts/profile_case.py bins || exit 1 ;;
+    t500)  run_case t500 python3 $R/scripts/profile_case.py t500 || exit 1 ;;
+    t1000) run_case t1000 python3 $R/scripts/profile_case.py t1000 || exit 1 ;;
     decode)
         # the device-side decode kernels (whole file + index-driven) on the 5e7-read BAM
         timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_decode_trace" -- python3 $R/scripts/decode_device_time.py > "$OUT/${TAG}_decode_trace.log" 2>&1 || exit 1

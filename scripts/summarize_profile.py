@@ -22,6 +22,8 @@ CASES = {
     "c4": ("k_profile<64, true", "python3 scripts/profile_case.py C4"),
     "count": ("k_count", "python3 scripts/profile_case.py count"),
     "bins": ("k_profile_small", "python3 scripts/profile_case.py bins"),
+    "t500": ("k_profile_multi", "python3 scripts/profile_case.py t500"),
+    "t1000": ("k_profile<64, false", "python3 scripts/profile_case.py t1000"),
 }
 
 
