@@ -783,29 +783,55 @@ def strong_block(a, rank, world, stream, ctx, reads, cols, use_dist, dist, cdev,
         plan = Plan(ctx, reads, rg["rid"][mine], rg["loc"][mine], rg["len"][mine], rg["strand"][mine], prm)
         assert plan.cells == sizes[rank]
         shard = torch.zeros(pad, dtype=torch.int32, device="cuda")
+        # the wire (see Workload.setup_gather): two bits a cell + exceptions, the room for them counted on a first run
+        narrow = a.wire == "narrow"
+        cap, send = 0, shard
+        if narrow:
+            from bamsignals_amd.device import narrow_bytes, narrow_count, narrow_pack
+            plan.run_device(shard.data_ptr())
+            probe = torch.empty(narrow_bytes(pad, 0) // 4, dtype=torch.int32, device="cuda")
+            narrow_pack(ctx, shard.data_ptr(), pad, probe.data_ptr(), 0)
+            cap = narrow_count(ctx, probe.data_ptr())
+            del probe
+            if use_dist:
+                t = torch.tensor([cap], dtype=torch.int64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                cap = int(t.item())
+            send = torch.empty(narrow_bytes(pad, cap) // 4, dtype=torch.int32, device="cuda")
         bufs = maps = final = None
         if rank == 0:
-            bufs = [torch.empty(pad, dtype=torch.int32, device=cdev) for _ in range(world)]
+            bufs = [torch.empty(len(send), dtype=torch.int32, device=cdev) for _ in range(world)]
             final = torch.zeros(max(int(off_all[-1]), 4), dtype=torch.int32, device="cuda")
             maps = [SegmentMap(ctx, loffs[r], off_all, shards[r]) for r in range(world)]
         dev_bufs = bufs
 
+        def produce():
+            plan.run_device(shard.data_ptr())
+            if narrow:
+                narrow_pack(ctx, shard.data_ptr(), pad, send.data_ptr(), cap)
+
+        def place():
+            for r in range(world):
+                if narrow:
+                    maps[r].run_narrow(dev_bufs[r].data_ptr(), pad, cap, final.data_ptr())
+                else:
+                    maps[r].run(dev_bufs[r].data_ptr(), final.data_ptr())
+
         def step():
             nonlocal dev_bufs
-            plan.run_device(shard.data_ptr())
+            produce()
             if use_dist:
                 if backend == "nccl":
-                    dist.gather(shard, bufs, dst=0)
+                    dist.gather(send, bufs, dst=0)
                 else:                           # gloo (testing the code path on a box with fewer GPUs): via host memory
                     torch.cuda.synchronize()
-                    dist.gather(shard.cpu(), bufs, dst=0)
+                    dist.gather(send.cpu(), bufs, dst=0)
                     if rank == 0:
                         dev_bufs = [b.cuda() for b in bufs]
             else:
-                dev_bufs = [shard]
+                dev_bufs = [send]
             if rank == 0:
-                for r in range(world):
-                    maps[r].run(dev_bufs[r].data_ptr(), final.data_ptr())
+                place()
 
         for _ in range(2):
             step()
@@ -815,15 +841,14 @@ def strong_block(a, rank, world, stream, ctx, reads, cols, use_dist, dist, cdev,
         for q in range(steps):
             if ev:
                 ev[q][0].record(stream)
-                plan.run_device(shard.data_ptr())
+                produce()
                 ev[q][1].record(stream)
                 if use_dist:
-                    dist.gather(shard, bufs, dst=0)
+                    dist.gather(send, bufs, dst=0)
                 else:
-                    dev_bufs = [shard]
+                    dev_bufs = [send]
                 ev[q][2].record(stream)
-                for r in range(world):
-                    maps[r].run(dev_bufs[r].data_ptr(), final.data_ptr())
+                place()
                 ev[q][3].record(stream)
             else:
                 step()
@@ -841,10 +866,13 @@ def strong_block(a, rank, world, stream, ctx, reads, cols, use_dist, dist, cdev,
                        n_gpus=world, ranges_total=n_ranges_total, ranges_per_gpu=len(mine), reads=int(reads.n_reads), steps=steps,
                        timed_region="kernel on the rank's shard + gather of the shards to rank 0 + reassembly in rank 0's HBM",
                        backend=backend, ms_per_step=elapsed / steps * 1e3, value=bases * steps / elapsed / 1e6, unit="Mbases/s",
-                       gather_bytes=int(sum(sizes[1:]) * 4), wire="int32")
+                       gather_bytes=int(sum(sizes[1:]) * 4) if not narrow else 4 * len(send) * (world - 1), wire=a.wire,
+                       wire_message_bytes=4 * len(send), wire_int32_bytes=4 * pad)
+            if narrow and any(m.narrow_overflowed() for m in maps):
+                raise SystemExit("strong: a narrow message had more exceptions than its list holds")
             if ev:
                 ph = np.asarray([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in ev]).mean(axis=0)
-                out["phases_ms_rank0"] = dict(kernel=float(ph[0]), gather=float(ph[1]), place=float(ph[2]))
+                out["phases_ms_rank0"] = dict(kernel_and_pack=float(ph[0]), gather=float(ph[1]), place=float(ph[2]))
                 if ph[1] > 0:
                     out["gather_GBps"] = out["gather_bytes"] / (ph[1] * 1e-3) / 1e9
             # the same ranges on rank 0's GPU alone
