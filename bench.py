@@ -603,7 +603,11 @@ class Workload:
         if ev:
             ev[1].record()
         narrow = self.wire == "narrow"
-        if narrow:
+        # The root's own shard crosses no link: with peers about, it is put in place as it is (int32, bsig_segmap_run)
+        # while their messages are on the way, and the root packs nothing.  (One rank alone -- --force-dist on a one-GPU
+        # box -- keeps the whole wire in its step: that run is how the wire's kernels are measured.)
+        own_direct = narrow and root and self.world > 1
+        if narrow and not own_direct:
             from bamsignals_amd.device import narrow_pack
             narrow_pack(self.ctx, self.outs[b].data_ptr(), self.pad, self.msg[b].data_ptr(), self.cap)
         send = self.msg[b] if narrow else self.outs[b][:self.pad]
@@ -611,21 +615,27 @@ class Workload:
             ev[2].record()
         if self.backend == "nccl":
             # torch.distributed.gather over RCCL: grouped ncclSend / ncclRecv, every peer straight to the root over its
-            # own link (the root's own shard is a copy on the device)
-            dist.gather(send, self.bufs if root else None, dst=0)
+            # own link (the root's own entry is a copy on the device); asynchronous, on RCCL's stream, so that the root's
+            # own placement runs under it
+            work = dist.gather(send, self.bufs if root else None, dst=0, async_op=True)
+            if own_direct:
+                self.maps[b][0].run(self.outs[b].data_ptr(), self.final[b].data_ptr())
+            work.wait()                                  # (this stream waits for RCCL's; the host does not)
         else:
             # gloo (the code path on a box with fewer GPUs than ranks): through host memory
+            if own_direct:
+                self.maps[b][0].run(self.outs[b].data_ptr(), self.final[b].data_ptr())
             torch.cuda.synchronize()
             mine = send.cpu()
             got = [torch.empty_like(mine) for _ in range(self.world)] if root else None
             dist.gather(mine, got, dst=0)
             if root:
-                for r in range(self.world):
+                for r in range(1 if own_direct else 0, self.world):
                     self.bufs[r].copy_(got[r])
         if ev:
             ev[3].record()
         if root:
-            for r in range(self.world):
+            for r in range(1 if own_direct else 0, self.world):
                 if narrow:
                     self.maps[b][r].run_narrow(self.bufs[r].data_ptr(), self.pad, self.cap, self.final[b].data_ptr())
                 else:
@@ -1101,8 +1111,9 @@ def main():
                           gather_bytes_into_rank0=w.gather_bytes[0],
                           gather_GBps=(w.gather_bytes[0] / (float(ph[2]) * 1e-3) / 1e9) if ph[2] > 0 else None,
                           note="HIP events between the parts of a step, on a second run of the same steps: the launches on the "
-                               "rank's shard, bsig_narrow_pack (the narrow wire only), torch.distributed.gather to rank 0, "
-                               "bsig_segmap_run[_narrow] over every rank's shard")
+                               "rank's shard, bsig_narrow_pack (the narrow wire only; with peers about the root packs nothing), "
+                               "torch.distributed.gather to rank 0 (the root puts its own shard in place under it), "
+                               "bsig_segmap_run[_narrow] over the peers' shards")
             replicas = dict(value=sum(w.step_bases[q % nb] for q in range(ksteps)) * world / float(t.item()) / 1e6, unit="Mbases/s",
                             ms_per_step=float(t.item()) / ksteps * 1e3, steps=ksteps, kernel_ms_rank0=kms_r,
                             what=f"every one of the {world} ranks runs the WHOLE range set by itself, nothing exchanged: {world} "

@@ -56,7 +56,7 @@ def test_two_ranks_emit_strong_and_in_process_blocks(wire):
     if wire == "narrow":
         # two bits a cell + 16 bytes in front + 8 bytes for every exception the longest list has room for
         assert wr["message_bytes"] == 16 + 4 * ((cells + 15) // 16) + 8 * wr["exceptions_room"] < cells
-        assert ph["gather_bytes_into_rank0"] == wr["message_bytes"] and ph["rank0_ms"]["pack"] > 0
+        assert ph["gather_bytes_into_rank0"] == wr["message_bytes"] and ph["rank0_ms"]["pack"] >= 0      # (the root packs nothing: its own shard crosses no link)
     else:
         assert ph["gather_bytes_into_rank0"] == 4 * cells
     assert len(ph["kernel_ms_by_rank"]) == 2
