@@ -395,7 +395,10 @@ int bsig_segmap_run(bsig_segmap *map, const int32_t *src_dev, int32_t *dst_dev);
  * and msg_dev 16-B aligned); bsig_narrow_count (synchronises) says how many exceptions a packed shard has -- a plan's result
  * is a function of plan and reads, so a first run tells the `cap` of every later one; bsig_segmap_run_narrow is
  * bsig_segmap_run from such a message; bsig_segmap_narrow_overflowed (synchronises) reports whether any message so far had
- * more exceptions than its list held (its result is then wrong).  Replaces nothing of the reference: each range owns its
+ * more exceptions than its list held (its result is then wrong).  The message, in 32-bit words: [0] the number of
+ * exceptions the shard has (it may exceed cap: then the list is incomplete), [1..3] zero, [4 .. 4 + ceil(n_cells / 16)) the
+ * codes (cell c in bits 2 (c % 16) .. + 1 of word c / 16), then cap pairs (cell, value) of which the first min([0], cap)
+ * are in use, in no particular order; n_cells < 2^32.  Replaces nothing of the reference: each range owns its
  * output there (ref: src/bamsignals.cpp:164,181,186), which is what makes shards -- and their reassembly -- legal.       */
 int64_t bsig_narrow_bytes(int64_t n_cells, int64_t cap);
 int bsig_narrow_pack(bsig_ctx *ctx, const int32_t *src_dev, int64_t n_cells, void *msg_dev, int64_t cap);

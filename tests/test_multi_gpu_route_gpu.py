@@ -670,6 +670,21 @@ def test_segment_map_on_the_device(synth_bam):
         ctx.close()
 
 
+def _narrow_decode(msg, n_cells, cap):
+    """The narrow message as include/bamsignals_abi.h lays it out, read back with numpy: dword 0 = number of exceptions,
+    dwords 1-3 zero, then ceil(n / 16) words of two-bit codes (cell c in bits 2 (c % 16) .. +1 of word c // 16; 3 = see
+    the list), then `cap` (cell, value) pairs of which the first `number of exceptions` are in use, in any order."""
+    m = msg.view(np.uint32)
+    n_exc, n_words = int(m[0]), (n_cells + 15) // 16
+    assert not m[1:4].any() and len(m) == 4 + n_words + 2 * cap and n_exc <= cap
+    codes = (m[4:4 + n_words, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3
+    out = codes.reshape(-1)[:n_cells].astype(np.int32)
+    pairs = m[4 + n_words:4 + n_words + 2 * n_exc].reshape(-1, 2)
+    assert len(np.unique(pairs[:, 0])) == n_exc and np.array_equal(np.sort(pairs[:, 0]), np.flatnonzero(out == 3))
+    out[pairs[:, 0]] = pairs[:, 1].view(np.int32)
+    return out
+
+
 def test_narrow_wire_is_lossless(synth_bam):
     """bsig_narrow_pack + bsig_segmap_run_narrow against bsig_segmap_run on the same shard: two bits a cell and a list of
     exceptions must give back every int32 (negative coverage differences, big counts, INT32_MIN), whatever the
@@ -704,6 +719,8 @@ def test_narrow_wire_is_lossless(synth_bam):
                     msg = torch.full((narrow_bytes(n_src, cap) // 4,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
                     narrow_pack(ctx, d_src.data_ptr(), n_src, msg.data_ptr(), cap)
                     assert narrow_count(ctx, msg.data_ptr()) == n_exc
+                    if shift == 0:
+                        assert np.array_equal(_narrow_decode(msg.cpu().numpy(), n_src, cap), src)
                     d_dst = torch.full((len(want),), -7, dtype=torch.int32, device="cuda")
                     m.run_narrow(msg.data_ptr(), n_src, cap, d_dst.data_ptr() + 4 * shift)
                     torch.cuda.synchronize()
