@@ -16,6 +16,7 @@ from conftest import GOLDEN, layout_info
 pytestmark = pytest.mark.gpu
 
 BAM = os.path.join(GOLDEN, "randomBam.bam")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
@@ -516,6 +517,36 @@ def test_inflate_kernel_alone_in_every_form(ctx, tmp_path, monkeypatch, shape):
         for first, n in ((0, 1 << 20), (3, 1), (1, 7), (2, 33)):
             rc, st, nb, _ = run(first, n)
             assert (rc, st) == (0, 0) and nb == min(n, n_all - first), (shape, lanes, pad, first, n, rc, st, nb)
+
+
+def test_inflate_kernel_on_every_kind_of_content(ctx, tmp_path, monkeypatch):
+    """k_inflate by itself on what BAM records never hold (scripts/fuzz_inflate.py's generator, two seeds here; DESIGN.md
+    section 4 has the long campaign): runs, periods of 1-40 bytes, copies at chosen distances (1, 7, 8, 9, 15, 16, 17, ... 32,768)
+    and lengths (3 ... 258), skewed alphabets, random bytes, zeros, in blocks of 1 ... 65,280 bytes at zlib levels 0 / 1 / 6 / 9
+    under all five strategies; every block's CRC32 and length checked on the device."""
+    import ctypes
+    import importlib.util
+    from bamsignals_amd import _lib
+    spec = importlib.util.spec_from_file_location("fuzz_inflate", os.path.join(ROOT, "scripts", "fuzz_inflate.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fn = _lib.load().bsig_debug_inflate_bench
+    fn.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+    for seed in (5, 6):
+        rng = np.random.default_rng(seed)
+        path, total, n_blocks = str(tmp_path / ("c%d.bgzf" % seed)), 0, 700
+        with open(path, "wb") as fh:
+            for _ in range(n_blocks):
+                b, n = fz.block(rng)
+                fh.write(b)
+                total += n
+            fh.write(fz.EOF_BLOCK)
+        for lanes in ("8", "32", "64"):
+            monkeypatch.setenv("BAMSIGNALS_INFLATE_LANES", lanes)
+            ms, by, st = (ctypes.c_double * 2)(), (ctypes.c_int64 * 3)(), ctypes.c_int(-1)
+            rc = fn(0, path.encode(), 0, n_blocks, 1, ms, by, ctypes.byref(st))
+            assert (rc, st.value, by[2], by[1]) == (0, 0, n_blocks, total), (seed, lanes, rc, st.value, by[2], by[1])
 
 
 def test_passes_are_whole_rounds_of_inflate_lanes(ctx, tmp_path, monkeypatch, capfd):
