@@ -5,7 +5,10 @@ the consumer's pattern path), short periods (distances 2 ... 40: a match that ov
 accumulator), copies at random distances up to 32,768 and lengths 3 ... 258, skewed alphabets (long codes: the canonical
 walk behind the first-level tables), random bytes (stored blocks), zeros, and mixtures -- at zlib levels 0 / 1 / 6 / 9 and all five
 strategies (default, filtered, Huffman only, RLE, fixed codes), in blocks of 1 ... 65,280 bytes, 4 / 8 / 16 / 32 / 64 blocks per
-workgroup.   usage: fuzz_inflate.py [first seed] [seeds] [blocks per seed]"""
+workgroup.   usage: fuzz_inflate.py [first seed] [seeds] [blocks per seed] [damage]
+With `damage`: one to four bytes of the DEFLATE data of seven blocks in ten are then overwritten at random (headers and
+trailers stay: the block table is as before) and the file goes through the kernel again -- a launch over damaged blocks must
+come back, with a status that says so, whatever the damage made of the code tables, the distances and the lengths."""
 import ctypes
 import os
 import struct
@@ -72,10 +75,22 @@ def block(rng):
                     + struct.pack("<II", zlib.crc32(chunk), len(chunk))), len(chunk)
 
 
+def damaged(rng, blk):
+    """`blk` (one BGZF block) with 1-4 bytes of its deflate data overwritten"""
+    b = bytearray(blk)
+    lo, hi = 18, len(b) - 8
+    if hi <= lo or rng.random() < 0.3:
+        return blk
+    for _ in range(int(rng.integers(1, 5))):
+        b[int(rng.integers(lo, hi))] = int(rng.integers(0, 256))
+    return bytes(b)
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     n_blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
+    damage = len(sys.argv) > 4 and sys.argv[4] == "damage"
     from bamsignals_amd import _lib
     lib = _lib.load()
     fn = lib.bsig_debug_inflate_bench
@@ -87,10 +102,12 @@ def main():
         rng = np.random.default_rng(seed)
         t0 = time.time()
         total = 0
+        blocks = []
         with open(path, "wb") as fh:
             for _ in range(n_blocks):
                 b, n = block(rng)
                 fh.write(b)
+                blocks.append(b)
                 total += n
             fh.write(EOF_BLOCK)
         t1 = time.time()
@@ -102,6 +119,18 @@ def main():
             ok = rc == 0 and st.value == 0 and by[2] == n_blocks and by[1] == total
             res.append(f"{lanes}: {'ok' if ok else f'FAILED rc {rc} status {st.value} blocks {by[2]} bytes {by[1]}'}")
             bad += not ok
+        if damage:
+            with open(path, "wb") as fh:
+                for b in blocks:
+                    fh.write(damaged(rng, b))
+                fh.write(EOF_BLOCK)
+            for lanes in ("8", "32", "64"):
+                os.environ["BAMSIGNALS_INFLATE_LANES"] = lanes
+                ms, by, st = (ctypes.c_double * 2)(), (ctypes.c_int64 * 3)(), ctypes.c_int(-1)
+                rc = fn(0, path.encode(), 0, n_blocks, 1, ms, by, ctypes.byref(st))
+                ok = rc == 0 and st.value != 0 and by[2] == n_blocks
+                res.append(f"damaged, {lanes}: {'came back, status ' + str(st.value) if ok else f'FAILED rc {rc} status {st.value}'}")
+                bad += not ok
         os.environ.pop("BAMSIGNALS_INFLATE_LANES", None)
         print(f"seed {seed}: {n_blocks} blocks, {total / 1e6:.1f} MB (made in {t1 - t0:.1f} s); blocks per workgroup " + ", ".join(res), flush=True)
     os.remove(path)
