@@ -1028,20 +1028,33 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, 8)
     }
 }
 
-// Wide bins (binsize >~ 64): a tile has few cells and thousands of reads, and the position-sorted
-// reads of one wave instruction fall into one or two bins, so plain LDS atomics serialise on a
-// bank.  Here the lanes add into replicas of the tile image (up to 32, odd stride:
-// the same cell of different replicas lies in different banks); the replicas are summed at the end.
+// Wide bins (binsize >~ 8): a tile has few cells and thousands of reads, and the position-sorted
+// reads of one wave instruction fall into one or two bins, so plain LDS atomics take turns on one or
+// two addresses.  32-bit cells in LDS, a few replicas of the image (odd stride: the same cell of
+// different replicas lies in different banks), summed at the end.
 constexpr int kSmallCells = 256;     // at most this many values (cells * S) per tile
-// replicas of the image (lanes add into replica `tid & (r - 1)`, the replicas are summed at the end): FEW.  Rounds 2-4
-// kept up to 32 of them (8 KiB) so that no two lanes of a wave would meet on a cell; measured in round 5 (100,000 x 2 kb
-// ranges, 1e8 reads, one box; 32 / 4 / 2 / 1 replicas): binsize 200 with strands (20 values) 0.157 / 0.112 / 0.112 / 0.120
-// ms, binsize 50 with strands (80 values) 0.167 / 0.117 / 0.114 / 0.107, binsize 16 (125 values) 0.174 / 0.116 / 0.113 /
-// 0.107.  Clearing and summing r x values dwords per tile and the LDS they take cost more than lanes taking turns on a
-// cell: four replicas for images of up to 32 values, two up to 64, one beyond.
+// Replicas of the image (lanes add into replica `tid & (r - 1)`, the replicas are summed at the end): FEW, and chosen by
+// the TILE's own values.  Rounds 2-4 kept up to 32 (8 KiB) so that no two lanes of a wave would meet on a cell; clearing
+// and summing r x values dwords per tile and the LDS they take cost more than lanes taking turns (100,000 x 2 kb ranges,
+// 1e8 reads, one box; 32 / 4 / 2 / 1 replicas: binsize 50 with strands (80 values) 0.167 / 0.117 / 0.114 / 0.107 ms,
+// binsize 16 (125 values) 0.174 / 0.116 / 0.113 / 0.107): four replicas for images of up to 32 values, two up to 64, one
+// beyond.  With a handful of cells they matter most -- one replica instead of four: binsize 2000 with strands (two
+// values) 0.107 -> 0.172 ms, binsize 500 (four values) 0.105 -> 0.24 -- and until late in round 5 the choice went by the
+// PLAN's tile_cells, which is never below 64: a 2-kb range in bins of 200 bases (10 cells, 20 values with strands) ran
+// with one replica.  By the tile's values: binsize 200 with strands 0.1235 -> 0.110 ms, binsize 500 0.139 -> 0.105.
+// (Spreading the lanes over the window instead -- a lane takes consecutive vectors, so that an instruction's reads come
+// from all over the tile -- does the same for 20 values and nothing once the replicas are right: not kept.)
 __host__ __device__ inline int small_replicas(int stride)
 {
     return stride <= 32 ? 4 : stride <= 64 ? 2 : 1;
+}
+// dwords of the largest image (replicas x odd stride) a tile of at most `stride_max` values can ask for
+__host__ __device__ inline int small_image_dwords(int stride_max)
+{
+    int most = stride_max * small_replicas(stride_max);          // (strides are odd: 31 and 63 are the last of their kind)
+    if (stride_max > 31) most = most > 31 * small_replicas(31) ? most : 31 * small_replicas(31);
+    if (stride_max > 63) most = most > 63 * small_replicas(63) ? most : 63 * small_replicas(63);
+    return most;
 }
 template <int NT, bool SS>
 __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
@@ -1057,10 +1070,13 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
     uint2 win[BSIG_MAX_CLASSES], clip;
     PackedWin pk;
     load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile, pk, clip);
-    const int stride = (P.tile_cells * S) | 1;                 // odd: replicas shift by one bank
+    // the replicas go by THIS tile's values (a plan's tile_cells is at least 64 cells); the launch reserves the image of
+    // the worst tile a plan of this tile_cells can hold
+    const int nv = w.nc * S;
+    const int stride = nv | 1;                                 // odd: replicas shift by one bank
     const int n_rep = small_replicas(stride);
     for (int v = tid; v < n_rep * stride; v += NT) lds[v] = 0;
-    uint8_t *ptab = reinterpret_cast<uint8_t *>(lds + ((n_rep * stride + 3) & ~3));
+    uint8_t *ptab = reinterpret_cast<uint8_t *>(lds + ((small_image_dwords((P.tile_cells * S) | 1) + 3) & ~3));
     build_ptab<NT>(ptab, R, P, tid);
     block_sync<NT>();
     const bool neg_range = (w.units_strand & BSIG_ITEM_NEG) != 0u;
@@ -1074,7 +1090,6 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
     if (pk.n_chunks > 1) packed_later_chunks<NT>(R, P, BSIG_MODE_PROFILE, w, pk.n_chunks, clip, ptab, tid, one);
     block_sync<NT>();
 
-    const int nv = w.nc * S;
     for (int v = tid; v < nv; v += NT) {
         int acc = 0;
         for (int r = 0; r < n_rep; ++r) acc += lds[r * stride + v];
@@ -1751,7 +1766,7 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
     const dim3 grid((unsigned)n_items), block(NT);
     if (mode == BSIG_MODE_PROFILE && tile_cells * (ss ? 2 : 1) <= kSmallCells && P.binsize > 1) {
         const int stride = (tile_cells * (ss ? 2 : 1)) | 1;
-        const size_t lds = (size_t)((small_replicas(stride) * stride + 3) & ~3) * sizeof(int32_t) + BSIG_PACK_CODES;   // + the packed class's table
+        const size_t lds = (size_t)((small_image_dwords(stride) + 3) & ~3) * sizeof(int32_t) + BSIG_PACK_CODES;   // + the packed class's table
         if (ss) hipLaunchKernelGGL((k_profile_small<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
         else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
     } else if (mode == BSIG_MODE_PROFILE) {

@@ -37,8 +37,9 @@ def main():
             elif case == "bins":
                 rgs, a, kind = [synth_ranges(100_000, 2000, [L], seed=20 + b) for b in range(2)], dict(binsize=200, ss=True), "pileup"
                 prm = make_params(_lib.MODE_PROFILE, **a)
-            elif case in ("bins16", "bins50ss"):
-                a = dict(binsize=16) if case == "bins16" else dict(binsize=50, ss=True)
+            elif case in ("bins16", "bins50ss", "bins2000ss", "bins500"):
+                a = {"bins16": dict(binsize=16), "bins50ss": dict(binsize=50, ss=True), "bins2000ss": dict(binsize=2000, ss=True),
+                     "bins500": dict(binsize=500)}[case]
                 rgs, kind = [synth_ranges(100_000, 2000, [L], seed=20 + b) for b in range(2)], "pileup"
                 prm = make_params(_lib.MODE_PROFILE, **a)
             elif case in ("t500", "t1000"):
