@@ -195,54 +195,56 @@ struct SmallOne {
         if ((unsigned)lc < (unsigned)nc) atomicAdd(&mine[lc * S + (SS ? anti : 0)], 1);
     }
     // four packed reads at once, as ProfileOne::quad, with the bin of the range-oriented position by an exact magic
-    // multiply (the position must lie inside the range for it: that test cannot ride on the cell test here).  Round 5:
-    // the count family's dword table (build_ctab: bit 0 reverse strand -- taken as a 24-bit factor --, bit 31
-    // rejected), no read-by-read "is it one of the window's" on an inner pass, and for ranges shorter than 32,768
-    // bases the bin by a 24-bit multiply at the vector unit's full rate instead of the quarter-rate v_mul_hi_u32:
-    // about 20 vector instructions a read where round 4 took 33.
+    // multiply.  The launch is bound by its vector instructions (0.98 of it once the replicas were right: `SQ_INSTS_VALU`),
+    // so the read body is counted out: the position is taken relative to the TILE's first base (K carries
+    // -c0 * binsize), which makes "inside the range" and "one of this tile's cells" ONE unsigned compare against the
+    // tile's length in bases and the cell its own index; the table byte is used as it is (bit 0 rejected, bit 1 reverse
+    // strand: two v_bfe_i32 make the masks); the strand's half of the address is a mask and an AND; for ranges
+    // shorter than 32,768 bases the bin is a 24-bit multiply at the vector unit's full rate instead of the
+    // quarter-rate v_mul_hi_u32.  19 vector instructions a read where the round began with 33 and its middle had 26.
     __device__ __forceinline__ void quad(const uint4 &w, const int4 &t, uint32_t dj, uint32_t nj, int base,
                                          const uint8_t *__restrict__ ptab) const
     {
-        // (table bytes -> bit 0 reverse strand, bit 31 rejected.  The count family's dword table was tried here: the
-        // 1.5 KB more of LDS per workgroup cost a fifth of the launch, 0.162 -> 0.196 ms -- this kernel lives on how
-        // many workgroups a CU holds, not on its instructions: the same read body with 25 % fewer of them is no faster)
-        auto e = [](uint32_t x) { return ((x >> 1) & 1u) | (x << 31); };
-        const uint32_t b0 = e(ptab[w.x >> 23]), b1 = e(ptab[w.y >> 23]), b2 = e(ptab[w.z >> 23]), b3 = e(ptab[w.w >> 23]);
+        const uint32_t b0 = ptab[w.x >> 23], b1 = ptab[w.y >> 23], b2 = ptab[w.z >> 23], b3 = ptab[w.w >> 23];
         // (uniform, like everything these branches ask.  Three forms only -- the orientation of the range is a sign and
-        // a strand bit, not a fourth template argument: the kernel inlines this at four places, and 32 copies of the
+        // a strand mask, not a fourth template argument: the kernel inlines this at four places, and 32 copies of the
         // read body were 35 KB of code that ran a third SLOWER than round 4's 16)
         const bool tl_rule = (P.has_tlen_filter | P.midpoint) != 0;
         const bool narrow = len < 32768 && P.div_s15 != 0;
         const int A = base - loc + P.shift;
-        const int K = neg_range ? len - 1 - A : A, sgn = neg_range ? -1 : 1;
-        if (tl_rule) four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn);
-        else if (narrow) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn);
-        else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn);
+        const int first = c0 * P.binsize;                                  // the tile's first base in range orientation
+        const int K = (neg_range ? len - 1 - A : A) - first, sgn = neg_range ? -1 : 1;
+        const int rest = len - first, mine_bases = nc * P.binsize;
+        const uint32_t tile_bases = (uint32_t)(rest < mine_bases ? rest : mine_bases);
+        if (tl_rule) four<true, false>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn, tile_bases);
+        else if (narrow) four<false, true>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn, tile_bases);
+        else four<false, false>(w, t, b0, b1, b2, b3, dj, nj, base, K, sgn, tile_bases);
     }
     template <bool TL, bool NARROW>
     __device__ __forceinline__ void four(const uint4 &w, const int4 &t, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t dj,
-                                         uint32_t nj, int base, int K, int sgn) const
+                                         uint32_t nj, int base, int K, int sgn, uint32_t tile_bases) const
     {
         const int cd = -2 * P.shift;                                   // (binsize > 1 here: bins of one base run k_profile)
-        const uint32_t flip = sgn < 0 ? 1u : 0u;
+        const int flip = sgn < 0 ? -1 : 0;
+        int Kv = K;
+        asm volatile("" : "+v"(Kv));                                   // (in a vector register once: v_mad_i32_i24 takes one scalar operand)
+        char *const image = reinterpret_cast<char *>(mine);
         auto rd = [&](uint32_t x, uint32_t b, int tl, uint32_t k) {
             const int d = (int)((x - (uint32_t)base) & (((uint32_t)1 << BSIG_PACK_POS_BITS) - 1u));
             int spcd = (int)((x >> BSIG_PACK_POS_BITS) & 0xFFu) + cd, h = 0;
-            uint32_t rj = b & 0x80000000u;
+            const int rev = __builtin_amdgcn_sbfe((int)b, 1, 1);       // all ones: reverse strand
+            int rj = __builtin_amdgcn_sbfe((int)b, 0, 1);              // all ones: rejected by flag / mapq
             if (TL) {
                 const int a = tl < 0 ? -tl : tl;
-                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? 0x80000000u : 0u;
+                if (P.has_tlen_filter) rj |= ((a < P.tf0) | (a > P.tf1)) ? -1 : 0;
                 if (P.midpoint) { h = a >> 1; spcd -= 2 * h; }
             }
             // (|spcd| and fwd < 2^23: a window that takes this path is narrower than 32,768 bases, and so are shift and h)
-            // (the strand bit as a mask -- v_bfe_i32 -- : as a factor the compiler made a 64-bit multiply-add of it here)
-            const int fwd = (__builtin_amdgcn_sbfe((int)b, 0, 1) & spcd) + d + h;
-            const uint32_t rel = (uint32_t)(__mul24(fwd, sgn) + K) | rj;       // position in range orientation
+            const int fwd = (rev & spcd) + d + h;
+            const uint32_t rel = (uint32_t)(__mul24(fwd, sgn) + Kv) | (uint32_t)rj;     // from the tile's first base, range orientation
             const uint32_t cell = NARROW ? __umul24(rel, P.div_m15) >> P.div_s15 : __umulhi(rel, P.div_magic) >> P.div_shift;
-            const uint32_t lc = cell - (uint32_t)c0;
-            const bool ok = (dj + k < nj) & (rel < (uint32_t)len) & (lc < (uint32_t)nc);
-            const uint32_t idx = SS ? 2u * lc + ((b ^ flip) & 1u) : lc;
-            if (ok) atomicAdd(&mine[idx], 1);
+            const bool ok = (dj + k < nj) & (rel < tile_bases);
+            if (ok) atomicAdd(reinterpret_cast<int32_t *>(image + (SS ? (cell << 3) + (uint32_t)((rev ^ flip) & 4) : cell << 2)), 1);
         };
         rd(w.x, b0, t.x, 0u);
         rd(w.y, b1, t.y, 1u);
