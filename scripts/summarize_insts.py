@@ -14,8 +14,9 @@ G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "g
 print("| case | kernel | launches | waves | VALU / wave | SALU / wave | LDS / wave | VMEM_RD / wave | VALU x 4 cycles / 1,024 SIMDs @ 2.4 GHz | launch (same run) | share |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 for case in ("ns", "C3", "C4", "count", "bins"):
-    f = sorted(glob.glob(os.path.join(G, f"{tag}_insts_{case}", "*", "*counter_collection.csv")))
-    t = sorted(glob.glob(os.path.join(G, f"{tag}_insts_{case}", "*", "*kernel_trace.csv")))
+    # (gpurun merges every run into the same directory: the newest files are the ones meant)
+    f = sorted(glob.glob(os.path.join(G, f"{tag}_insts_{case}", "*", "*counter_collection.csv")), key=os.path.getmtime)
+    t = sorted(glob.glob(os.path.join(G, f"{tag}_insts_{case}", "*", "*kernel_trace.csv")), key=os.path.getmtime)
     if not f:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
