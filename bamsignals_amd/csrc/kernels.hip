@@ -1058,7 +1058,7 @@ __host__ __device__ inline int small_image_dwords(int stride_max)
     if (stride_max > 63) most = most > 63 * small_replicas(63) ? most : 63 * small_replicas(63);
     return most;
 }
-template <int NT, bool SS>
+template <int NT, bool SS, bool RES>
 __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__restrict__ items, uint32_t n_tiles,
                                                       int32_t *__restrict__ out,
                                                       const uint2 *__restrict__ windows,
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(NT) void k_profile_small(const BsigWorkItem *__rest
     const BsigWorkItem w = items[tile];
     uint2 win[BSIG_MAX_CLASSES], clip;
     PackedWin pk;
-    load_windows(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile, pk, clip);
+    load_windows<RES>(R, P, BSIG_MODE_PROFILE, w, items, windows, win, tile, pk, clip);
     // the replicas go by THIS tile's values (a plan's tile_cells is at least 64 cells); the launch reserves the image of
     // the worst tile a plan of this tile_cells can hold
     const int nv = w.nc * S;
@@ -1769,8 +1769,11 @@ static hipError_t launch_mode(int mode, int ss, const BsigReadsDev &R, const Bsi
     if (mode == BSIG_MODE_PROFILE && tile_cells * (ss ? 2 : 1) <= kSmallCells && P.binsize > 1) {
         const int stride = (tile_cells * (ss ? 2 : 1)) | 1;
         const size_t lds = (size_t)((small_image_dwords(stride) + 3) & ~3) * sizeof(int32_t) + BSIG_PACK_CODES;   // + the packed class's table
-        if (ss) hipLaunchKernelGGL((k_profile_small<NT, true>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
-        else    hipLaunchKernelGGL((k_profile_small<NT, false>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P);
+        // (the form for resolved windows has no lookup code in it, as k_profile's)
+#define BSIG_KS(SS_, RES_) hipLaunchKernelGGL((k_profile_small<NT, SS_, RES_>), grid, block, lds, st, items, (uint32_t)n_items, out, windows, R, P)
+        if (ss) { if (P.resolved) BSIG_KS(true, true); else BSIG_KS(true, false); }
+        else    { if (P.resolved) BSIG_KS(false, true); else BSIG_KS(false, false); }
+#undef BSIG_KS
     } else if (mode == BSIG_MODE_PROFILE) {
         const size_t lds = (size_t)((tile_cells * (ss ? 2 : 1) + 8 + 7) / 8) * 16 + BSIG_PACK_CODES;     // 16-bit counters + the packed class's table
         // class-0 passes requested before anything is consumed (knob 0: 2, 3 or 4; fewer = fewer VGPRs = more
