@@ -627,7 +627,8 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
         const uint32_t j = jbp + 4u * NT * k;
-        t0[k] = make_int4(0, 0, 0, 0);
+        // (t0[k] is read under P.use_tlen only, which is when it is loaded: setting it to zero otherwise was four vector
+        // instructions a pass in launches that are bound by exactly those)
         if (j < win[BSIG_CLASS_PACKED].y) {
             w0[k] = *reinterpret_cast<const uint4 *>(CP.fm + j);
             if (P.use_tlen) t0[k] = *reinterpret_cast<const int4 *>(CP.tlen + j);
@@ -669,7 +670,7 @@ __device__ __forceinline__ void for_each_read(const BsigReadsDev &R, const BsigK
         for (uint32_t j = jbp + 4u * NT * kPre, jf = jp0 + 4u * NT * kPre; j < j_hi; j += 8u * NT, jf += 8u * NT) {
             const uint32_t j2 = j + 4u * NT;
             const uint4 wa = *reinterpret_cast<const uint4 *>(CP.fm + j);
-            int4 xa = make_int4(0, 0, 0, 0), xb = make_int4(0, 0, 0, 0);
+            int4 xa, xb;                                                   // (as t0: read under P.use_tlen only)
             uint4 wb = make_uint4(0, 0, 0, 0);
             if (P.use_tlen) xa = *reinterpret_cast<const int4 *>(CP.tlen + j);
             if (j2 < j_hi) {
