@@ -1219,9 +1219,9 @@ __global__ __launch_bounds__(kWave) void k_count_multi(const BsigWorkItem *__res
             packed_later_chunks<kWave>(R, P, BSIG_MODE_COUNT, w2, pchunks, make_uint2(0u, 0xFFFFFFFFu), ptab, lane, one);
         }
         // (the wave's sum stays packed: a tile that is not sliced has at most 32,768 reads in its windows)
-#pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d);
-        const int c_all = (int)(acc & 0xFFFFu), c_neg = (int)(acc >> 16);
+        // (six DPP adds and a v_readlane; the butterfly of __shfl_xor was six trips through LDS and their addresses)
+        const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)acc), kWave - 1);
+        const int c_all = (int)(sum & 0xFFFFu), c_neg = (int)(sum >> 16);
         const int c_anti = neg_range ? c_all - c_neg : c_neg, c_sense = c_all - c_anti;
         if (lane == t) { my_sense = c_sense; my_anti = c_anti; }
     }
