@@ -531,8 +531,6 @@ class Workload:
             self.plans = [Plan(self.ctx, self.reads, g["rid"], g["loc"], g["len"], g["strand"], self.params)
                           for g in self.batches]
             self.t_plan = (time.time() - t0) / nb
-            all_stats = [p.stats() for p in self.plans]
-            self.stats = {k: int(round(float(np.mean([st[k] for st in all_stats])))) for k in all_stats[0]}
             self.step_bases = [int(g["len"].astype(np.int64).sum()) for g in self.full]      # of the whole job
             # the shards travel as equal-sized messages (the largest shard of any batch, in cells)
             self.shard_offs = [[layout(g["len"][r::world], cfg["args"].get("binsize", 1), ss) for r in range(world)] for g in self.full] \
@@ -542,6 +540,10 @@ class Workload:
             self.outs = [torch.zeros(max(p.cells, 4, self.pad), dtype=torch.int32, device="cuda") for p in self.plans]
             for b in range(nb):                      # every result buffer is produced at least once
                 self.plans[b].run_device(self.outs[b].data_ptr())
+            # (after a first run: a plan's later steps -- the timed ones -- may read kept windows where its first looked them
+            # up, and the algorithmic bytes are those of the form that is timed)
+            all_stats = [p.stats() for p in self.plans]
+            self.stats = {k: int(round(float(np.mean([st[k] for st in all_stats])))) for k in all_stats[0]}
             self.full_plans, self.full_outs = self.plans, self.outs
             if self.gathered:
                 self.full_plans = [Plan(self.ctx, self.reads, g["rid"], g["loc"], g["len"], g["strand"], self.params) for g in self.full]
@@ -1209,8 +1211,8 @@ def main():
                                        + ") + reassembly in rank 0's HBM, all inside the timed region") if gathered
                                       else "one GPU: a step = the launch, nothing to gather",
                        "launch": "one bsig_plan_run per step from the host loop; the tiles' index windows are looked up (k_resolve_tiles) in "
-                                 "a plan's first run and kept with the plan, which is immutable like the layout of the reads: the timed steps "
-                                 "read them back" if os.environ.get("BAMSIGNALS_CACHE_WINDOWS") != "0" else
+                                 "a plan's first run (its second, below 32,768 tiles) and kept with the plan, which is immutable like the "
+                                 "layout of the reads: the timed steps read them back" if os.environ.get("BAMSIGNALS_CACHE_WINDOWS") != "0" else
                                  "one bsig_plan_run per step from the host loop: k_resolve_tiles + the pileup launch in every step (BAMSIGNALS_CACHE_WINDOWS=0)",
                        "threads": w.params.threads or 64,
                        "tile_cells": w.params.tile_cells or "auto (widest range, at most 2048)"},
