@@ -292,10 +292,10 @@ static bool plan_two_launches(const bsig_plan *p)
     static const int64_t resolve_min = getenv("BAMSIGNALS_RESOLVE_MIN_TILES") ? atoll(getenv("BAMSIGNALS_RESOLVE_MIN_TILES")) : (int64_t)32768;
     // (the count family walks four tiles per wave and looks their windows up side by side: a launch of its own
     // for them measured the same or slower there -- 0.1469 fused, 0.1476 in two launches on config 3's tiling --
-    // so bamCount keeps the fused form unless the knob asks)
-    if (g_resolve_min_override < 0 && p->kernel_mode == BSIG_MODE_COUNT) return false;
+    // so bamCount keeps the fused form for a step that pays the lookup; with the windows kept it takes the other
+    // from its second run on like everybody: 0.0949 / 0.0975 -> 0.0925 / 0.0945 ms on that tiling)
     if (g_resolve_min_override >= 0) return p->n_items > 0 && p->n_items >= g_resolve_min_override;
-    if (p->n_items >= resolve_min) return p->n_items > 0;
+    if (p->n_items >= resolve_min && p->kernel_mode != BSIG_MODE_COUNT) return p->n_items > 0;
     // Those figures are for a step that pays the lookup launch.  A plan that is run a second time is a resident one, and
     // with the windows kept its later steps pay nothing for them: from its second run on a plan of 1,024 tiles and more
     // takes the form for resolved windows too (config 2, 10,000 tiles: 19.56 -> 18.30 us a step; its second run carries

@@ -23,6 +23,11 @@ def main():
     from oracle import oracle_c
 
     L = 248_956_422
+    if os.environ.get("BSIG_CASE_RESOLVE_MIN"):              # (diagnostic: the two-launch form from that many tiles on, bamCount included)
+        import ctypes
+        fn = _lib.load().bsig_debug_set_resolve_min
+        fn.argtypes = [ctypes.c_longlong]
+        fn(int(os.environ["BSIG_CASE_RESOLVE_MIN"]))
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx = Context(0, stream=stream.cuda_stream)
