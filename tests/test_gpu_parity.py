@@ -361,6 +361,56 @@ def test_a_plans_windows_are_kept_after_its_first_run_and_die_with_the_layout(ct
     small.close()
 
 
+def test_a_plan_that_is_run_again_takes_the_resolved_form(ctx, synth, monkeypatch):
+    """Below 32,768 tiles a plan's first run looks its windows up inside the pileup kernel (a file-level call runs its plan
+    once and must not pay a launch for nothing); a plan that is run AGAIN is a resident one: its second run looks the
+    windows up in a launch of their own and keeps them, the third reads them back (bamCount included).  Every run is
+    identical to the oracle; which form the next run takes shows in the plan's algorithmic bytes (the figure is
+    computed once, when it is first asked for: one plan per question)."""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    from bamsignals_amd.synth import synth_ranges
+    from oracle import oracle_c
+    gpu, orc, cols, _, _ = synth["se"]
+    rg = synth_ranges(3000, 700, cols["ref_len"], seed=99, jitter=300)
+
+    def per_tile(plan):
+        st = plan.stats()
+        assert 1024 <= st["n_items"] < 32768
+        return (st["algorithmic_bytes"] - 4 * st["cells"]) / st["n_items"]
+
+    for mode, a in ((_lib.MODE_PROFILE, dict(binsize=1, ss=True)), (_lib.MODE_COUNT, dict(binsize=-1, ss=True)),
+                    (_lib.MODE_PROFILE, dict(binsize=40)), (_lib.MODE_COVERAGE, dict())):
+        want, _ = (oracle_c.coverage_core if mode == _lib.MODE_COVERAGE else oracle_c.pileup_core)(orc, rg, **a)
+        asked = {}
+        for runs_before_asking in (0, 1, 3):
+            plan = Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(mode, **a))
+            for run in range(runs_before_asking):
+                assert np.array_equal(plan.run_host(), want), (mode, a, run)
+            asked[runs_before_asking] = per_tile(plan)
+            for run in range(3):
+                assert np.array_equal(plan.run_host(), want), (mode, a, "after asking", run)
+            plan.close()
+        # before any run: the fused form's bytes (the index entries); once it has run: the kept windows' (48 B a tile)
+        assert asked[1] == asked[3] != asked[0], (mode, a, asked)
+    monkeypatch.setenv("BAMSIGNALS_CACHE_WINDOWS", "0")                  # nothing is kept: nothing to run again for
+    plan = Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=1, ss=True))
+    for run in range(2):
+        plan.run_host()
+    assert per_tile(plan) == asked_fused(ctx, gpu, rg)
+    plan.close()
+
+
+def asked_fused(ctx, gpu, rg):
+    """per-tile algorithmic bytes (without the cells) of a fresh plan of bamProfile binsize=1 ss=TRUE: the fused form's"""
+    from bamsignals_amd import _lib
+    from bamsignals_amd.device import Plan, make_params
+    plan = Plan(ctx, gpu, rg["rid"], rg["loc"], rg["len"], rg["strand"], make_params(_lib.MODE_PROFILE, binsize=1, ss=True))
+    st = plan.stats()
+    plan.close()
+    return (st["algorithmic_bytes"] - 4 * st["cells"]) / st["n_items"]
+
+
 @pytest.mark.parametrize("which,cases", [("se", PILEUP_CASES), ("pe", PE_CASES)])
 def test_pileup_vs_oracle(ctx, synth, which, cases):
     from oracle import oracle_c
