@@ -297,10 +297,11 @@ static bool plan_two_launches(const bsig_plan *p)
     if (g_resolve_min_override >= 0) return p->n_items > 0 && p->n_items >= g_resolve_min_override;
     if (p->n_items >= resolve_min && p->kernel_mode != BSIG_MODE_COUNT) return p->n_items > 0;
     // Those figures are for a step that pays the lookup launch.  A plan that is run a second time is a resident one, and
-    // with the windows kept its later steps pay nothing for them: from its second run on a plan of 1,024 tiles and more
-    // takes the form for resolved windows too (config 2, 10,000 tiles: 19.56 -> 18.30 us a step; its second run carries
-    // the lookup launch, a plan that is run once -- every file-level call -- never sees it).
-    static const int64_t again_min = getenv("BAMSIGNALS_RESOLVE_AGAIN_MIN_TILES") ? atoll(getenv("BAMSIGNALS_RESOLVE_AGAIN_MIN_TILES")) : (int64_t)1024;
+    // with the windows kept its later steps pay nothing for them: from its second run on a plan takes the form for
+    // resolved windows whatever its size -- a workgroup's life is one dependent memory trip shorter -- (10,000 tiles: 19.56
+    // -> 18.30 us a step; 4,000: 10.08 -> 9.37; 1,500: 6.76 -> 5.57; 400: 5.58 -> 4.62; 100: 5.29 -> 4.35; its second
+    // run carries the lookup launch, a plan that is run once -- every file-level call -- never sees it).
+    static const int64_t again_min = getenv("BAMSIGNALS_RESOLVE_AGAIN_MIN_TILES") ? atoll(getenv("BAMSIGNALS_RESOLVE_AGAIN_MIN_TILES")) : (int64_t)1;
     return windows_kept() && p->runs >= 1 && p->n_items >= again_min;
 }
 
